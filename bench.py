@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Benchmark of the message-passing hot path (message + aggregate + update) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5] [--mode fwd|train]
+
+One process per GPU (N>1: launched by torch.distributed.run, RCCL backend).  A "step" is one pass
+of the hot path over one resident batch: T message-passing rounds of
+EdgeNetwork message -> AdjMsgAgg -> GRUUpdate through models.basic_model.BasicModel
+(`--mode train` adds the backward pass and the RCCL gradient all-reduce).  Inputs are resident
+in HBM before the timed region.  Molecules shard by graph: every rank holds its own 100k-molecule
+batch (weak scaling), no data-path collective.
+
+Prints ONE JSON line (rank 0) with the whole-job edges/s, the aggregator's live-measured roofline
+figures and, at N=1, the CPU baseline (the oracle's dense restatement of the reference path) timed
+on this host's cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+WORKLOADS = {
+    # name: (mols per GPU, hidden, MP steps, size distribution, description)
+    "c2": (100_000, 64, 3, "drug", "100k synthetic mols/GPU, ~30 atoms/60 edges, hidden=64, 3 MP steps, sum aggregator"),
+    "c4": (125_000, 128, 3, "drug", "125k synthetic mols/GPU (1M over 8), hidden=128, 3 MP steps"),
+    "c5": (50_000, 256, 3, "skewed", "50k mols 10-200 atoms, preferential attachment, hidden=256"),
+    "tiny": (2_000, 64, 3, "drug", "2k mols (plumbing check)"),
+}
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="fwd", choices=["fwd", "train"])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(mb, hidden, steps, mode, budget_s):
+    """The oracle's dense padded CPU path (== the reference's op sequence, validated against the
+    reference's own outputs in tests/test_oracle_golden.py), batches of 16 molecules (the
+    reference's batch size, test_lipo.py:150), all host cores, until `budget_s` is spent."""
+    from mpnn_amd import synth
+    from mpnn_amd.models.basic_model import BasicModel      # parameters only: same init as the GPU model
+    from oracle import dense_ref as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(317)
+    model = BasicModel(hidden, 4, hidden, 50, 8, message_opts={}, agg_opts={}, update_opts={}, readout_opts={},
+                       message_steps=steps)
+    params = {k: v.detach().clone().requires_grad_(mode == "train") for k, v in model.state_dict().items()}
+    mfp, ufp = O.sub(params, "mf."), O.sub(params, "uf.")
+    edges = 0
+    nb = 0
+    t0 = time.perf_counter()
+    for b0 in range(0, mb.num_mols - 16, 16):
+        d = synth.to_dense(synth.select(mb, np.arange(b0, b0 + 16)))
+        afm, bfm, adj, mask = (torch.from_numpy(d[k]) for k in ("afm", "bfm", "adj", "mask"))
+        ctx = torch.enable_grad() if mode == "train" else torch.no_grad()
+        with ctx:
+            h = afm
+            for i in range(steps):
+                # per step: message (edge_embed reused after step 0, as reuse_graph_tensors does) -> sum -> GRU
+                if i == 0:
+                    A = O.edge_matrices(mfp, bfm, hidden, hidden)
+                pair = torch.einsum("bijmn,bjn->bijm", A, afm)
+                h = O.gru_update(ufp, O.agg_adj(pair, adj), h, mask)
+            if mode == "train":
+                h.sum().backward()
+        edges += int(adj.sum().item()) * steps
+        nb += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": edges / dt, "unit": "edges/s", "cores": cores, "kind": "port",
+            "sample": "%d batches of 16 molecules of the same synthetic set, dense padded torch-CPU path, "
+                      "%s, %.1f s" % (nb, "forward+backward" if mode == "train" else "forward", dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    from mpnn_amd import ops, synth
+    from mpnn_amd.graph import MolGraph
+    from mpnn_amd.models.basic_model import BasicModel
+
+    mols, hidden, T, dist_name, desc = WORKLOADS[args.workload]
+    mb = synth.make_molecules(mols, hidden, seed=317 + rank, dist=dist_name, edge_features=4)
+    graph = MolGraph.from_molbatch(mb, dev)
+    afm = torch.from_numpy(mb.atom_feat).to(dev)
+    mask = torch.ones(mb.num_atoms, 1, device=dev)
+    V, E = graph.num_nodes, graph.num_edges
+    graph.order, graph.type_ptr                          # index arrays built once, outside the timed region
+    if args.mode == "train":
+        graph.transpose, graph.edge_dst
+
+    torch.manual_seed(317)                               # same weights on every rank
+    model = BasicModel(hidden, 4, hidden, 50, 8, message_opts={}, agg_opts={}, update_opts={}, readout_opts={},
+                       message_steps=T).to(dev)
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def step():
+        if args.mode == "fwd":
+            with torch.no_grad():
+                state, _ = model.message_passing(afm, graph, graph, mask)
+            return state
+        for p in params:
+            p.grad = None
+        state, _ = model.message_passing(afm, graph, graph, mask)
+        state.sum().backward()
+        if dist is not None:
+            flat = torch.cat([p.grad.reshape(-1) for p in params if p.grad is not None])
+            dist.all_reduce(flat)                        # one RCCL all-reduce of the flat gradient bucket
+        return state
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    timer = ops.KernelTimer(["segsum", "edge_message", "gru_update"])
+    ops.set_kernel_timer(timer)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    ops.set_kernel_timer(None)
+
+    t_max = torch.tensor([dt], device=dev, dtype=torch.float64)
+    edges = torch.tensor([float(E)], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(edges)
+    dt = float(t_max.item())
+    total_edges = float(edges.item())
+
+    if rank == 0:
+        F = hidden
+        seg_ms = timer.mean_ms("segsum")
+        alg_bytes = 4.0 * F * (E + V) + 4.0 * (V + 1) + 4.0 * E     # msg rows + out rows + row_ptr + edge weights
+        achieved = alg_bytes / (seg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "edges/sec (message+aggregate+update)",
+            "value": total_edges * T * args.steps / dt,
+            "unit": "edges/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "%s: %s" % (args.workload, desc), "mode": args.mode, "mols_per_gpu": mols,
+                       "atoms_per_gpu": V, "edges_per_gpu": E, "hidden": hidden, "mp_steps": T,
+                       "edge_features": 4, "edge_types": graph.num_types, "parallelism": "dp%d" % world,
+                       "edges_counted": "directed edges x MP steps per pass"},
+            "roofline": {"kernel": "segsum_kernel (aggregator, mpnn_segsum_f32)", "bound": "hbm",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "avg_launch_ms": seg_ms, "algorithmic_bytes_per_launch": alg_bytes},
+            "kernels_ms": {k: timer.mean_ms(k) for k in ("edge_message", "segsum", "gru_update")},
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(mb, hidden, T, args.mode, args.cpu_seconds)
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

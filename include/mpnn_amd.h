@@ -1,0 +1,134 @@
+/*
+ * mpnn_amd -- C ABI of the MI355X (gfx950) message-passing hot path.
+ *
+ * The reference (hochshi/mpnn) has no FFI: its hot path is three families of Python
+ * nn.Module operators lowered to ATen ops.  Each entry point below replaces the ATen
+ * call sequence of one reference operator; the citation after "replaces:" is the
+ * reference file:line (relative to the reference root) whose arithmetic it performs.
+ *
+ * Conventions (every function):
+ *   - all data pointers are DEVICE pointers owned by the caller; fp32 data, int32 indices;
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued, never synchronised;
+ *   - no allocation, no host<->device copy, no global state except the last-error string;
+ *   - re-entrant; returns 0 on success, a negative MPNN_E* code on a rejected call;
+ *   - row-major, densely packed arrays; "V" = atoms (rows of node arrays), "E" = directed
+ *     edges sorted by destination atom (CSR: row_ptr[V+1], col_idx[E] = source atom).
+ *
+ * Python binds these with ctypes (mpnn_amd/_lib.py); see INTEGRATION.md for the stub a
+ * maintainer of the reference would add.
+ */
+#ifndef MPNN_AMD_H
+#define MPNN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPNN_OK 0
+#define MPNN_EINVAL (-1)   /* bad argument (null pointer, negative size, unsupported width) */
+#define MPNN_ELAUNCH (-2)  /* the HIP runtime rejected a launch (see mpnn_last_error_string) */
+#define MPNN_EWORKSPACE (-3) /* workspace too small */
+
+#define MPNN_MAX_FEATURES 512   /* largest nf / mf any kernel accepts */
+
+/* ABI version: major*10000 + minor*100 + patch. */
+int mpnn_version(void);
+/* Message for the last non-zero return on the calling thread ("" if none). */
+const char* mpnn_last_error_string(void);
+
+/* ------------------------------------------------------------------ graph build ---- */
+/*
+ * Dense padded batch -> CSR by destination, in exactly the order adj.nonzero() yields
+ * (lexicographic (b,i,j)); replaces: the implicit all-pairs iteration of
+ * mpnn_functions/message/edge_network.py:34-38 and the adj multiply of
+ * mpnn_functions/message_aggregators/adjacent_message_agg.py:18.
+ *   adj  [rows, cols]      (rows = B*N, cols = N), may be NULL
+ *   bfm  [rows, cols, ef]  may be NULL (ef ignored then)
+ * A pair (row, j) is an edge when adj != 0 or any of its ef bond features != 0.
+ * Step 1 writes row_ptr[rows+1] (row_ptr[rows] = E, device side); the caller reads E,
+ * allocates, and calls step 2.  Node ids are flat padded ids: source = (row/cols)*cols + j.
+ */
+size_t mpnn_csr_workspace_bytes(int64_t rows);
+int mpnn_csr_count(const float* adj, const float* bfm, int64_t rows, int cols, int ef,
+                   int32_t* row_ptr, void* workspace, size_t workspace_bytes, void* stream);
+int mpnn_csr_fill(const float* adj, const float* bfm, int64_t rows, int cols, int ef,
+                  const int32_t* row_ptr, int32_t* col_idx,
+                  float* edge_weight /* [E] adj value (1 if adj NULL), may be NULL */,
+                  float* edge_feat   /* [E, ef] gathered bfm rows, may be NULL */,
+                  void* stream);
+
+/* ------------------------------------------------------------------ message -------- */
+/*
+ * Typed edge message: msg[e, :] = A[type[e]] (mf x nf) . h[src[e], :]
+ * replaces: mpnn_functions/message/edge_network.py:40,52 (per-pair form),
+ *           :50 (the bmm), mpnn_functions/message/ggnn_msg_pass.py:19-31.
+ * Edges are visited in type-sorted order so one tile multiplies by one matrix:
+ *   order[E]     edge ids stably sorted by type
+ *   type_ptr[K+1] start of each type's run inside `order`
+ *   gate         optional [E, nf]: msg = A . (gate[e] * h[src[e]])  (AttEdgeNetwork,
+ *                mpnn_functions/message/att_edge_network.py:26-31), may be NULL
+ */
+int mpnn_edge_message_f32(const float* h, const float* A, const int32_t* src,
+                          const int32_t* order, const int32_t* type_ptr, const float* gate,
+                          float* msg, int64_t V, int64_t E, int K, int nf, int mf, void* stream);
+/* Backward of the above for d(msg):
+ *   dx[e, :] = A[type[e]]^T . dmsg[e, :]   (E x nf; multiplied by gate / scattered by caller kernels)
+ *   dA[k]   += sum_{e in type k} dmsg[e] (x) x[e]     (K x mf x nf, must be zeroed by the caller)
+ */
+int mpnn_edge_message_bwd_f32(const float* h, const float* A, const int32_t* src,
+                              const int32_t* order, const int32_t* type_ptr, const float* gate,
+                              const float* dmsg, float* dx, float* dA,
+                              int64_t V, int64_t E, int K, int nf, int mf, void* stream);
+
+/* ------------------------------------------------------------------ aggregator ----- */
+/*
+ * out[i, :] = sum_{e in row i} w[e] * msg[e, :]      (w == NULL: plain sum)
+ * replaces: mpnn_functions/message_aggregators/adjacent_message_agg.py:18 and, with the
+ * caller's weights, weighted_adjacent_message_agg.py:20 / attention_message_agg.py:24.
+ * Summation order inside a row is edge order (deterministic).
+ */
+int mpnn_segsum_f32(const float* msg, const int32_t* row_ptr, const float* w, float* out,
+                    int64_t V, int F, void* stream);
+/* dmsg[e, :] = w[e] * dout[row(e), :] */
+int mpnn_segsum_bwd_f32(const float* dout, const int32_t* row_ptr, const float* w, float* dmsg,
+                        int64_t V, int F, void* stream);
+/*
+ * Gathered variant: out[i, :] = sum_{e in row i} w[e] * x[idx[e], :]  -- used for the
+ * transposed scatter of the backward pass (idx = edge ids sorted by source) and for
+ * per-molecule sums (graph_ptr as row_ptr, idx NULL).
+ */
+int mpnn_segsum_gather_f32(const float* x, const int32_t* row_ptr, const int32_t* idx,
+                           const float* w, float* out, int64_t V, int F, void* stream);
+
+/* ------------------------------------------------------------------ update --------- */
+/*
+ * Masked GRU cell, gate order r,z,n, weights stored (in, 3H) as the reference does:
+ *   gi = m W_ih + b_ih ; gh = h W_hh + b_hh
+ *   r = sigmoid(gi_r+gh_r)*mask ; z = sigmoid(gi_z+gh_z)*mask ; n = tanh(gi_n + r*gh_n)*mask
+ *   out = ((1-z)*n + z*h) * mask
+ * replaces: mpnn_functions/update/gru_update.py:26-35 and :66-68.
+ *   m [V,H], h [V,H], mask [V], W_ih [H,3H], W_hh [H,3H], b_ih [3H], b_hh [3H], out [V,H]
+ *   saved: optional [V,4H] = (r, z, n, gh_n) kept for the backward pass, may be NULL
+ */
+int mpnn_gru_update_f32(const float* m, const float* h, const float* mask,
+                        const float* W_ih, const float* W_hh, const float* b_ih, const float* b_hh,
+                        float* out, float* saved, int64_t V, int H, void* stream);
+/*
+ * Backward: given dout [V,H] and `saved`, writes dm [V,H], dh [V,H] and ACCUMULATES into
+ * dW_ih, dW_hh [H,3H], db_ih, db_hh [3H] (caller zeroes them).  `workspace` holds the
+ * pre-activation gradients [V,6H] (dgi | dgh); see mpnn_gru_bwd_workspace_bytes.
+ */
+size_t mpnn_gru_bwd_workspace_bytes(int64_t V, int H);
+int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const float* h, const float* mask,
+                            const float* W_ih, const float* W_hh, const float* saved,
+                            float* dm, float* dh, float* dW_ih, float* dW_hh,
+                            float* db_ih, float* db_hh, void* workspace, size_t workspace_bytes,
+                            int64_t V, int H, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPNN_AMD_H */

@@ -1,0 +1,58 @@
+"""Build libmpnn_amd.so (the C-ABI library) in-tree with hipcc for gfx950.
+
+    python -m mpnn_amd.build [--force]
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the resulting
+.so travels to the GPU box with the source snapshot.
+"""
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libmpnn_amd.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
+         "-fno-fast-math"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "mpnn_amd.h")]
+    return any(os.path.getmtime(p) > t for p in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source into one shared object; returns its path."""
+    if not force and not _stale():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libmpnn_amd.so (and there is no CPU fallback)")
+    os.makedirs(LIBDIR, exist_ok=True)
+    tmp = LIB + ".tmp"
+    cmd = [hipcc] + FLAGS + ["-o", tmp] + sources()
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("hipcc failed building libmpnn_amd.so")
+    if verbose and r.stderr:
+        sys.stderr.write(r.stderr)
+    os.replace(tmp, LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

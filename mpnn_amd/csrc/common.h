@@ -1,0 +1,42 @@
+// Shared host/device helpers for the gfx950 kernels.  CDNA4 only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/mpnn_amd.h"
+
+namespace mpnn {
+
+constexpr int kWave = 64;
+constexpr int kNumXcd = 8;     // MI355X: 8 XCDs, private L2 each; blocks b and b+8 share an XCD
+
+void set_error(const char* fmt, ...);
+
+inline int launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return MPNN_ELAUNCH;
+    }
+    return MPNN_OK;
+}
+
+#define MPNN_REQUIRE(cond, ...)              \
+    do {                                     \
+        if (!(cond)) {                       \
+            ::mpnn::set_error(__VA_ARGS__);  \
+            return MPNN_EINVAL;              \
+        }                                    \
+    } while (0)
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// 32x32 accumulator tile of v_mfma_f32_32x32x2_f32: register `reg` of lane `lane`
+// holds element (row, col) = ((reg&3) + 8*(reg>>2) + 4*(lane>>5), lane&31).
+__device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+}  // namespace mpnn

@@ -1,0 +1,167 @@
+// Masked GRU node update, fused: two fp32-MFMA GEMMs + gate epilogue in one kernel.
+//
+//   gi = m W_ih + b_ih ; gh = h W_hh + b_hh            (W stored (H, 3H), gate order r,z,n)
+//   r = sig(gi_r+gh_r)*mask ; z = sig(gi_z+gh_z)*mask ; n = tanh(gi_n + r*gh_n)*mask
+//   out = ((1-z)*n + z*h) * mask
+//
+// 12*H^2 flops per atom against 12*H bytes: matrix-core bound for H >= 64 (fp32 MFMA, exact).
+//
+// Tiling: a block owns 128 atoms x 32 hidden columns of ALL gates, so a wave (32 atoms) keeps
+// four 32x32 accumulators -- r, z, gi_n, gh_n for the same (atom, column) elements in the same
+// lane/register -- and the gate math needs no cross-wave exchange.  r and z accumulate the m-
+// and h-products into one accumulator (K = 2H), gi_n / gh_n stay apart because of r*gh_n.
+// Blocks that share an atom tile (the H/32 column slices) are dealt to the same XCD so the
+// tile's second read hits that XCD's L2.
+#include "common.h"
+
+namespace mpnn {
+
+constexpr int kRows = 128;
+constexpr int kKC = 64;
+constexpr int kLDX = kKC + 4;     // Xs row stride (floats): conflict-free ds_read_b128
+constexpr int kLDB = 96;          // Bs row stride: 3 gates x 32 columns, k-major
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// acc{0,1,2} += X[128 x KC] . W[k0:k0+KC, {0,H,2H}+c0 : +32]
+__device__ __forceinline__ void gru_gemm_pass(const float* __restrict__ X, const float* __restrict__ W,
+                                              float* Xs, float* Bs, int64_t i0, int64_t V, int H, int c0, bool vec,
+                                              f32x16& acc0, f32x16& acc1, f32x16& acc2) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int c4 = tid & 15, r0 = tid >> 4;
+    const int r = lane & 31, hi = lane >> 5;
+    for (int k0 = 0; k0 < H; k0 += kKC) {
+        __syncthreads();   // previous pass finished reading Xs/Bs
+        const int k = k0 + 4 * c4;
+#pragma unroll
+        for (int p = 0; p < kRows / 16; ++p) {
+            const int row = r0 + 16 * p;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (i0 + row < V) {
+                const float* src = X + (i0 + row) * H + k;
+                if (vec) {
+                    if (k < H) v = *reinterpret_cast<const f32x4*>(src);
+                } else {
+                    if (k + 0 < H) v.x = src[0];
+                    if (k + 1 < H) v.y = src[1];
+                    if (k + 2 < H) v.z = src[2];
+                    if (k + 3 < H) v.w = src[3];
+                }
+            }
+            *reinterpret_cast<f32x4*>(Xs + row * kLDX + 4 * c4) = v;
+        }
+#pragma unroll
+        for (int p = 0; p < (kKC * 24) / 256; ++p) {
+            const int idx = tid + 256 * p;
+            const int kk = idx / 24, q = idx % 24, g = q >> 3, j4 = q & 7;
+            const int col = c0 + 4 * j4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k0 + kk < H) {
+                const float* src = W + (int64_t)(k0 + kk) * 3 * H + g * H + col;
+                if (vec) {
+                    if (col < H) v = *reinterpret_cast<const f32x4*>(src);
+                } else {
+                    if (col + 0 < H) v.x = src[0];
+                    if (col + 1 < H) v.y = src[1];
+                    if (col + 2 < H) v.z = src[2];
+                    if (col + 3 < H) v.w = src[3];
+                }
+            }
+            *reinterpret_cast<f32x4*>(Bs + kk * kLDB + g * 32 + 4 * j4) = v;
+        }
+        __syncthreads();
+        if (i0 + 32 * wv < V) {
+            const float* xa = Xs + (32 * wv + r) * kLDX + hi * (kKC / 2);
+            const float* xb = Bs + hi * (kKC / 2) * kLDB + r;
+#pragma unroll
+            for (int kq = 0; kq < kKC / 8; ++kq) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(xa + 4 * kq);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float* bp = xb + (4 * kq + c) * kLDB;
+                    const float av = a[c];
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[0], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[32], acc1, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[64], acc2, 0, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) gru_update_kernel(const float* __restrict__ m, const float* __restrict__ h,
+                                                         const float* __restrict__ mask,
+                                                         const float* __restrict__ W_ih, const float* __restrict__ W_hh,
+                                                         const float* __restrict__ b_ih, const float* __restrict__ b_hh,
+                                                         float* __restrict__ out, float* __restrict__ saved, int64_t V,
+                                                         int H, int row_tiles, int col_slices) {
+    __shared__ __attribute__((aligned(16))) float Xs[kRows * kLDX];
+    __shared__ __attribute__((aligned(16))) float Bs[kKC * kLDB];
+
+    // XCD-aware placement: blocks b and b+8 share an XCD (speed only, never correctness)
+    const int xcd = blockIdx.x % kNumXcd, slot = blockIdx.x / kNumXcd;
+    const int cs = slot % col_slices;
+    const int rt = (slot / col_slices) * kNumXcd + xcd;
+    if (rt >= row_tiles) return;   // uniform per block
+    const int64_t i0 = (int64_t)rt * kRows;
+    const int c0 = cs * 32;
+    const bool vec = (H & 3) == 0;
+
+    f32x16 acc_r, acc_z, acc_ni, acc_nh;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc_r[i] = 0.f; acc_z[i] = 0.f; acc_ni[i] = 0.f; acc_nh[i] = 0.f; }
+
+    gru_gemm_pass(m, W_ih, Xs, Bs, i0, V, H, c0, vec, acc_r, acc_z, acc_ni);
+    gru_gemm_pass(h, W_hh, Xs, Bs, i0, V, H, c0, vec, acc_r, acc_z, acc_nh);
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int col = c0 + (lane & 31);
+    if (col >= H) return;
+    const float br = b_ih[col] + b_hh[col];
+    const float bz = b_ih[H + col] + b_hh[H + col];
+    const float bni = b_ih[2 * H + col], bnh = b_hh[2 * H + col];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int64_t row = i0 + 32 * wv + acc_row(i, lane);
+        if (row >= V) continue;
+        const float mk = mask ? mask[row] : 1.0f;
+        const float hv = h[row * H + col];
+        const float r = sigmoidf_(acc_r[i] + br) * mk;
+        const float z = sigmoidf_(acc_z[i] + bz) * mk;
+        const float nh = acc_nh[i] + bnh;
+        const float n = tanhf(acc_ni[i] + bni + r * nh) * mk;
+        out[row * H + col] = ((1.0f - z) * n + z * hv) * mk;
+        if (saved) {
+            float* sv = saved + row * 4 * H + col;
+            sv[0] = r;
+            sv[H] = z;
+            sv[2 * H] = n;
+            sv[3 * H] = nh;
+        }
+    }
+}
+
+}  // namespace mpnn
+
+using namespace mpnn;
+
+extern "C" int mpnn_gru_update_f32(const float* m, const float* h, const float* mask, const float* W_ih,
+                                   const float* W_hh, const float* b_ih, const float* b_hh, float* out, float* saved,
+                                   int64_t V, int H, void* stream) {
+    MPNN_REQUIRE(V >= 0 && H > 0 && H <= MPNN_MAX_FEATURES, "mpnn_gru_update_f32: V=%lld H=%d out of range",
+                 (long long)V, H);
+    if (V == 0) return MPNN_OK;
+    MPNN_REQUIRE(m && h && W_ih && W_hh && b_ih && b_hh && out, "mpnn_gru_update_f32: NULL buffer");
+    if ((H & 3) == 0) {
+        const uintptr_t al = reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(h) |
+                             reinterpret_cast<uintptr_t>(W_ih) | reinterpret_cast<uintptr_t>(W_hh);
+        MPNN_REQUIRE(al % 16 == 0, "mpnn_gru_update_f32: buffers must be 16-byte aligned");
+    }
+    const int64_t row_tiles = ceil_div(V, kRows);
+    MPNN_REQUIRE(row_tiles < (1 << 24), "mpnn_gru_update_f32: V too large for one launch");
+    const int col_slices = (H + 31) / 32;
+    const int64_t blocks = ceil_div(row_tiles, kNumXcd) * kNumXcd * col_slices;
+    hipLaunchKernelGGL(gru_update_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, m, h, mask, W_ih,
+                       W_hh, b_ih, b_hh, out, saved, V, H, (int)row_tiles, col_slices);
+    return launch_status("mpnn_gru_update_f32");
+}

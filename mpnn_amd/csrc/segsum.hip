@@ -1,0 +1,201 @@
+// Neighbour aggregation: segmented sum over destination-sorted edge rows.
+//
+//   out[i,:] = sum_{e in [row_ptr[i], row_ptr[i+1])} w[e] * msg[e,:]
+//
+// HBM-bound: every message row is read once, every output row written once.
+// Algorithmic bytes per launch = 4*F*(E+V) + 4*(V+1) (+4*E with weights).
+//
+// Mapping: a row of F floats is covered by LPR lanes x VEC floats (16 lanes x float4 at
+// F=64), so one wave64 reduces 64/LPR destination atoms side by side.  Edges of one atom
+// are contiguous (CSR by destination) and atoms of one wave are adjacent, so the wave's
+// loads walk one contiguous span of `msg`.  The edge loop is unrolled x4 with the adds kept
+// in edge order, which keeps the sum deterministic and order-identical to a serial loop.
+#include "common.h"
+
+namespace mpnn {
+
+template <int VEC>
+struct Row;
+template <>
+struct Row<4> {
+    f32x4 v;
+    __device__ __forceinline__ void zero() { v = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const f32x4*>(p); }
+    __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<f32x4*>(p) = v; }
+    __device__ __forceinline__ void fma(const Row& o, float s) { v += o.v * s; }
+    __device__ __forceinline__ void add(const Row& o) { v += o.v; }
+    __device__ __forceinline__ void scale(float s) { v *= s; }
+};
+template <>
+struct Row<1> {
+    float v;
+    __device__ __forceinline__ void zero() { v = 0.f; }
+    __device__ __forceinline__ void load(const float* p) { v = *p; }
+    __device__ __forceinline__ void store(float* p) const { *p = v; }
+    __device__ __forceinline__ void fma(const Row& o, float s) { v += o.v * s; }
+    __device__ __forceinline__ void add(const Row& o) { v += o.v; }
+    __device__ __forceinline__ void scale(float s) { v *= s; }
+};
+
+// GATHER: message row of edge e is x[idx[e]] (idx may be NULL => e)
+template <int VEC, int LPR, bool GATHER>
+__global__ void __launch_bounds__(256) segsum_kernel(const float* __restrict__ msg, const int32_t* __restrict__ row_ptr,
+                                                     const int32_t* __restrict__ idx, const float* __restrict__ w,
+                                                     float* __restrict__ out, int64_t V, int F) {
+    constexpr int GPB = 256 / LPR;                  // destination atoms per block pass
+    const int lig = threadIdx.x % LPR;              // lane inside the row group
+    const int grp = threadIdx.x / LPR;
+    for (int64_t i = (int64_t)blockIdx.x * GPB + grp; i < V; i += (int64_t)gridDim.x * GPB) {
+        const int e0 = row_ptr[i], e1 = row_ptr[i + 1];
+        for (int c = lig * VEC; c < F; c += LPR * VEC) {
+            Row<VEC> acc;
+            acc.zero();
+            int e = e0;
+            for (; e + 4 <= e1; e += 4) {
+                Row<VEC> r0, r1, r2, r3;
+                int64_t s0 = e, s1 = e + 1, s2 = e + 2, s3 = e + 3;
+                if (GATHER && idx) { s0 = idx[e]; s1 = idx[e + 1]; s2 = idx[e + 2]; s3 = idx[e + 3]; }
+                r0.load(msg + s0 * F + c);
+                r1.load(msg + s1 * F + c);
+                r2.load(msg + s2 * F + c);
+                r3.load(msg + s3 * F + c);
+                if (w) {
+                    acc.fma(r0, w[e]); acc.fma(r1, w[e + 1]); acc.fma(r2, w[e + 2]); acc.fma(r3, w[e + 3]);
+                } else {
+                    acc.add(r0); acc.add(r1); acc.add(r2); acc.add(r3);
+                }
+            }
+            for (; e < e1; ++e) {
+                Row<VEC> r;
+                int64_t s = e;
+                if (GATHER && idx) s = idx[e];
+                r.load(msg + s * F + c);
+                if (w) acc.fma(r, w[e]); else acc.add(r);
+            }
+            acc.store(out + i * F + c);
+        }
+    }
+}
+
+template <int VEC, int LPR>
+__global__ void __launch_bounds__(256) segsum_bwd_kernel(const float* __restrict__ dout,
+                                                         const int32_t* __restrict__ row_ptr,
+                                                         const float* __restrict__ w, float* __restrict__ dmsg,
+                                                         int64_t V, int F) {
+    constexpr int GPB = 256 / LPR;
+    const int lig = threadIdx.x % LPR;
+    const int grp = threadIdx.x / LPR;
+    for (int64_t i = (int64_t)blockIdx.x * GPB + grp; i < V; i += (int64_t)gridDim.x * GPB) {
+        const int e0 = row_ptr[i], e1 = row_ptr[i + 1];
+        for (int c = lig * VEC; c < F; c += LPR * VEC) {
+            Row<VEC> g;
+            g.load(dout + i * F + c);
+            for (int e = e0; e < e1; ++e) {
+                Row<VEC> r = g;
+                if (w) r.scale(w[e]);
+                r.store(dmsg + (int64_t)e * F + c);
+            }
+        }
+    }
+}
+
+static int pick_lpr(int F, int vec) {
+    int need = (F + vec - 1) / vec;   // lanes to cover a row in one pass
+    int lpr = 4;
+    while (lpr < need && lpr < 64) lpr <<= 1;
+    return lpr;
+}
+
+static int grid_for(int64_t V, int lpr) {
+    int64_t g = ceil_div(V, 256 / lpr);
+    const int64_t cap = 256 * 16;   // 16 blocks of 4 waves per CU, grid-stride beyond
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+template <bool GATHER>
+static int launch_segsum(const float* msg, const int32_t* row_ptr, const int32_t* idx, const float* w, float* out,
+                         int64_t V, int F, hipStream_t s) {
+    const bool v4 = (F % 4 == 0) && ((reinterpret_cast<uintptr_t>(msg) | reinterpret_cast<uintptr_t>(out)) % 16 == 0);
+    const int lpr = pick_lpr(F, v4 ? 4 : 1);
+    const dim3 grid(grid_for(V, lpr)), block(256);
+#define MPNN_SEGSUM_CASE(VEC, LPR)                                                                              \
+    hipLaunchKernelGGL((segsum_kernel<VEC, LPR, GATHER>), grid, block, 0, s, msg, row_ptr, idx, w, out, V, F); \
+    break;
+    if (v4) {
+        switch (lpr) {
+            case 4: MPNN_SEGSUM_CASE(4, 4)
+            case 8: MPNN_SEGSUM_CASE(4, 8)
+            case 16: MPNN_SEGSUM_CASE(4, 16)
+            case 32: MPNN_SEGSUM_CASE(4, 32)
+            default: MPNN_SEGSUM_CASE(4, 64)
+        }
+    } else {
+        switch (lpr) {
+            case 4: MPNN_SEGSUM_CASE(1, 4)
+            case 8: MPNN_SEGSUM_CASE(1, 8)
+            case 16: MPNN_SEGSUM_CASE(1, 16)
+            case 32: MPNN_SEGSUM_CASE(1, 32)
+            default: MPNN_SEGSUM_CASE(1, 64)
+        }
+    }
+#undef MPNN_SEGSUM_CASE
+    return launch_status("mpnn_segsum");
+}
+
+}  // namespace mpnn
+
+using namespace mpnn;
+
+extern "C" int mpnn_segsum_f32(const float* msg, const int32_t* row_ptr, const float* w, float* out, int64_t V, int F,
+                               void* stream) {
+    MPNN_REQUIRE(row_ptr && out && V >= 0, "mpnn_segsum_f32: bad arguments");
+    MPNN_REQUIRE(F > 0 && F <= MPNN_MAX_FEATURES, "mpnn_segsum_f32: F=%d out of range", F);
+    if (V == 0) return MPNN_OK;
+    MPNN_REQUIRE(msg, "mpnn_segsum_f32: msg is NULL");
+    return launch_segsum<false>(msg, row_ptr, nullptr, w, out, V, F, (hipStream_t)stream);
+}
+
+extern "C" int mpnn_segsum_gather_f32(const float* x, const int32_t* row_ptr, const int32_t* idx, const float* w,
+                                      float* out, int64_t V, int F, void* stream) {
+    MPNN_REQUIRE(row_ptr && out && V >= 0, "mpnn_segsum_gather_f32: bad arguments");
+    MPNN_REQUIRE(F > 0 && F <= MPNN_MAX_FEATURES, "mpnn_segsum_gather_f32: F=%d out of range", F);
+    if (V == 0) return MPNN_OK;
+    MPNN_REQUIRE(x, "mpnn_segsum_gather_f32: x is NULL");
+    return launch_segsum<true>(x, row_ptr, idx, w, out, V, F, (hipStream_t)stream);
+}
+
+extern "C" int mpnn_segsum_bwd_f32(const float* dout, const int32_t* row_ptr, const float* w, float* dmsg, int64_t V,
+                                   int F, void* stream) {
+    MPNN_REQUIRE(row_ptr && V >= 0, "mpnn_segsum_bwd_f32: bad arguments");
+    MPNN_REQUIRE(F > 0 && F <= MPNN_MAX_FEATURES, "mpnn_segsum_bwd_f32: F=%d out of range", F);
+    if (V == 0) return MPNN_OK;
+    MPNN_REQUIRE(dout && dmsg, "mpnn_segsum_bwd_f32: NULL buffer");
+    hipStream_t s = (hipStream_t)stream;
+    const bool v4 = (F % 4 == 0) && ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(dmsg)) % 16 == 0);
+    const int lpr = pick_lpr(F, v4 ? 4 : 1);
+    const dim3 grid(grid_for(V, lpr)), block(256);
+#define MPNN_BWD_CASE(VEC, LPR) \
+    hipLaunchKernelGGL((segsum_bwd_kernel<VEC, LPR>), grid, block, 0, s, dout, row_ptr, w, dmsg, V, F); \
+    break;
+    if (v4) {
+        switch (lpr) {
+            case 4: MPNN_BWD_CASE(4, 4)
+            case 8: MPNN_BWD_CASE(4, 8)
+            case 16: MPNN_BWD_CASE(4, 16)
+            case 32: MPNN_BWD_CASE(4, 32)
+            default: MPNN_BWD_CASE(4, 64)
+        }
+    } else {
+        switch (lpr) {
+            case 4: MPNN_BWD_CASE(1, 4)
+            case 8: MPNN_BWD_CASE(1, 8)
+            case 16: MPNN_BWD_CASE(1, 16)
+            case 32: MPNN_BWD_CASE(1, 32)
+            default: MPNN_BWD_CASE(1, 64)
+        }
+    }
+#undef MPNN_BWD_CASE
+    return launch_status("mpnn_segsum_bwd");
+}

@@ -1,0 +1,183 @@
+"""Sparse molecule batch resident in HBM (CSR by destination atom).
+
+Layout (all device tensors, int32 indices, fp32 data):
+
+    row_ptr[V+1]   edges of atom i are [row_ptr[i], row_ptr[i+1])      (destination-sorted)
+    col_idx[E]     source atom of edge e
+    edge_dst[E]    destination atom of edge e (expanded row_ptr; backward + gating)
+    edge_weight[E] adjacency value of the pair (multiplier in AdjMsgAgg,
+                   reference: mpnn_functions/message_aggregators/adjacent_message_agg.py:18)
+    edge_type[E]   row of `type_feat` holding this edge's bond-feature vector
+    type_feat[K,ef] distinct bond-feature rows (the tower is evaluated on K rows, not B*N*N)
+    order[E], type_ptr[K+1]  edge ids stably sorted by type: the tile order of the message kernel
+    graph_ptr[G+1] first atom of each molecule
+    t_row_ptr[V+1], t_eid[E]  the same edges grouped by SOURCE atom (transposed graph, backward)
+
+Two sources: a dense padded batch (the reference's wire format, atoms numbered b*N+i so every
+(B,N,.) tensor is a free view of a (V,.) array), or a compact `synth.MolBatch`.
+"""
+import torch
+
+from . import _lib
+
+
+def _i32(t):
+    return t.to(torch.int32).contiguous()
+
+
+class MolGraph:
+    def __init__(self, row_ptr, col_idx, edge_weight, edge_type, type_feat, graph_ptr, dense_shape=None,
+                 edge_feat=None):
+        self.row_ptr = row_ptr
+        self.col_idx = col_idx
+        self.edge_weight = edge_weight
+        self.edge_type = edge_type
+        self.type_feat = type_feat
+        self.graph_ptr = graph_ptr
+        self.dense_shape = dense_shape          # (B, N) when built from a padded batch
+        self.edge_feat = edge_feat              # (E, ef) raw rows when known
+        self.num_nodes = int(row_ptr.shape[0]) - 1
+        self.num_edges = int(col_idx.shape[0])
+        self.num_types = int(type_feat.shape[0])
+        self.num_graphs = int(graph_ptr.shape[0]) - 1
+        self.device = row_ptr.device
+        self._order = None
+        self._type_ptr = None
+        self._edge_dst = None
+        self._transpose = None
+        self._node_graph = None
+        self._pad_size = None
+
+    # ------------------------------------------------------------------ derived index arrays
+    @property
+    def order(self):
+        if self._order is None:
+            self._build_type_order()
+        return self._order
+
+    @property
+    def type_ptr(self):
+        if self._type_ptr is None:
+            self._build_type_order()
+        return self._type_ptr
+
+    def _build_type_order(self):
+        et = self.edge_type.to(torch.int64)
+        self._order = _i32(torch.sort(et, stable=True).indices)
+        counts = torch.bincount(et, minlength=self.num_types)
+        tp = torch.zeros(self.num_types + 1, dtype=torch.int64, device=self.device)
+        tp[1:] = torch.cumsum(counts, 0)
+        self._type_ptr = _i32(tp)
+
+    @property
+    def edge_dst(self):
+        if self._edge_dst is None:
+            deg = (self.row_ptr[1:] - self.row_ptr[:-1]).to(torch.int64)
+            self._edge_dst = _i32(torch.repeat_interleave(
+                torch.arange(self.num_nodes, device=self.device), deg, output_size=self.num_edges))
+        return self._edge_dst
+
+    @property
+    def transpose(self):
+        """(t_row_ptr, t_eid): edge ids grouped by source atom, stable in edge order."""
+        if self._transpose is None:
+            src = self.col_idx.to(torch.int64)
+            t_eid = _i32(torch.sort(src, stable=True).indices)
+            counts = torch.bincount(src, minlength=self.num_nodes)
+            tp = torch.zeros(self.num_nodes + 1, dtype=torch.int64, device=self.device)
+            tp[1:] = torch.cumsum(counts, 0)
+            self._transpose = (_i32(tp), t_eid)
+        return self._transpose
+
+    @property
+    def node_graph(self):
+        """Molecule id of every atom, int64 (V,)."""
+        if self._node_graph is None:
+            n = (self.graph_ptr[1:] - self.graph_ptr[:-1]).to(torch.int64)
+            self._node_graph = torch.repeat_interleave(
+                torch.arange(self.num_graphs, device=self.device), n, output_size=self.num_nodes)
+        return self._node_graph
+
+    @property
+    def pad_size(self):
+        """Per-atom padded row length N (dense batch: the batch's N; compact batch: its molecule's size)."""
+        if self._pad_size is None:
+            if self.dense_shape is not None:
+                self._pad_size = torch.full((self.num_nodes,), float(self.dense_shape[1]), device=self.device)
+            else:
+                n = (self.graph_ptr[1:] - self.graph_ptr[:-1]).to(torch.float32)
+                self._pad_size = n[self.node_graph]
+        return self._pad_size
+
+    # ------------------------------------------------------------------ constructors
+    @classmethod
+    def from_dense(cls, adj=None, bfm=None):
+        """CSR of the pairs where adj != 0 or any bond feature != 0, in adj.nonzero() order.
+
+        Runs mpnn_csr_count / mpnn_csr_fill; one host read of E in between (allocation size).
+        """
+        lib = _lib.load()
+        ref = adj if adj is not None else bfm
+        if ref is None:
+            raise _lib.MpnnError("from_dense needs adj or bfm")
+        B, N = int(ref.shape[0]), int(ref.shape[1])
+        dev = ref.device
+        ef = int(bfm.shape[-1]) if bfm is not None else 0
+        adj_c = adj.contiguous().float() if adj is not None else None
+        bfm_c = bfm.contiguous().float() if bfm is not None else None
+        rows = B * N
+        row_ptr = torch.empty(rows + 1, dtype=torch.int32, device=dev)
+        ws_bytes = lib.mpnn_csr_workspace_bytes(rows)
+        ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
+        _lib.check(lib.mpnn_csr_count(_lib.fptr(adj_c), _lib.fptr(bfm_c), rows, N, ef, _lib.iptr(row_ptr),
+                                      _lib.ptr(ws), ws_bytes, _lib.stream()), "mpnn_csr_count")
+        E = int(row_ptr[-1].item())
+        col_idx = torch.empty(E, dtype=torch.int32, device=dev)
+        edge_weight = torch.empty(E, dtype=torch.float32, device=dev)
+        edge_feat = torch.empty(E, ef, dtype=torch.float32, device=dev) if bfm is not None else None
+        _lib.check(lib.mpnn_csr_fill(_lib.fptr(adj_c), _lib.fptr(bfm_c), rows, N, ef, _lib.iptr(row_ptr),
+                                     _lib.iptr(col_idx), _lib.fptr(edge_weight), _lib.fptr(edge_feat),
+                                     _lib.stream()), "mpnn_csr_fill")
+        if edge_feat is not None and E > 0:
+            type_feat, inv = torch.unique(edge_feat, dim=0, return_inverse=True)
+            edge_type = _i32(inv)
+        elif edge_feat is not None:
+            type_feat = torch.zeros(1, ef, device=dev)
+            edge_type = torch.zeros(0, dtype=torch.int32, device=dev)
+        else:
+            type_feat = torch.zeros(1, 1, device=dev)
+            edge_type = torch.zeros(E, dtype=torch.int32, device=dev)
+        graph_ptr = torch.arange(0, rows + 1, N, dtype=torch.int32, device=dev)
+        return cls(row_ptr, col_idx, edge_weight, edge_type, type_feat.contiguous(), graph_ptr,
+                   dense_shape=(B, N), edge_feat=edge_feat)
+
+    @classmethod
+    def from_molbatch(cls, mb, device, dedupe=False):
+        """Upload a compact synth.MolBatch.  `dedupe` collapses a continuous batch's per-edge
+        feature rows to distinct rows (reverse edges share a row)."""
+        def up(a, dt):
+            return torch.from_numpy(a).to(device=device, dtype=dt)
+        edge_type = up(mb.bond_type, torch.int32)
+        type_feat = up(mb.type_feat, torch.float32)
+        if dedupe and mb.edge_feat is not None:
+            type_feat, inv = torch.unique(type_feat, dim=0, return_inverse=True)
+            edge_type = _i32(inv)
+        E = mb.num_edges
+        return cls(up(mb.row_ptr, torch.int32), up(mb.col_idx, torch.int32),
+                   torch.ones(E, dtype=torch.float32, device=device), edge_type, type_feat.contiguous(),
+                   up(mb.atom_ptr, torch.int32), dense_shape=None,
+                   edge_feat=(up(mb.edge_feat, torch.float32) if mb.edge_feat is not None else None))
+
+    # ------------------------------------------------------------------ views
+    def node_view(self, x):
+        """(B,N,F) or (V,F) -> contiguous (V,F)."""
+        F = x.shape[-1]
+        x2 = x.reshape(-1, F)
+        if x2.shape[0] != self.num_nodes:
+            raise _lib.MpnnError("node array has %d rows, graph has %d atoms" % (x2.shape[0], self.num_nodes))
+        return x2.contiguous()
+
+    def node_unview(self, x2, like=None):
+        if self.dense_shape is not None:
+            return x2.view(self.dense_shape[0], self.dense_shape[1], x2.shape[-1])
+        return x2

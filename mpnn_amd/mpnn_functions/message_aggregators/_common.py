@@ -1,0 +1,25 @@
+"""Shared plumbing of the three aggregators: turn (messages, adj) into CSR rows + per-edge weights."""
+import torch
+
+from ...graph import MolGraph
+from ...messages import EdgeMessages
+
+
+def edge_adjacency(msgs, adj):
+    """adj value of every member pair of `msgs.graph` (E,)."""
+    g = msgs.graph
+    if isinstance(adj, MolGraph) or adj is None:
+        return g.edge_weight
+    if g.dense_shape is None:
+        raise ValueError("a dense adj tensor cannot be matched to a compact batch")
+    N = g.dense_shape[1]
+    dst = g.edge_dst.to(torch.int64)
+    flat = dst * N + (g.col_idx.to(torch.int64) - (dst // N) * N)
+    return adj.reshape(-1)[flat].contiguous().float()
+
+
+def dense_rows(messages, adj):
+    """A dense (B,N,N,mf) message tensor as CSR with EVERY pair a member (row i = N entries)."""
+    B, N = messages.shape[0], messages.shape[1]
+    row_ptr = torch.arange(0, B * N * N + 1, N, dtype=torch.int32, device=messages.device)
+    return messages.reshape(B * N * N, messages.shape[-1]), row_ptr, (B, N)

@@ -1,0 +1,23 @@
+"""AdjMsgAgg: out_i = sum_j adj_ij * m_ij  -> the destination-sorted segmented sum kernel.
+
+Reference: mpnn_functions/message_aggregators/adjacent_message_agg.py:4-18.  adj values act as
+multipliers (any float), so they ride along as per-edge weights of mpnn_segsum_f32; pairs with
+adj == 0 contribute nothing, hence no non-member correction here.
+"""
+from torch import nn
+
+from ... import ops
+from ...messages import EdgeMessages
+from ._common import dense_rows, edge_adjacency
+
+
+class AdjMsgAgg(nn.Module):
+    def __init__(self, adj_dim, attn_act=None):
+        super().__init__()
+
+    def forward(self, messages, adj):
+        if isinstance(messages, EdgeMessages):
+            g = messages.graph
+            return g.node_unview(ops.segsum(messages.values, g.row_ptr, edge_adjacency(messages, adj)))
+        rows, row_ptr, (B, N) = dense_rows(messages, adj)
+        return ops.segsum(rows, row_ptr, adj.reshape(-1).contiguous().float()).view(B, N, -1)

@@ -1,0 +1,262 @@
+"""torch.autograd bindings of the HIP kernels (the only callers of the C ABI).
+
+Each Function enqueues its kernel on torch's current stream and owns nothing: torch tensors
+are the buffers.  Backward passes call the matching *_bwd kernels.
+"""
+import torch
+
+from . import _lib
+
+
+def _empty(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+class KernelTimer:
+    """Opt-in per-launch timing with HIP events on the launch stream (bench.py's roofline leg).
+    Events are recorded on torch's current stream, which is the stream every kernel here is
+    launched on (`_lib.stream()`)."""
+
+    def __init__(self, names):
+        self.names = set(names)
+        self.events = {n: [] for n in names}
+
+    def launch(self, name, fn):
+        if name not in self.names:
+            return fn()
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        r = fn()
+        b.record()
+        self.events[name].append((a, b))
+        return r
+
+    def mean_ms(self, name):
+        ev = self.events[name]
+        if not ev:
+            return None
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+
+    def reset(self):
+        for v in self.events.values():
+            v.clear()
+
+
+_timer = None
+
+
+def set_kernel_timer(timer):
+    global _timer
+    _timer = timer
+
+
+def _timed(name, fn):
+    return fn() if _timer is None else _timer.launch(name, fn)
+
+
+# --------------------------------------------------------------------------- raw launches
+def segsum_raw(msg, row_ptr, w, num_rows):
+    lib = _lib.load()
+    F = int(msg.shape[-1])
+    out = _empty((num_rows, F), msg)
+    _lib.check(_timed("segsum", lambda: lib.mpnn_segsum_f32(
+        _lib.fptr(msg), _lib.iptr(row_ptr), _lib.fptr(w), _lib.fptr(out), num_rows, F, _lib.stream())),
+        "mpnn_segsum_f32")
+    return out
+
+
+def segsum_bwd_raw(dout, row_ptr, w, num_edges):
+    lib = _lib.load()
+    V, F = int(dout.shape[0]), int(dout.shape[1])
+    dmsg = _empty((num_edges, F), dout)
+    _lib.check(lib.mpnn_segsum_bwd_f32(_lib.fptr(dout), _lib.iptr(row_ptr), _lib.fptr(w), _lib.fptr(dmsg),
+                                       V, F, _lib.stream()), "mpnn_segsum_bwd_f32")
+    return dmsg
+
+
+def segsum_gather_raw(x, row_ptr, idx, w, num_rows):
+    lib = _lib.load()
+    F = int(x.shape[-1])
+    out = _empty((num_rows, F), x)
+    _lib.check(lib.mpnn_segsum_gather_f32(_lib.fptr(x), _lib.iptr(row_ptr), _lib.iptr(idx), _lib.fptr(w),
+                                          _lib.fptr(out), num_rows, F, _lib.stream()), "mpnn_segsum_gather_f32")
+    return out
+
+
+def edge_message_raw(h, A, graph, gate=None):
+    lib = _lib.load()
+    K, mf, nf = (int(s) for s in A.shape)
+    E = graph.num_edges
+    msg = _empty((E, mf), h)
+    _lib.check(_timed("edge_message", lambda: lib.mpnn_edge_message_f32(
+        _lib.fptr(h), _lib.fptr(A), _lib.iptr(graph.col_idx), _lib.iptr(graph.order), _lib.iptr(graph.type_ptr),
+        _lib.fptr(gate), _lib.fptr(msg), graph.num_nodes, E, K, nf, mf, _lib.stream())),
+        "mpnn_edge_message_f32")
+    return msg
+
+
+def edge_message_bwd_raw(h, A, graph, gate, dmsg):
+    lib = _lib.load()
+    K, mf, nf = (int(s) for s in A.shape)
+    E = graph.num_edges
+    dx = _empty((E, nf), h)
+    dA = torch.zeros_like(A)
+    _lib.check(lib.mpnn_edge_message_bwd_f32(_lib.fptr(h), _lib.fptr(A), _lib.iptr(graph.col_idx),
+                                             _lib.iptr(graph.order), _lib.iptr(graph.type_ptr), _lib.fptr(gate),
+                                             _lib.fptr(dmsg), _lib.fptr(dx), _lib.fptr(dA),
+                                             graph.num_nodes, E, K, nf, mf, _lib.stream()),
+               "mpnn_edge_message_bwd_f32")
+    return dx, dA
+
+
+def gru_update_raw(m, h, mask, W_ih, W_hh, b_ih, b_hh, save):
+    lib = _lib.load()
+    V, H = int(h.shape[0]), int(h.shape[1])
+    out = _empty((V, H), h)
+    saved = _empty((V, 4 * H), h) if save else None
+    _lib.check(_timed("gru_update", lambda: lib.mpnn_gru_update_f32(
+        _lib.fptr(m), _lib.fptr(h), _lib.fptr(mask), _lib.fptr(W_ih), _lib.fptr(W_hh), _lib.fptr(b_ih),
+        _lib.fptr(b_hh), _lib.fptr(out), _lib.fptr(saved), V, H, _lib.stream())), "mpnn_gru_update_f32")
+    return out, saved
+
+
+def gru_update_bwd_raw(dout, m, h, mask, W_ih, W_hh, saved):
+    lib = _lib.load()
+    V, H = int(h.shape[0]), int(h.shape[1])
+    dm, dh = _empty((V, H), h), _empty((V, H), h)
+    dW_ih, dW_hh = torch.zeros_like(W_ih), torch.zeros_like(W_hh)
+    db_ih = torch.zeros(3 * H, dtype=torch.float32, device=h.device)
+    db_hh = torch.zeros(3 * H, dtype=torch.float32, device=h.device)
+    ws_bytes = lib.mpnn_gru_bwd_workspace_bytes(V, H)
+    ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=h.device)
+    _lib.check(lib.mpnn_gru_update_bwd_f32(_lib.fptr(dout), _lib.fptr(m), _lib.fptr(h), _lib.fptr(mask),
+                                           _lib.fptr(W_ih), _lib.fptr(W_hh), _lib.fptr(saved),
+                                           _lib.fptr(dm), _lib.fptr(dh), _lib.fptr(dW_ih), _lib.fptr(dW_hh),
+                                           _lib.fptr(db_ih), _lib.fptr(db_hh), _lib.ptr(ws), ws_bytes,
+                                           V, H, _lib.stream()), "mpnn_gru_update_bwd_f32")
+    return dm, dh, dW_ih, dW_hh, db_ih, db_hh
+
+
+# --------------------------------------------------------------------------- autograd
+class SegSum(torch.autograd.Function):
+    """out[i] = sum_{e in row i} w[e] * msg[e]   (w optional, not differentiated)."""
+
+    @staticmethod
+    def forward(ctx, msg, row_ptr, w, num_rows):
+        msg = msg.contiguous()
+        ctx.save_for_backward(row_ptr, w)
+        ctx.num_edges = int(msg.shape[0])
+        return segsum_raw(msg, row_ptr, w, num_rows)
+
+    @staticmethod
+    def backward(ctx, dout):
+        row_ptr, w = ctx.saved_tensors
+        return segsum_bwd_raw(dout.contiguous(), row_ptr, w, ctx.num_edges), None, None, None
+
+
+class SegSumGather(torch.autograd.Function):
+    """out[i] = sum_{e in row i} w[e] * x[idx[e]];  backward runs the same kernel on the transposed
+    index (`t_row_ptr`, `t_idx`, `t_w`): dx[j] = sum_{e: idx[e]=j} w[e] * dout[row(e)]."""
+
+    @staticmethod
+    def forward(ctx, x, row_ptr, idx, w, num_rows, t_row_ptr, t_idx, t_w):
+        x = x.contiguous()
+        ctx.save_for_backward(t_row_ptr, t_idx, t_w)
+        ctx.num_src = int(x.shape[0])
+        return segsum_gather_raw(x, row_ptr, idx, w, num_rows)
+
+    @staticmethod
+    def backward(ctx, dout):
+        t_row_ptr, t_idx, t_w = ctx.saved_tensors
+        if t_row_ptr is None:
+            raise _lib.MpnnError("SegSumGather: no transposed index was supplied, cannot differentiate")
+        dx = segsum_gather_raw(dout.contiguous(), t_row_ptr, t_idx, t_w, ctx.num_src)
+        return dx, None, None, None, None, None, None, None
+
+
+class EdgeMessage(torch.autograd.Function):
+    """msg[e] = A[type(e)] . (gate[e] * h[src(e)])"""
+
+    @staticmethod
+    def forward(ctx, h, A, gate, graph):
+        h = h.contiguous()
+        A = A.contiguous()
+        gate = gate.contiguous() if gate is not None else None
+        ctx.graph = graph
+        ctx.save_for_backward(h, A, gate)
+        return edge_message_raw(h, A, graph, gate)
+
+    @staticmethod
+    def backward(ctx, dmsg):
+        h, A, gate = ctx.saved_tensors
+        g = ctx.graph
+        dx, dA = edge_message_bwd_raw(h, A, g, gate, dmsg.contiguous())     # dx = A^T dmsg per edge
+        t_row_ptr, t_eid = g.transpose
+        dgate = None
+        if gate is not None:
+            src = g.col_idx.to(torch.int64)
+            if ctx.needs_input_grad[2]:
+                dgate = dx * h[src]
+            dx = dx * gate
+        dh = segsum_gather_raw(dx, t_row_ptr, t_eid, None, g.num_nodes) if ctx.needs_input_grad[0] else None
+        return dh, (dA if ctx.needs_input_grad[1] else None), dgate, None
+
+
+class GRUUpdateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, m, h, mask, W_ih, W_hh, b_ih, b_hh):
+        m, h = m.contiguous(), h.contiguous()
+        mask = mask.contiguous() if mask is not None else None
+        need = any(ctx.needs_input_grad)
+        out, saved = gru_update_raw(m, h, mask, W_ih.contiguous(), W_hh.contiguous(), b_ih.contiguous(),
+                                    b_hh.contiguous(), need)
+        if need:
+            ctx.save_for_backward(m, h, mask, W_ih, W_hh, saved)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        m, h, mask, W_ih, W_hh, saved = ctx.saved_tensors
+        dm, dh, dW_ih, dW_hh, db_ih, db_hh = gru_update_bwd_raw(dout.contiguous(), m, h, mask,
+                                                                 W_ih.contiguous(), W_hh.contiguous(), saved)
+        return dm, dh, None, dW_ih, dW_hh, db_ih, db_hh
+
+
+def segsum(msg, row_ptr, w=None, num_rows=None):
+    return SegSum.apply(msg, row_ptr, w, int(row_ptr.shape[0]) - 1 if num_rows is None else num_rows)
+
+
+def neighbour_sum(x, graph, weighted=False):
+    """sum over incoming edges of x[src]  (V,F) -> (V,F); differentiable through the transposed graph."""
+    t_row_ptr, t_eid = graph.transpose
+    w = graph.edge_weight if weighted else None
+    t_w = w[t_eid.to(torch.int64)].contiguous() if w is not None else None
+    t_dst = graph.edge_dst[t_eid.to(torch.int64)].contiguous()
+    return SegSumGather.apply(x, graph.row_ptr, graph.col_idx, w, graph.num_nodes, t_row_ptr, t_dst, t_w)
+
+
+def molecule_sum(x, graph):
+    """Per-molecule sum of atom rows (V,F) -> (G,F).  Backward is a row broadcast."""
+    return _MoleculeSum.apply(x, graph)
+
+
+class _MoleculeSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, graph):
+        ctx.graph = graph
+        return segsum_raw(x.contiguous(), graph.graph_ptr, None, graph.num_graphs)
+
+    @staticmethod
+    def backward(ctx, dout):
+        g = ctx.graph
+        return segsum_bwd_raw(dout.contiguous(), g.graph_ptr, None, g.num_nodes), None
+
+
+def edge_message(h, A, graph, gate=None):
+    return EdgeMessage.apply(h, A, gate, graph)
+
+
+def gru_update(m, h, mask, W_ih, W_hh, b_ih, b_hh):
+    return GRUUpdateFn.apply(m, h, mask, W_ih, W_hh, b_ih, b_hh)

@@ -24,7 +24,7 @@ class Fixture:
         self.raw = {k: z[k] for k in z.files}
         self.inputs, self.params, self.out, self.gin, self.gp, self.pre = {}, {}, {}, {}, {}, {}
         for k, v in self.raw.items():
-            tv = torch.from_numpy(v) if v.dtype.kind in "fiu" and v.shape != () else v
+            tv = torch.from_numpy(np.asarray(v)) if v.dtype.kind in "fiu" else v
             if k.startswith("in."):
                 self.inputs[k[3:]] = tv
             elif k.startswith("p."):

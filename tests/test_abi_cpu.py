@@ -1,0 +1,90 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol the header declares, the
+operator modules keep the reference's state_dict layout, the product path refuses CPU tensors."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import Fixture
+from mpnn_amd import _lib, synth
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_lib.load()._name)
+    names = _lib.declared_symbols()
+    assert len(names) >= 13
+    for n in names:
+        assert hasattr(lib, n), "libmpnn_amd.so lacks %s declared in include/mpnn_amd.h" % n
+    assert set(_lib._SIGNATURES) == set(names)
+    assert _lib.load().mpnn_version() >= 100
+
+
+def test_no_cpu_fallback():
+    from mpnn_amd import ops
+    with pytest.raises(_lib.MpnnError):
+        ops.segsum_raw(torch.zeros(4, 8), torch.zeros(3, dtype=torch.int32), None, 2)
+    from mpnn_amd.mpnn_functions import GRUUpdate
+    g = GRUUpdate(8, 8)
+    with pytest.raises(_lib.MpnnError):
+        g(torch.zeros(2, 3, 8), torch.zeros(2, 3, 8), torch.ones(2, 3, 1))
+
+
+def test_rejected_calls_report_an_error_string():
+    lib = _lib.load()
+    rc = lib.mpnn_segsum_f32(None, None, None, None, 4, 8, None)
+    assert rc == -1 and b"mpnn_segsum_f32" in lib.mpnn_last_error_string()
+    rc = lib.mpnn_gru_update_f32(None, None, None, None, None, None, None, None, None, 4, 100000, None)
+    assert rc == -1
+    assert lib.mpnn_edge_message_f32(None, None, None, None, None, None, None, 0, 0, 0, 8, 8, None) == 0   # empty
+
+
+@pytest.mark.parametrize("name,prefix", [("model_basic_h8", ""), ("model_lipo_T3_train", "")])
+def test_state_dict_layout_matches_reference(name, prefix):
+    f = Fixture(name)
+    if name.startswith("model_basic"):
+        from mpnn_amd.models.basic_model import BasicModel
+        from mpnn_amd.models.graph_model_wrapper import GraphWrapper
+        m = GraphWrapper(BasicModel(8, 4, 8, 9, 6, message_opts={}, agg_opts={}, update_opts={}, readout_opts={}))
+    else:
+        from mpnn_amd.models.lipo_basic_model import BasicModel
+        from mpnn_amd.models.graph_norm_wrapper import GraphWrapper
+        m = GraphWrapper(BasicModel(22, 7, 22, 9, 38, message_opts={}, agg_opts={}, update_opts={},
+                                    readout_opts={}, message_steps=3), 3)
+    sd = m.state_dict()
+    assert set(sd) == set(f.params), set(sd) ^ set(f.params)
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(f.params[k].shape), k
+    m.load_state_dict(f.params)     # reference checkpoints load as they are
+    # the 50 tower aliases are ONE tensor here as well
+    import re
+    tower = [k for k in sd if re.search(r"\.edge_map\.\d+\.0\.weight$", k)]
+    assert len(tower) == 50 and len({sd[k].data_ptr() for k in tower}) == 1
+
+
+def test_mutable_default_opts_are_shared_like_the_reference():
+    from mpnn_amd.models.basic_model import BasicModel
+    BasicModel(8, 4, 8, 9, 6)
+    assert BasicModel.__init__.__defaults__[1]["node_features"] == 8    # reference quirk
+
+
+def test_synthetic_molecules():
+    mb = synth.make_molecules(2000, 16, seed=3)
+    V, E = mb.num_atoms, mb.num_edges
+    deg = np.diff(mb.row_ptr)
+    assert mb.row_ptr[-1] == E and deg.sum() == E
+    dst = np.repeat(np.arange(V), deg)
+    mol = np.repeat(np.arange(mb.num_mols), mb.n_atoms)
+    assert (mol[dst] == mol[mb.col_idx]).all()                   # no cross-molecule edges
+    assert (dst != mb.col_idx).all()                             # no self loops
+    key = dst.astype(np.int64) * V + mb.col_idx
+    assert (np.diff(key) > 0).all()                              # sorted by (dst, src), no duplicates
+    rev = mb.col_idx.astype(np.int64) * V + dst
+    assert np.array_equal(np.sort(rev), key)                     # symmetric
+    order = np.argsort(rev, kind="stable")
+    assert np.array_equal(mb.bond_type[order], mb.bond_type)     # same bond type both directions
+    assert 55 < E / mb.num_mols < 65
+    sk = synth.make_molecules(500, 4, seed=5, dist="skewed")
+    assert np.diff(sk.row_ptr).max() > 12                        # heavy-tailed hubs
+    d = synth.to_dense(synth.select(mb, [3, 1, 4]))
+    assert d["adj"].shape[0] == 3 and (d["adj"] == d["adj"].transpose(0, 2, 1)).all()

@@ -1,0 +1,218 @@
+"""Kernel-level parity on a real MI355X, through the C ABI (ctypes) -- never through the oracle.
+
+Integer / index work is checked bit-exact; fp32 work against the CPU oracle within 1e-5
+(BASELINE.json north_star tolerance) on O(1) data.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import Fixture, max_err
+from oracle import dense_ref as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    from mpnn_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _rand_graph(rng, V, max_deg, skew=False):
+    if skew:
+        deg = np.minimum((rng.pareto(1.2, V) * 2).astype(np.int64), max_deg)
+    else:
+        deg = rng.integers(0, max_deg + 1, V)
+    row_ptr = np.zeros(V + 1, np.int32)
+    np.cumsum(deg, out=row_ptr[1:])
+    col = rng.integers(0, V, int(row_ptr[-1])).astype(np.int32)
+    return row_ptr, col
+
+
+# ----------------------------------------------------------------------------- dense -> CSR
+def test_csr_matches_reference_fixture_bit_exact(dev):
+    from mpnn_amd.graph import MolGraph
+    f = Fixture("csr_ragged")
+    adj = torch.from_numpy(f.raw["adj"]).to(dev)
+    g = MolGraph.from_dense(adj, None)
+    assert torch.equal(g.row_ptr.cpu(), torch.from_numpy(f.raw["row_ptr"]))
+    assert torch.equal(g.col_idx.cpu(), torch.from_numpy(f.raw["col_idx"]))
+    assert torch.equal(g.edge_weight.cpu(), torch.ones(g.num_edges))
+
+
+@pytest.mark.parametrize("B,N,p", [(1, 1, 1.0), (3, 7, 0.0), (5, 64, 0.3), (4, 65, 0.5), (2, 200, 0.05), (700, 50, 0.04)])
+def test_csr_random_bit_exact(dev, B, N, p):
+    from mpnn_amd.graph import MolGraph
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    adj = (torch.rand(B, N, N, generator=g) < p).float() * (torch.rand(B, N, N, generator=g) + 0.5)
+    bfm = torch.zeros(B, N, N, 3)
+    extra = torch.rand(B, N, N, generator=g) < p / 2          # pairs that only carry bond features
+    bfm[extra] = torch.rand(int(extra.sum()), 3, generator=g) + 0.1
+    for use_adj, use_bfm in ((True, False), (True, True), (False, True)):
+        a = adj if use_adj else None
+        b = bfm if use_bfm else None
+        member = torch.zeros(B, N, N, dtype=torch.bool)
+        if use_adj:
+            member |= adj != 0
+        if use_bfm:
+            member |= (bfm != 0).any(-1)
+        rp, ci, _ = O.dense_to_csr(member.float())
+        mg = MolGraph.from_dense(a.to(dev) if a is not None else None, b.to(dev) if b is not None else None)
+        assert torch.equal(mg.row_ptr.cpu(), rp)
+        assert torch.equal(mg.col_idx.cpu(), ci)
+        nz = member.nonzero()
+        if use_adj:
+            assert torch.equal(mg.edge_weight.cpu(), adj[nz[:, 0], nz[:, 1], nz[:, 2]])
+        if use_bfm:
+            assert torch.equal(mg.edge_feat.cpu(), bfm[nz[:, 0], nz[:, 1], nz[:, 2]])
+            assert torch.equal(mg.type_feat[mg.edge_type.long()].cpu(), mg.edge_feat.cpu())
+
+
+# ----------------------------------------------------------------------------- aggregator
+def _segsum_oracle(msg, row_ptr, w):
+    V = row_ptr.shape[0] - 1
+    deg = np.diff(row_ptr)
+    dst = torch.from_numpy(np.repeat(np.arange(V), deg))
+    m = msg.double() * (w.double().unsqueeze(-1) if w is not None else 1.0)
+    return torch.zeros(V, msg.shape[1], dtype=torch.float64).index_add_(0, dst, m)
+
+
+@pytest.mark.parametrize("F", [1, 3, 8, 22, 64, 100, 128, 256, 260, 512])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_segsum(dev, F, weighted):
+    from mpnn_amd import ops
+    rng = np.random.default_rng(F)
+    row_ptr, _ = _rand_graph(rng, 777, 9, skew=(F % 2 == 0))
+    E = int(row_ptr[-1])
+    msg = torch.from_numpy(rng.standard_normal((E, F)).astype(np.float32))
+    w = torch.from_numpy(rng.random(E).astype(np.float32)) if weighted else None
+    out = ops.segsum_raw(msg.to(dev), torch.from_numpy(row_ptr).to(dev), w.to(dev) if weighted else None, 777)
+    ref = _segsum_oracle(msg, row_ptr, w)
+    assert max_err(out.cpu(), ref) < TOL
+    # rows without edges are exactly zero
+    empty = np.diff(row_ptr) == 0
+    assert float(out.cpu()[torch.from_numpy(empty)].abs().sum()) == 0.0
+    # backward kernel: dmsg[e] = w[e] * dout[dst(e)]
+    dout = torch.from_numpy(rng.standard_normal((777, F)).astype(np.float32))
+    dmsg = ops.segsum_bwd_raw(dout.to(dev), torch.from_numpy(row_ptr).to(dev), w.to(dev) if weighted else None, E)
+    dst = np.repeat(np.arange(777), np.diff(row_ptr))
+    exp = dout[dst] * (w.unsqueeze(-1) if weighted else 1.0)
+    assert max_err(dmsg.cpu(), exp) == 0.0
+
+
+def test_segsum_empty_and_long_rows(dev):
+    from mpnn_amd import ops
+    rng = np.random.default_rng(9)
+    deg = np.array([0, 0, 1500, 0, 3, 1, 0, 0], np.int64)       # one hub, ragged tail
+    row_ptr = np.zeros(9, np.int32)
+    np.cumsum(deg, out=row_ptr[1:])
+    msg = torch.from_numpy(rng.standard_normal((int(row_ptr[-1]), 64)).astype(np.float32))
+    out = ops.segsum_raw(msg.to(dev), torch.from_numpy(row_ptr).to(dev), None, 8)
+    assert max_err(out.cpu(), _segsum_oracle(msg, row_ptr, None)) < 5e-5     # 1500-term fp32 sums
+    z = ops.segsum_raw(torch.zeros(0, 64, device=dev), torch.zeros(5, dtype=torch.int32, device=dev), None, 4)
+    assert z.shape == (4, 64) and float(z.abs().sum()) == 0.0
+
+
+def test_segsum_gather(dev):
+    from mpnn_amd import ops
+    rng = np.random.default_rng(10)
+    row_ptr, col = _rand_graph(rng, 500, 6)
+    x = torch.from_numpy(rng.standard_normal((500, 64)).astype(np.float32))
+    out = ops.segsum_gather_raw(x.to(dev), torch.from_numpy(row_ptr).to(dev), torch.from_numpy(col).to(dev), None, 500)
+    assert max_err(out.cpu(), _segsum_oracle(x[col.astype(np.int64)], row_ptr, None)) < TOL
+
+
+# ----------------------------------------------------------------------------- edge message
+def _message_setup(rng, V, K, nf, mf, max_deg=5):
+    from mpnn_amd.graph import MolGraph
+    row_ptr, col = _rand_graph(rng, V, max_deg)
+    E = int(row_ptr[-1])
+    et = rng.integers(0, K, E).astype(np.int32)
+    if K > 2:
+        et[et == 1] = 0                 # leave one type empty
+    h = rng.standard_normal((V, nf)).astype(np.float32)
+    A = (rng.standard_normal((K, mf, nf)) / np.sqrt(nf)).astype(np.float32)
+    return row_ptr, col, et, h, A
+
+
+@pytest.mark.parametrize("nf,mf,K,V", [(8, 8, 4, 50), (22, 22, 5, 333), (64, 64, 4, 2000), (64, 32, 3, 700),
+                                       (100, 72, 2, 300), (128, 128, 4, 900), (256, 256, 3, 400), (64, 64, 1, 129)])
+@pytest.mark.parametrize("gated", [False, True])
+def test_edge_message(dev, nf, mf, K, V, gated):
+    from mpnn_amd import ops
+    from mpnn_amd.graph import MolGraph
+    rng = np.random.default_rng(nf * 7 + mf + K)
+    row_ptr, col, et, h, A = _message_setup(rng, V, K, nf, mf)
+    E = int(row_ptr[-1])
+    t = lambda a, dt=None: torch.from_numpy(a).to(dev)
+    g = MolGraph(t(row_ptr), t(col), None, t(et), torch.zeros(K, 1, device=dev),
+                 torch.tensor([0, V], dtype=torch.int32, device=dev))
+    gate = rng.random((E, nf)).astype(np.float32) if gated else None
+    msg = ops.edge_message_raw(t(h), t(A), g, t(gate) if gated else None)
+    x = torch.from_numpy(h)[col.astype(np.int64)].double()
+    if gated:
+        x = x * torch.from_numpy(gate).double()
+    ref = torch.einsum("emn,en->em", torch.from_numpy(A)[et.astype(np.int64)].double(), x)
+    assert msg.shape == (E, mf)
+    assert max_err(msg.cpu(), ref) < TOL * max(1.0, float(ref.abs().max()))
+    # type-sorted order really is a permutation grouped by type
+    order = g.order.cpu().numpy()
+    assert np.array_equal(np.sort(order), np.arange(E))
+    assert (np.diff(et[order]) >= 0).all()
+
+
+def test_edge_message_integer_exact(dev):
+    """Small-integer data: fp32 products and sums are exact, so any indexing slip shows as != 0."""
+    from mpnn_amd import ops
+    from mpnn_amd.graph import MolGraph
+    rng = np.random.default_rng(77)
+    V, K, nf, mf = 600, 4, 64, 64
+    row_ptr, col, et, _, _ = _message_setup(rng, V, K, nf, mf)
+    h = rng.integers(-3, 4, (V, nf)).astype(np.float32)
+    A = rng.integers(-2, 3, (K, mf, nf)).astype(np.float32)          # asymmetric by construction
+    t = lambda a: torch.from_numpy(a).to(dev)
+    g = MolGraph(t(row_ptr), t(col), None, t(et), torch.zeros(K, 1, device=dev),
+                 torch.tensor([0, V], dtype=torch.int32, device=dev))
+    msg = ops.edge_message_raw(t(h), t(A), g)
+    ref = torch.einsum("emn,en->em", torch.from_numpy(A)[et.astype(np.int64)], torch.from_numpy(h)[col.astype(np.int64)])
+    assert torch.equal(msg.cpu(), ref)
+
+
+# ----------------------------------------------------------------------------- GRU
+@pytest.mark.parametrize("tag", ["h8", "h22", "h64"])
+def test_gru_against_reference_fixture(dev, tag):
+    from mpnn_amd import ops
+    f = Fixture("gru_update_" + tag)
+    H = f.inputs["node_states"].shape[-1]
+    p = {k: v.to(dev) for k, v in f.params.items()}
+    out, saved = ops.gru_update_raw(f.inputs["messages"].reshape(-1, H).to(dev),
+                                    f.inputs["node_states"].reshape(-1, H).contiguous().to(dev),
+                                    f.inputs["mask"].reshape(-1).to(dev), p["gru_cell.weight_ih"],
+                                    p["gru_cell.weight_hh"], p["gru_cell.bias_ih"], p["gru_cell.bias_hh"], True)
+    assert max_err(out.cpu().view(f.out[""].shape), f.out[""]) < TOL
+    pad = f.inputs["mask"].reshape(-1) == 0
+    assert float(out.cpu()[pad].abs().sum()) == 0.0          # padded atoms exactly zero
+    assert saved.shape == (out.shape[0], 4 * H)
+
+
+@pytest.mark.parametrize("V,H", [(1, 64), (127, 64), (129, 64), (1000, 128), (300, 256), (257, 100), (513, 48)])
+def test_gru_random(dev, V, H):
+    from mpnn_amd import ops
+    g = torch.Generator().manual_seed(V + H)
+    m = torch.rand(V, H, generator=g) * 2 - 1
+    h = torch.rand(V, H, generator=g) * 2 - 1
+    mask = (torch.rand(V, generator=g) < 0.8).float()
+    s = 1.0 / np.sqrt(H)
+    p = {"gru_cell.weight_ih": (torch.rand(H, 3 * H, generator=g) * 2 - 1) * s,
+         "gru_cell.weight_hh": (torch.rand(H, 3 * H, generator=g) * 2 - 1) * s,
+         "gru_cell.bias_ih": torch.rand(3 * H, generator=g) - 0.5,
+         "gru_cell.bias_hh": torch.rand(3 * H, generator=g) - 0.5}
+    ref = O.gru_update(p, m, h, mask.view(-1, 1))
+    out, _ = ops.gru_update_raw(m.to(dev), h.to(dev), mask.to(dev), *(p[k].to(dev) for k in
+                                ("gru_cell.weight_ih", "gru_cell.weight_hh", "gru_cell.bias_ih", "gru_cell.bias_hh")),
+                                False)
+    assert max_err(out.cpu(), ref) < TOL

@@ -1,0 +1,194 @@
+"""Operator- and model-level parity on the GPU against vectors produced by the REAL reference
+(tests/golden/*.npz) -- the modules are driven exactly as the reference's would be."""
+import pytest
+import torch
+from torch import nn
+
+from conftest import Fixture, max_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _to(d, dev):
+    return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in d.items()}
+
+
+@pytest.mark.parametrize("tag,nf,ef", [("h8_rand", 8, 4), ("h8_init", 8, 4), ("h22_rand", 22, 7), ("h8_cont", 8, 4)])
+def test_edge_network(dev, tag, nf, ef):
+    from mpnn_amd.mpnn_functions import AdjMsgAgg, EdgeNetwork
+    f = Fixture("edge_network_" + tag)
+    m = EdgeNetwork(nf, ef, nf).to(dev)
+    m.load_state_dict(f.params)
+    i = _to(f.inputs, dev)
+    with torch.no_grad():
+        fused = m(i["afm"], i["bfm"])                                     # HEAD semantics
+        assert max_err(fused.cpu(), f.out[""]) < 2 * TOL
+        assert max_err(m(i["afm"], i["bfm"], reuse_graph_tensors=True).cpu(), f.out[""]) < 2 * TOL
+        assert max_err(m.edge_embed.A0.cpu(), f.out["A0"]) < TOL
+        m.pairwise = True
+        msgs = m(i["afm"], i["bfm"])
+        assert max_err(msgs.to_dense().cpu(), f.out["pair"]) < TOL         # legacy per-pair contract
+        agg = AdjMsgAgg(9)(msgs, i["adj"])
+    fa = Fixture("edge_network_%s_pairagg" % tag)
+    assert max_err(agg.cpu(), fa.out[""]) < TOL
+
+
+@pytest.mark.parametrize("tag,nf,ef", [("h8", 8, 4), ("h22", 22, 7)])
+def test_att_edge_network(dev, tag, nf, ef):
+    from mpnn_amd.mpnn_functions import AdjMsgAgg, AttEdgeNetwork
+    f = Fixture("att_edge_network_" + tag)
+    m = AttEdgeNetwork(nf, ef, nf).to(dev)
+    m.load_state_dict(f.params)
+    i = _to(f.inputs, dev)
+    with torch.no_grad():
+        msgs = m(i["afm"], i["bfm"])
+        assert max_err(msgs.to_dense().cpu(), f.out["pair"]) < TOL
+        assert max_err(AdjMsgAgg(9)(msgs, i["adj"]).cpu(), f.out[""]) < TOL
+
+
+def test_ggnn(dev):
+    from mpnn_amd.mpnn_functions import GGNNMsgPass
+    f = Fixture("ggnn_msg_pass")
+    m = GGNNMsgPass(8, 4, 8).to(dev)
+    m.load_state_dict(f.params)
+    i = _to(f.inputs, dev)
+    with torch.no_grad():
+        assert max_err(m(i["afm"], i["ibfm"]).cpu(), f.out[""]) < TOL
+
+
+def test_bilinear(dev):
+    from mpnn_amd.mpnn_functions import BiLiniearEdgeNetwork
+    f = Fixture("bilinear_edge_network")
+    i = _to(f.inputs, dev)
+    with torch.no_grad():
+        assert max_err(BiLiniearEdgeNetwork(3, 27, 3)(i["afm"], i["bfm"]).cpu(), f.out[""]) < TOL
+
+
+def test_aggregators_on_dense_messages(dev):
+    from mpnn_amd.mpnn_functions import AdjMsgAgg, AttMsgAgg, WAdjMsgAgg
+    for name, make in (("agg_adj", lambda: AdjMsgAgg(9)), ("agg_adj_weighted", lambda: AdjMsgAgg(9)),
+                       ("agg_wadj", lambda: WAdjMsgAgg(9)), ("agg_att_default", lambda: AttMsgAgg(1)),
+                       ("agg_att_sigmoid", lambda: AttMsgAgg(1, attn_act=nn.Sigmoid()))):
+        f = Fixture(name)
+        m = make().to(dev)
+        if f.params:
+            m.load_state_dict(f.params)
+        i = _to(f.inputs, dev)
+        with torch.no_grad():
+            assert max_err(m(i["messages"], i["adj"]).cpu(), f.out[""]) < TOL, name
+
+
+@pytest.mark.parametrize("kind", ["wadj", "att_sigmoid", "att_default"])
+def test_aggregators_on_sparse_messages_match_dense_semantics(dev, kind):
+    """Non-member pairs (A0 != 0) and the padded row length enter the weighted aggregators: the
+    sparse path must equal the reference aggregator applied to the reference's dense messages."""
+    from oracle import dense_ref as O
+    from mpnn_amd.mpnn_functions import AttMsgAgg, EdgeNetwork, WAdjMsgAgg
+    f = Fixture("edge_network_h8_rand")
+    m = EdgeNetwork(8, 4, 8).to(dev)
+    m.load_state_dict(f.params)
+    m.pairwise = True
+    i = _to(f.inputs, dev)
+    pair = f.out["pair"]
+    if kind == "wadj":
+        agg, ref = WAdjMsgAgg(9), O.agg_wadj(pair, f.inputs["adj"])
+    else:
+        act = nn.Sigmoid() if kind == "att_sigmoid" else None
+        agg = AttMsgAgg(1, attn_act=act)
+        with torch.no_grad():
+            agg.att[0].weight.fill_(0.7)
+            agg.att[0].bias.fill_(-0.2)
+        p = {"att.0.weight": agg.att[0].weight.detach(), "att.0.bias": agg.att[0].bias.detach()}
+        ref = O.agg_att(p, pair, f.inputs["adj"], torch.sigmoid if act is not None else None)
+    with torch.no_grad():
+        out = agg.to(dev)(m(i["afm"], i["bfm"]), i["adj"])
+    assert max_err(out.cpu(), ref) < 2 * TOL
+
+
+@pytest.mark.parametrize("tag,H", [("h8", 8), ("h22", 22), ("h64", 64)])
+def test_gru_update_module(dev, tag, H):
+    from mpnn_amd.mpnn_functions import GRUUpdate
+    f = Fixture("gru_update_" + tag)
+    m = GRUUpdate(H, H).to(dev)
+    m.load_state_dict(f.params)
+    i = _to(f.inputs, dev)
+    with torch.no_grad():
+        out = m(i["messages"], i["node_states"], i["mask"])
+    assert out.shape == f.out[""].shape and max_err(out.cpu(), f.out[""]) < TOL
+
+
+def test_gru_rejects_mismatched_widths(dev):
+    from mpnn_amd.mpnn_functions import GRUUpdate
+    m = GRUUpdate(8, 16).to(dev)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 2, 16, device=dev), torch.zeros(1, 2, 8, device=dev), torch.ones(1, 2, 1, device=dev))
+
+
+@pytest.mark.parametrize("tag,H,ef", [("h8", 8, 4), ("h22", 22, 7)])
+def test_basic_model_forward(dev, tag, H, ef):
+    """models.basic_model.BasicModel under graph_model_wrapper.GraphWrapper, dict batch in."""
+    from mpnn_amd.models.basic_model import BasicModel
+    from mpnn_amd.models.graph_model_wrapper import GraphWrapper
+    f = Fixture("model_basic_" + tag)
+    model = GraphWrapper(BasicModel(H, ef, H, 9, 6, message_opts={}, agg_opts={}, update_opts={},
+                                    readout_opts={})).to(dev)
+    model.load_state_dict(f.params)
+    batch = _to(f.inputs, dev)
+    with torch.no_grad():
+        out = model(batch)
+        state, _ = model.graph_model.message_passing(batch["afm"], batch["bfm"], batch["adj"], batch["mask"])
+        model.graph_model.hoist_message = True
+        out_h = model(batch)
+    assert max_err(state.cpu(), f.out["node_state"]) < TOL
+    assert max_err(out.cpu(), f.out[""]) < TOL
+    assert torch.equal(out_h, out)                   # hoisting the constant message changes nothing
+
+
+@pytest.mark.parametrize("T", [3, 6])
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_lipo_model_forward(dev, T, mode):
+    from mpnn_amd.models.graph_norm_wrapper import GraphWrapper
+    from mpnn_amd.models.lipo_basic_model import BasicModel
+    f = Fixture("model_lipo_T%d_%s" % (T, mode))
+    model = GraphWrapper(BasicModel(22, 7, 22, 9, 38, message_opts={}, agg_opts={}, update_opts={},
+                                    readout_opts={}, message_steps=T), 3).to(dev)
+    sd = dict(f.params)
+    sd.update(f.pre)
+    model.load_state_dict(sd)
+    model.train(mode == "train")
+    with torch.no_grad():
+        out = model(_to(f.inputs, dev))
+    assert max_err(out.cpu(), f.out[""]) < 5e-5      # 2*T chained batch norms amplify fp32 rounding
+    if mode == "train":
+        for k, v in model.state_dict().items():
+            if "running_" in k:
+                assert max_err(v.cpu(), f.params[k]) < 1e-5, k
+
+
+def test_sparse_native_batch_equals_dense_batch(dev):
+    """The compact MolGraph entry (no padding, no dense tensors) gives the dense path's numbers."""
+    import numpy as np
+    from mpnn_amd import synth
+    from mpnn_amd.graph import MolGraph
+    from mpnn_amd.models.basic_model import BasicModel
+    from mpnn_amd.models.graph_model_wrapper import GraphWrapper
+    mb = synth.make_molecules(40, 16, seed=5)
+    torch.manual_seed(0)
+    model = GraphWrapper(BasicModel(16, 4, 16, 50, 5, message_opts={}, agg_opts={}, update_opts={},
+                                    readout_opts={})).to(dev)
+    d = {k: torch.from_numpy(v).to(dev) for k, v in synth.to_dense(mb).items()}
+    g = MolGraph.from_molbatch(mb, dev)
+    sparse = {"afm": torch.from_numpy(mb.atom_feat).to(dev), "graph": g,
+              "mask": torch.ones(mb.num_atoms, 1, device=dev)}
+    with torch.no_grad():
+        a = model(d)
+        b = model(sparse)
+    assert a.shape == b.shape == (40, 5)
+    assert max_err(a.cpu(), b.cpu()) < TOL
