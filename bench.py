@@ -48,6 +48,31 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores():
+    """Host cores this process may really use: min(affinity mask, cgroup cpu quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, q // int(f.read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return min(n, int(os.environ.get("MPNN_CPU_THREADS", "16")))   # the GPU box's CPU share per GPU is 16
+
+
 def cpu_baseline(mb, hidden, steps, mode, budget_s):
     """The oracle's dense padded CPU path (== the reference's op sequence, validated against the
     reference's own outputs in tests/test_oracle_golden.py), batches of 16 molecules (the
@@ -55,7 +80,7 @@ def cpu_baseline(mb, hidden, steps, mode, budget_s):
     from mpnn_amd import synth
     from mpnn_amd.models.basic_model import BasicModel      # parameters only: same init as the GPU model
     from oracle import dense_ref as O
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(317)
     model = BasicModel(hidden, 4, hidden, 50, 8, message_opts={}, agg_opts={}, update_opts={}, readout_opts={},

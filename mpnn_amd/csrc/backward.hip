@@ -1,0 +1,409 @@
+// Backward kernels of the edge message and the GRU update (fp32 MFMA).
+//
+// Two GEMM shapes cover every gradient:
+//   rows_gemm      out[r,:] = X[r,:] . B          one 128-row tile per block, K in chunks of 64
+//                  - dx[e]  = A_type(e)^T dmsg[e]     (typed tiles, B = A_k stored (mf,nf) = [k][n])
+//                  - dm     = dgi W_ih^T, dh = dgh W_hh^T + z*dout   (B = W stored (H,3H) = [n][k])
+//   tn_accumulate  C += X^T . Y  (reduction over rows; persistent blocks, one atomic flush each)
+//                  - dA[k]  = sum_{e of type k} dmsg[e] (x) (gate[e]*h[src e])
+//                  - dW_ih  = m^T dgi, dW_hh = h^T dgh, db = column sums of dgi / dgh
+// plus the elementwise gate-gradient kernel of the GRU.
+#include "common.h"
+
+namespace mpnn {
+
+constexpr int kBT = 128;          // rows per tile (4 waves x 32)
+constexpr int kBK = 64;           // contraction chunk
+constexpr int kLDA = kBK + 4;     // row stride of k-contiguous LDS images
+
+__device__ __forceinline__ f32x4 ld4(const float* __restrict__ p, int have, bool vec) {
+    // 4 consecutive floats at p, the first `have` of them valid (have <= 0 -> zeros)
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (vec) {
+        if (have >= 4) v = *reinterpret_cast<const f32x4*>(p);
+    } else {
+        if (have > 0) v.x = p[0];
+        if (have > 1) v.y = p[1];
+        if (have > 2) v.z = p[2];
+        if (have > 3) v.w = p[3];
+    }
+    return v;
+}
+
+__device__ __forceinline__ int count_tiles(const int32_t* __restrict__ type_ptr, int K) {
+    int acc = 0;
+    for (int k = 0; k < K; ++k) acc += (type_ptr[k + 1] - type_ptr[k] + kBT - 1) / kBT;
+    return acc;
+}
+
+__device__ __forceinline__ bool find_tile(const int32_t* __restrict__ type_ptr, int K, int tile, int* type, int* start,
+                                          int* rows) {
+    int acc = 0;
+    for (int k = 0; k < K; ++k) {
+        const int b = type_ptr[k], e = type_ptr[k + 1];
+        const int nt = (e - b + kBT - 1) / kBT;
+        if (tile < acc + nt) {
+            const int s = b + (tile - acc) * kBT;
+            *type = k;
+            *start = s;
+            *rows = min(kBT, e - s);
+            return true;
+        }
+        acc += nt;
+    }
+    return false;
+}
+
+// ------------------------------------------------------------------------------------ rows_gemm
+// out[row, n] = sum_k X[row, k] * Bop[k, n] (+ add[row, n]),  n < N, k < Kdim
+//   B_IS_NK: B stored [n][k] (ldb = row stride over n) else [k][n]
+//   TYPED:   tile rows are edge ids order[start + r], B = Bbase + type * b_type_stride
+template <int NB, bool B_IS_NK, bool TYPED>
+__global__ void __launch_bounds__(256) rows_gemm_kernel(const float* __restrict__ X, int ldx,
+                                                        const int32_t* __restrict__ order,
+                                                        const int32_t* __restrict__ type_ptr, int K_types,
+                                                        const float* __restrict__ Bbase, int64_t b_type_stride, int ldb,
+                                                        const float* add, float* out, int ldo, int64_t R, int Kdim,
+                                                        int N) {
+    constexpr int LDB = 32 * NB + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* Xs = reinterpret_cast<float*>(smem_raw);      // [kBT][kLDA]
+    float* Bs = Xs + kBT * kLDA;                         // [kBK][LDB]
+    int* s_row = reinterpret_cast<int*>(Bs + kBK * LDB); // [kBT]
+
+    int type = 0, start, rows;
+    if (TYPED) {
+        if (!find_tile(type_ptr, K_types, blockIdx.x, &type, &start, &rows)) return;
+    } else {
+        const int64_t s = (int64_t)blockIdx.x * kBT;
+        if (s >= R) return;
+        start = (int)s;
+        rows = (int)min((int64_t)kBT, R - s);
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < kBT) s_row[tid] = (tid < rows) ? (TYPED ? order[start + tid] : start + tid) : -1;
+    __syncthreads();
+
+    const float* B = Bbase + (int64_t)type * b_type_stride;
+    const bool vecx = ((ldx & 3) == 0) && ((Kdim & 3) == 0);
+    const bool vecb = ((ldb & 3) == 0) && (((B_IS_NK ? Kdim : N) & 3) == 0);
+    const int c4 = tid & 15, r0 = tid >> 4;
+    const int r = lane & 31, hi = lane >> 5;
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
+
+    for (int k0 = 0; k0 < Kdim; k0 += kBK) {
+        if (k0) __syncthreads();
+        const int k = k0 + 4 * c4;
+#pragma unroll
+        for (int p = 0; p < kBT / 16; ++p) {
+            const int row = r0 + 16 * p;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row < rows) v = ld4(X + (int64_t)s_row[row] * ldx + k, Kdim - k, vecx);
+            *reinterpret_cast<f32x4*>(Xs + row * kLDA + 4 * c4) = v;
+        }
+        if (B_IS_NK) {
+            // global [n][k] -> LDS [k][n]: read 4 consecutive k of one n, write them down a column
+#pragma unroll
+            for (int p = 0; p < 2 * NB; ++p) {
+                const int n = r0 + 16 * p;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (n < N) v = ld4(B + (int64_t)n * ldb + k, Kdim - k, vecb);
+                Bs[(4 * c4 + 0) * LDB + n] = v.x;
+                Bs[(4 * c4 + 1) * LDB + n] = v.y;
+                Bs[(4 * c4 + 2) * LDB + n] = v.z;
+                Bs[(4 * c4 + 3) * LDB + n] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 2 * NB; ++p) {
+                const int idx = tid + 256 * p;
+                const int kk = idx / (8 * NB), q = idx % (8 * NB);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (k0 + kk < Kdim) v = ld4(B + (int64_t)(k0 + kk) * ldb + 4 * q, N - 4 * q, vecb);
+                *reinterpret_cast<f32x4*>(Bs + kk * LDB + 4 * q) = v;
+            }
+        }
+        __syncthreads();
+        if (32 * wv < rows) {
+            const float* xa = Xs + (32 * wv + r) * kLDA + hi * (kBK / 2);
+            const float* xb = Bs + hi * (kBK / 2) * LDB + r;
+#pragma unroll
+            for (int kq = 0; kq < kBK / 8; ++kq) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(xa + 4 * kq);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float* bp = xb + (4 * kq + c) * LDB;
+                    const float av = a[c];
+#pragma unroll
+                    for (int n = 0; n < NB; ++n)
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[32 * n], acc[n], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const int col = 32 * n + r;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = 32 * wv + acc_row(i, lane);
+            if (row < rows && col < N) {
+                const int64_t o = (int64_t)s_row[row] * ldo + col;
+                out[o] = add ? acc[n][i] + add[o] : acc[n][i];
+            }
+        }
+    }
+}
+
+static size_t rows_gemm_lds(int nb) { return (size_t)(kBT * kLDA + kBK * (32 * nb + 4)) * 4 + kBT * 4; }
+
+template <bool B_IS_NK, bool TYPED>
+static int launch_rows_gemm(const float* X, int ldx, const int32_t* order, const int32_t* type_ptr, int K_types,
+                            const float* B, int64_t b_type_stride, int ldb, const float* add, float* out, int ldo,
+                            int64_t R, int Kdim, int N, hipStream_t s, const char* what) {
+    const int nb = (N + 31) / 32;
+    const int64_t tiles = TYPED ? ceil_div(R, kBT) + K_types : ceil_div(R, kBT);
+    const dim3 grid((unsigned)tiles), block(256);
+    const size_t lds = rows_gemm_lds(nb);
+#define MPNN_RG_CASE(NB)                                                                                               \
+    case NB:                                                                                                           \
+        if (lds > 48 * 1024)                                                                                           \
+            (void)hipFuncSetAttribute((const void*)rows_gemm_kernel<NB, B_IS_NK, TYPED>,                               \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+        hipLaunchKernelGGL((rows_gemm_kernel<NB, B_IS_NK, TYPED>), grid, block, lds, s, X, ldx, order, type_ptr,       \
+                           K_types, B, b_type_stride, ldb, add, out, ldo, R, Kdim, N);                                 \
+        break;
+    switch (nb) {
+        MPNN_RG_CASE(1)
+        MPNN_RG_CASE(2)
+        MPNN_RG_CASE(3)
+        MPNN_RG_CASE(4)
+        MPNN_RG_CASE(5)
+        MPNN_RG_CASE(6)
+        MPNN_RG_CASE(7)
+        MPNN_RG_CASE(8)
+        default:
+            set_error("%s: N=%d wider than 256 columns", what, N);
+            return MPNN_EINVAL;
+    }
+#undef MPNN_RG_CASE
+    return launch_status(what);
+}
+
+// ------------------------------------------------------------------------------------ tn_accumulate
+// C[type][a, b] += sum_rows X[xrow, a] * (gate[xrow, b] *) Y[yrow, b]      a < M, b < N
+//   TYPED: rows of a tile are edges e = order[start+r]; xrow = e, yrow = src[e], gate row = e
+//   else : xrow = yrow = start + r
+// grid.y enumerates 64x64 blocks of C; grid.x blocks each own a contiguous range of row tiles and
+// keep their partial C in registers until the type changes or the range ends (one atomic flush).
+template <bool TYPED>
+__global__ void __launch_bounds__(256) tn_accumulate_kernel(const float* __restrict__ X, int ldx, int M,
+                                                            const float* __restrict__ Y, int ldy, int N,
+                                                            const int32_t* __restrict__ order,
+                                                            const int32_t* __restrict__ src,
+                                                            const float* __restrict__ gate,
+                                                            const int32_t* __restrict__ type_ptr, int K_types,
+                                                            float* C, float* colsum, int64_t R) {
+    __shared__ __attribute__((aligned(16))) float Xs[kBT * kLDA];
+    __shared__ __attribute__((aligned(16))) float Ys[kBT * kLDA];
+    __shared__ int s_x[kBT];
+    __shared__ int s_y[kBT];
+
+    const int nbc = (N + 63) / 64;
+    const int a0 = (blockIdx.y / nbc) * 64, b0 = (blockIdx.y % nbc) * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wa = wv >> 1, wb = wv & 1;
+    const int c4 = tid & 15, r0 = tid >> 4;
+    const int i = lane & 31, hi = lane >> 5;
+    const bool vecx = ((ldx & 3) == 0) && ((M & 3) == 0);
+    const bool vecy = ((ldy & 3) == 0) && ((N & 3) == 0);
+
+    const int total = TYPED ? count_tiles(type_ptr, K_types) : (int)ceil_div(R, kBT);
+    const int per = (total + gridDim.x - 1) / gridDim.x;
+    const int t_lo = blockIdx.x * per, t_hi = min(total, t_lo + per);
+
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    float cs = 0.f;
+    int cur_type = -1;
+
+    auto flush = [&](int type) {
+        float* Ct = C + (int64_t)type * M * N;
+        const int col = b0 + 32 * wb + i;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = a0 + 32 * wa + acc_row(q, lane);
+            if (row < M && col < N) atomicAdd(Ct + (int64_t)row * N + col, acc[q]);
+            acc[q] = 0.f;
+        }
+    };
+
+    for (int t = t_lo; t < t_hi; ++t) {
+        int type = 0, start, rows;
+        if (TYPED) {
+            find_tile(type_ptr, K_types, t, &type, &start, &rows);
+        } else {
+            start = t * kBT;
+            rows = (int)min((int64_t)kBT, R - (int64_t)start);
+        }
+        if (type != cur_type) {
+            if (cur_type >= 0) flush(cur_type);
+            cur_type = type;
+        }
+        __syncthreads();   // previous tile's LDS reads are done
+        if (tid < kBT) {
+            int xr = -1, yr = 0;
+            if (tid < rows) {
+                xr = TYPED ? order[start + tid] : start + tid;
+                yr = TYPED ? src[xr] : xr;
+            }
+            s_x[tid] = xr;
+            s_y[tid] = yr;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < kBT / 16; ++p) {
+            const int row = r0 + 16 * p;
+            f32x4 vx = {0.f, 0.f, 0.f, 0.f}, vy = {0.f, 0.f, 0.f, 0.f};
+            if (row < rows) {
+                const int ka = a0 + 4 * c4, kb = b0 + 4 * c4;
+                vx = ld4(X + (int64_t)s_x[row] * ldx + ka, M - ka, vecx);
+                vy = ld4(Y + (int64_t)s_y[row] * ldy + kb, N - kb, vecy);
+                if (gate) vy *= ld4(gate + (int64_t)s_x[row] * N + kb, N - kb, vecy);
+            }
+            *reinterpret_cast<f32x4*>(Xs + row * kLDA + 4 * c4) = vx;
+            *reinterpret_cast<f32x4*>(Ys + row * kLDA + 4 * c4) = vy;
+        }
+        __syncthreads();
+        const float* xa = Xs + hi * (kBT / 2) * kLDA + 32 * wa + i;
+        const float* yb = Ys + hi * (kBT / 2) * kLDA + 32 * wb + i;
+#pragma unroll 16
+        for (int s = 0; s < kBT / 2; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[s * kLDA], yb[s * kLDA], acc, 0, 0, 0);
+        if (colsum && a0 == 0 && tid < 64) {
+            float part = 0.f;
+            for (int rr = 0; rr < kBT; ++rr) part += Ys[rr * kLDA + tid];
+            cs += part;
+        }
+    }
+    if (cur_type >= 0) flush(cur_type);
+    if (colsum && a0 == 0 && tid < 64 && b0 + tid < N && t_hi > t_lo) atomicAdd(colsum + b0 + tid, cs);
+}
+
+// ------------------------------------------------------------------------------------ GRU gate gradients
+// From dout and the saved forward gates (r, z, n, gh_n) to the pre-activation gradients
+//   ws[row] = [ dgi_r dgi_z dgi_n | dgh_r dgh_z dgh_n ]   (6H floats)   and   dh_direct = dout*mask*z.
+// mask is 0/1 (as the reference's create_mask makes it): d sigma / d tanh use the masked gate values.
+__global__ void __launch_bounds__(256) gru_gate_grad_kernel(const float* __restrict__ dout, const float* __restrict__ h,
+                                                            const float* __restrict__ mask,
+                                                            const float* __restrict__ saved, float* __restrict__ ws,
+                                                            float* __restrict__ dh, int64_t V, int H) {
+    const int64_t total = V * H;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = idx / H;
+        const int col = (int)(idx - row * H);
+        const float mk = mask ? mask[row] : 1.0f;
+        const float* sv = saved + row * 4 * H + col;
+        const float r = sv[0], z = sv[H], n = sv[2 * H], nh = sv[3 * H];
+        const float g = dout[idx] * mk;                 // through the final "* mask"
+        const float dn = g * (1.0f - z);
+        const float dz = g * (h[idx] - n);
+        const float dan = dn * mk * (1.0f - n * n);     // n = tanh(.)*mask
+        const float dar = dan * nh * mk * r * (1.0f - r);
+        const float daz = dz * mk * z * (1.0f - z);
+        float* w = ws + row * 6 * H + col;
+        w[0] = dar;
+        w[H] = daz;
+        w[2 * H] = dan;
+        w[3 * H] = dar;
+        w[4 * H] = daz;
+        w[5 * H] = dan * r;
+        dh[idx] = g * z;
+    }
+}
+
+}  // namespace mpnn
+
+using namespace mpnn;
+
+extern "C" int mpnn_edge_message_bwd_f32(const float* h, const float* A, const int32_t* src, const int32_t* order,
+                                         const int32_t* type_ptr, const float* gate, const float* dmsg, float* dx,
+                                         float* dA, int64_t V, int64_t E, int K, int nf, int mf, void* stream) {
+    MPNN_REQUIRE(E >= 0 && V >= 0 && K >= 0, "mpnn_edge_message_bwd_f32: negative size");
+    MPNN_REQUIRE(nf > 0 && nf <= 256 && mf > 0 && mf <= MPNN_MAX_FEATURES,
+                 "mpnn_edge_message_bwd_f32: nf=%d mf=%d unsupported (nf<=256)", nf, mf);
+    MPNN_REQUIRE(E < (1ll << 31) && V < (1ll << 31), "mpnn_edge_message_bwd_f32: int32 index overflow");
+    if (E == 0) return MPNN_OK;
+    MPNN_REQUIRE(h && A && src && order && type_ptr && dmsg && K > 0, "mpnn_edge_message_bwd_f32: NULL buffer");
+    MPNN_REQUIRE(K <= 4096, "mpnn_edge_message_bwd_f32: K=%d edge types unsupported", K);
+    hipStream_t s = (hipStream_t)stream;
+    int rc = MPNN_OK;
+    if (dx) {
+        // dx[e, b] = sum_a dmsg[e, a] * A_k[a, b]  : X = dmsg (ld mf), B = A_k as [k=a][n=b]
+        rc = launch_rows_gemm<false, true>(dmsg, mf, order, type_ptr, K, A, (int64_t)mf * nf, nf, nullptr, dx, nf, E, mf,
+                                           nf, s, "mpnn_edge_message_bwd_f32(dx)");
+        if (rc) return rc;
+    }
+    if (dA) {
+        const int pairs = (int)(ceil_div(mf, 64) * ceil_div(nf, 64));
+        int64_t gx = ceil_div(E, kBT) + K;
+        if (gx > 1024) gx = 1024;
+        hipLaunchKernelGGL((tn_accumulate_kernel<true>), dim3((unsigned)gx, pairs), dim3(256), 0, s, dmsg, mf, mf, h, nf,
+                           nf, order, src, gate, type_ptr, K, dA, (float*)nullptr, E);
+        rc = launch_status("mpnn_edge_message_bwd_f32(dA)");
+    }
+    return rc;
+}
+
+extern "C" size_t mpnn_gru_bwd_workspace_bytes(int64_t V, int H) {
+    if (V < 0 || H <= 0) return 0;
+    return (size_t)V * 6 * H * sizeof(float);
+}
+
+extern "C" int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const float* h, const float* mask,
+                                       const float* W_ih, const float* W_hh, const float* saved, float* dm, float* dh,
+                                       float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, void* workspace,
+                                       size_t workspace_bytes, int64_t V, int H, void* stream) {
+    MPNN_REQUIRE(V >= 0 && H > 0 && H <= 256, "mpnn_gru_update_bwd_f32: V=%lld H=%d out of range (H<=256)",
+                 (long long)V, H);
+    if (V == 0) return MPNN_OK;
+    MPNN_REQUIRE(dout && m && h && W_ih && W_hh && saved && dm && dh && dW_ih && dW_hh && db_ih && db_hh,
+                 "mpnn_gru_update_bwd_f32: NULL buffer");
+    if (!workspace || workspace_bytes < mpnn_gru_bwd_workspace_bytes(V, H)) {
+        set_error("mpnn_gru_update_bwd_f32: workspace %zu < %zu", workspace_bytes, mpnn_gru_bwd_workspace_bytes(V, H));
+        return MPNN_EWORKSPACE;
+    }
+    MPNN_REQUIRE(V * 6 * (int64_t)H < (1ll << 40), "mpnn_gru_update_bwd_f32: V too large");
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    int64_t g = ceil_div(V * H, 256);
+    if (g > 256 * 16) g = 256 * 16;
+    hipLaunchKernelGGL(gru_gate_grad_kernel, dim3((unsigned)g), dim3(256), 0, s, dout, h, mask, saved, ws, dh, V, H);
+    int rc = launch_status("mpnn_gru_update_bwd_f32(gates)");
+    if (rc) return rc;
+    // dm = dgi . W_ih^T : B given as [n = input feature][k = gate column], ld 3H
+    rc = launch_rows_gemm<true, false>(ws, 6 * H, nullptr, nullptr, 0, W_ih, 0, 3 * H, nullptr, dm, H, V, 3 * H, H, s,
+                                       "mpnn_gru_update_bwd_f32(dm)");
+    if (rc) return rc;
+    // dh = dgh . W_hh^T + dout*mask*z   (the direct term already sits in dh)
+    rc = launch_rows_gemm<true, false>(ws + 3 * H, 6 * H, nullptr, nullptr, 0, W_hh, 0, 3 * H, dh, dh, H, V, 3 * H, H, s,
+                                       "mpnn_gru_update_bwd_f32(dh)");
+    if (rc) return rc;
+    const int pairs = (int)(ceil_div(H, 64) * ceil_div(3 * H, 64));
+    int64_t gx = ceil_div(V, kBT);
+    if (gx > 512) gx = 512;
+    hipLaunchKernelGGL((tn_accumulate_kernel<false>), dim3((unsigned)gx, pairs), dim3(256), 0, s, m, H, H, ws, 6 * H,
+                       3 * H, (const int32_t*)nullptr, (const int32_t*)nullptr, (const float*)nullptr,
+                       (const int32_t*)nullptr, 1, dW_ih, db_ih, V);
+    hipLaunchKernelGGL((tn_accumulate_kernel<false>), dim3((unsigned)gx, pairs), dim3(256), 0, s, h, H, H, ws + 3 * H,
+                       6 * H, 3 * H, (const int32_t*)nullptr, (const int32_t*)nullptr, (const float*)nullptr,
+                       (const int32_t*)nullptr, 1, dW_hh, db_hh, V);
+    return launch_status("mpnn_gru_update_bwd_f32(dW)");
+}

@@ -170,6 +170,9 @@ extern "C" int mpnn_edge_message_f32(const float* h, const float* A, const int32
     const size_t lds = message_lds_bytes(nb);
 #define MPNN_MSG_CASE(NB)                                                                                            \
     case NB:                                                                                                         \
+        if (lds > 48 * 1024)                                                                                         \
+            (void)hipFuncSetAttribute((const void*)edge_message_kernel<NB>,                                          \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
         hipLaunchKernelGGL((edge_message_kernel<NB>), grid, block, lds, s, h, A, src, order, type_ptr, gate, msg, K, \
                            nf, mf);                                                                                  \
         break;

@@ -141,6 +141,155 @@ __global__ void __launch_bounds__(256) gru_update_kernel(const float* __restrict
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Fast path (H a multiple of 32, weight slice fits LDS): persistent waves, no per-tile barrier.
+//
+// A block keeps the (H x 3*CS) slices of W_ih and W_hh for its CS = 32*NCS hidden columns resident
+// in LDS for its whole life (k-major, so a B fragment is one conflict-free ds_read_b32).  Each of
+// its 8 waves then walks 32-atom tiles on its own: the A fragments of v_mfma_f32_32x32x2_f32 are
+// the lane's own contiguous half-row of m / h (lane (r,hi) holds X[row r][hi*H/2 ...]), loaded
+// straight from global into registers -- no LDS image, no __syncthreads in the loop -- with the
+// next operand block requested before the current one is multiplied.
+template <int H, int NCS, int NW>   // NW waves per block (8 = two per SIMD; 4 when the fragments need >256 VGPRs)
+__global__ void __launch_bounds__(64 * NW) gru_update_resident_kernel(
+    const float* __restrict__ m, const float* __restrict__ h, const float* __restrict__ mask,
+    const float* __restrict__ W_ih, const float* __restrict__ W_hh, const float* __restrict__ b_ih,
+    const float* __restrict__ b_hh, float* __restrict__ out, float* __restrict__ saved, int64_t V, int slices) {
+    constexpr int CS = 32 * NCS;
+    constexpr int LDW = 3 * CS;              // multiple of 32: lanes j..j+31 hit 32 distinct banks
+    constexpr int NF4 = H / 8;               // float4 fragments per lane per operand
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* Wi = reinterpret_cast<float*>(smem_raw);     // [H][LDW]
+    float* Wh = Wi + H * LDW;                           // [H][LDW]
+
+    const int slice = blockIdx.x % slices;              // neighbouring blocks share the atom range
+    const int pblock = blockIdx.x / slices, pblocks = gridDim.x / slices;
+    const int c0 = slice * CS;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    // one-time weight slice load: W[k][g*H + c0 + c] -> Ws[k][g*CS + c]
+    for (int idx = tid; idx < H * (LDW / 4); idx += 64 * NW) {
+        const int k = idx / (LDW / 4), q = idx % (LDW / 4);
+        const int g = (4 * q) / CS, c = (4 * q) % CS;
+        const int64_t srcoff = (int64_t)k * 3 * H + g * H + c0 + c;
+        *reinterpret_cast<f32x4*>(Wi + k * LDW + 4 * q) = *reinterpret_cast<const f32x4*>(W_ih + srcoff);
+        *reinterpret_cast<f32x4*>(Wh + k * LDW + 4 * q) = *reinterpret_cast<const f32x4*>(W_hh + srcoff);
+    }
+    __syncthreads();
+
+    const int r = lane & 31, hi = lane >> 5;
+    float br[NCS], bz[NCS], bni[NCS], bnh[NCS];
+#pragma unroll
+    for (int s = 0; s < NCS; ++s) {
+        const int col = c0 + 32 * s + r;
+        br[s] = b_ih[col] + b_hh[col];
+        bz[s] = b_ih[H + col] + b_hh[H + col];
+        bni[s] = b_ih[2 * H + col];
+        bnh[s] = b_hh[2 * H + col];
+    }
+    const float* wi_lane = Wi + hi * (H / 2) * LDW + r;
+    const float* wh_lane = Wh + hi * (H / 2) * LDW + r;
+
+    const int64_t tiles = (V + 31) / 32;
+    const int64_t stride = (int64_t)pblocks * NW;
+    int64_t t = (int64_t)pblock * NW + wv;
+    if (t >= tiles) return;
+
+    f32x4 fa[NF4], fb[NF4];
+    auto load_frags = [&](const float* __restrict__ X, int64_t tile, f32x4 (&f)[NF4]) {
+        int64_t row = tile * 32 + r;
+        if (row >= V) row = V - 1;                       // clamp: loads stay in bounds, stores are skipped
+        const float* p = X + row * H + hi * (H / 2);
+#pragma unroll
+        for (int q = 0; q < NF4; ++q) f[q] = *reinterpret_cast<const f32x4*>(p + 4 * q);
+    };
+    load_frags(m, t, fa);
+    for (; t < tiles; t += stride) {
+        f32x16 acc_r[NCS], acc_z[NCS], acc_ni[NCS], acc_nh[NCS];
+#pragma unroll
+        for (int s = 0; s < NCS; ++s)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc_r[s][i] = 0.f; acc_z[s][i] = 0.f; acc_ni[s][i] = 0.f; acc_nh[s][i] = 0.f; }
+
+        load_frags(h, t, fb);                            // in flight while the m-products run
+#pragma unroll
+        for (int q = 0; q < NF4; ++q) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float av = fa[q][c];
+                const float* bp = wi_lane + (4 * q + c) * LDW;
+#pragma unroll
+                for (int s = 0; s < NCS; ++s) {
+                    acc_r[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[32 * s], acc_r[s], 0, 0, 0);
+                    acc_z[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[CS + 32 * s], acc_z[s], 0, 0, 0);
+                    acc_ni[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[2 * CS + 32 * s], acc_ni[s], 0, 0, 0);
+                }
+            }
+        }
+        if (t + stride < tiles) load_frags(m, t + stride, fa);   // next tile's m rows, behind the h-products
+#pragma unroll
+        for (int q = 0; q < NF4; ++q) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float av = fb[q][c];
+                const float* bp = wh_lane + (4 * q + c) * LDW;
+#pragma unroll
+                for (int s = 0; s < NCS; ++s) {
+                    acc_r[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[32 * s], acc_r[s], 0, 0, 0);
+                    acc_z[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[CS + 32 * s], acc_z[s], 0, 0, 0);
+                    acc_nh[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[2 * CS + 32 * s], acc_nh[s], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int64_t row = t * 32 + acc_row(i, lane);
+            if (row >= V) continue;
+            const float mk = mask ? mask[row] : 1.0f;
+#pragma unroll
+            for (int s = 0; s < NCS; ++s) {
+                const int col = c0 + 32 * s + r;
+                const float hv = h[row * H + col];
+                const float rg = sigmoidf_(acc_r[s][i] + br[s]) * mk;
+                const float zg = sigmoidf_(acc_z[s][i] + bz[s]) * mk;
+                const float nh = acc_nh[s][i] + bnh[s];
+                const float ng = tanhf(acc_ni[s][i] + bni[s] + rg * nh) * mk;
+                out[row * H + col] = ((1.0f - zg) * ng + zg * hv) * mk;
+                if (saved) {
+                    float* sv = saved + row * 4 * H + col;
+                    sv[0] = rg;
+                    sv[H] = zg;
+                    sv[2 * H] = ng;
+                    sv[3 * H] = nh;
+                }
+            }
+        }
+    }
+}
+
+template <int H, int NCS, int NW>
+static int launch_gru_resident(const float* m, const float* h, const float* mask, const float* W_ih, const float* W_hh,
+                               const float* b_ih, const float* b_hh, float* out, float* saved, int64_t V,
+                               hipStream_t s) {
+    constexpr int CS = 32 * NCS;
+    constexpr int slices = H / CS;
+    const size_t lds = (size_t)2 * H * 3 * CS * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gru_update_resident_kernel<H, NCS, NW>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int64_t tiles = (V + 31) / 32;
+    int64_t pblocks = (256 + slices - 1) / slices;        // one block per CU (LDS-bound residency)
+    if (pblocks * NW > tiles) pblocks = (tiles + NW - 1) / NW;
+    if (pblocks < 1) pblocks = 1;
+    hipLaunchKernelGGL((gru_update_resident_kernel<H, NCS, NW>), dim3((unsigned)(pblocks * slices)), dim3(64 * NW), lds, s, m,
+                       h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, slices);
+    return launch_status("mpnn_gru_update_f32(resident)");
+}
+
 }  // namespace mpnn
 
 using namespace mpnn;
@@ -157,6 +306,10 @@ extern "C" int mpnn_gru_update_f32(const float* m, const float* h, const float* 
                              reinterpret_cast<uintptr_t>(W_ih) | reinterpret_cast<uintptr_t>(W_hh);
         MPNN_REQUIRE(al % 16 == 0, "mpnn_gru_update_f32: buffers must be 16-byte aligned");
     }
+    hipStream_t st = (hipStream_t)stream;
+    if (H == 64) return launch_gru_resident<64, 2, 8>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, st);
+    if (H == 128) return launch_gru_resident<128, 1, 4>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, st);
+    if (H == 32) return launch_gru_resident<32, 1, 8>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, st);
     const int64_t row_tiles = ceil_div(V, kRows);
     MPNN_REQUIRE(row_tiles < (1 << 24), "mpnn_gru_update_f32: V too large for one launch");
     const int col_slices = (H + 31) / 32;

@@ -135,9 +135,10 @@ class MolGraph:
         col_idx = torch.empty(E, dtype=torch.int32, device=dev)
         edge_weight = torch.empty(E, dtype=torch.float32, device=dev)
         edge_feat = torch.empty(E, ef, dtype=torch.float32, device=dev) if bfm is not None else None
-        _lib.check(lib.mpnn_csr_fill(_lib.fptr(adj_c), _lib.fptr(bfm_c), rows, N, ef, _lib.iptr(row_ptr),
-                                     _lib.iptr(col_idx), _lib.fptr(edge_weight), _lib.fptr(edge_feat),
-                                     _lib.stream()), "mpnn_csr_fill")
+        if E > 0:
+            _lib.check(lib.mpnn_csr_fill(_lib.fptr(adj_c), _lib.fptr(bfm_c), rows, N, ef, _lib.iptr(row_ptr),
+                                         _lib.iptr(col_idx), _lib.fptr(edge_weight), _lib.fptr(edge_feat),
+                                         _lib.stream()), "mpnn_csr_fill")
         if edge_feat is not None and E > 0:
             type_feat, inv = torch.unique(edge_feat, dim=0, return_inverse=True)
             edge_type = _i32(inv)

@@ -60,6 +60,8 @@ def _timed(name, fn):
 def segsum_raw(msg, row_ptr, w, num_rows):
     lib = _lib.load()
     F = int(msg.shape[-1])
+    if msg.shape[0] == 0 or num_rows == 0:          # no edges at all: every row is an empty sum
+        return torch.zeros(num_rows, F, dtype=torch.float32, device=msg.device)
     out = _empty((num_rows, F), msg)
     _lib.check(_timed("segsum", lambda: lib.mpnn_segsum_f32(
         _lib.fptr(msg), _lib.iptr(row_ptr), _lib.fptr(w), _lib.fptr(out), num_rows, F, _lib.stream())),
@@ -71,6 +73,8 @@ def segsum_bwd_raw(dout, row_ptr, w, num_edges):
     lib = _lib.load()
     V, F = int(dout.shape[0]), int(dout.shape[1])
     dmsg = _empty((num_edges, F), dout)
+    if num_edges == 0 or V == 0:
+        return dmsg
     _lib.check(lib.mpnn_segsum_bwd_f32(_lib.fptr(dout), _lib.iptr(row_ptr), _lib.fptr(w), _lib.fptr(dmsg),
                                        V, F, _lib.stream()), "mpnn_segsum_bwd_f32")
     return dmsg
@@ -79,6 +83,8 @@ def segsum_bwd_raw(dout, row_ptr, w, num_edges):
 def segsum_gather_raw(x, row_ptr, idx, w, num_rows):
     lib = _lib.load()
     F = int(x.shape[-1])
+    if x.shape[0] == 0 or num_rows == 0 or (idx is not None and idx.shape[0] == 0):
+        return torch.zeros(num_rows, F, dtype=torch.float32, device=x.device)
     out = _empty((num_rows, F), x)
     _lib.check(lib.mpnn_segsum_gather_f32(_lib.fptr(x), _lib.iptr(row_ptr), _lib.iptr(idx), _lib.fptr(w),
                                           _lib.fptr(out), num_rows, F, _lib.stream()), "mpnn_segsum_gather_f32")
@@ -90,6 +96,8 @@ def edge_message_raw(h, A, graph, gate=None):
     K, mf, nf = (int(s) for s in A.shape)
     E = graph.num_edges
     msg = _empty((E, mf), h)
+    if E == 0:
+        return msg
     _lib.check(_timed("edge_message", lambda: lib.mpnn_edge_message_f32(
         _lib.fptr(h), _lib.fptr(A), _lib.iptr(graph.col_idx), _lib.iptr(graph.order), _lib.iptr(graph.type_ptr),
         _lib.fptr(gate), _lib.fptr(msg), graph.num_nodes, E, K, nf, mf, _lib.stream())),
@@ -103,6 +111,8 @@ def edge_message_bwd_raw(h, A, graph, gate, dmsg):
     E = graph.num_edges
     dx = _empty((E, nf), h)
     dA = torch.zeros_like(A)
+    if E == 0:
+        return dx, dA
     _lib.check(lib.mpnn_edge_message_bwd_f32(_lib.fptr(h), _lib.fptr(A), _lib.iptr(graph.col_idx),
                                              _lib.iptr(graph.order), _lib.iptr(graph.type_ptr), _lib.fptr(gate),
                                              _lib.fptr(dmsg), _lib.fptr(dx), _lib.fptr(dA),

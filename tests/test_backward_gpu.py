@@ -1,0 +1,170 @@
+"""Gradients of the HIP path against gradients recorded from the REAL reference (g.in.* / g.p.* in
+tests/golden/*.npz: d(sum(out * cot)) / d(input | parameter))."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import Fixture, max_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    return max_err(a, b) / max(1.0, float(torch.as_tensor(b).abs().max()))
+
+
+def _check_param_grads(module, f, tol):
+    seen = 0
+    for k, p in module.named_parameters():
+        if k in f.gp:
+            assert p.grad is not None, k
+            assert _rel(p.grad.cpu(), f.gp[k]) < tol, (k, _rel(p.grad.cpu(), f.gp[k]))
+            seen += 1
+    assert seen > 0
+
+
+@pytest.mark.parametrize("tag,H", [("h8", 8), ("h22", 22), ("h64", 64)])
+def test_gru_update_backward(dev, tag, H):
+    from mpnn_amd.mpnn_functions import GRUUpdate
+    f = Fixture("gru_update_" + tag)
+    m = GRUUpdate(H, H).to(dev)
+    m.load_state_dict(f.params)
+    msg = f.inputs["messages"].to(dev).requires_grad_(True)
+    h = f.inputs["node_states"].to(dev).requires_grad_(True)
+    out = m(msg, h, f.inputs["mask"].to(dev))
+    (out * f.cot.to(dev)).sum().backward()
+    assert _rel(msg.grad.cpu(), f.gin["messages"]) < TOL
+    assert _rel(h.grad.cpu(), f.gin["node_states"]) < TOL
+    _check_param_grads(m, f, TOL)
+
+
+@pytest.mark.parametrize("V,H", [(300, 64), (1000, 128), (130, 256), (77, 40)])
+def test_gru_backward_random(dev, V, H):
+    from oracle import dense_ref as O
+    from mpnn_amd import ops
+    g = torch.Generator().manual_seed(V * 3 + H)
+    mk = lambda *s: (torch.rand(*s, generator=g) * 2 - 1)
+    m, h, cot = mk(V, H), mk(V, H), mk(V, H)
+    mask = (torch.rand(V, generator=g) < 0.8).float()
+    s = 1.0 / np.sqrt(H)
+    names = ("gru_cell.weight_ih", "gru_cell.weight_hh", "gru_cell.bias_ih", "gru_cell.bias_hh")
+    p = {names[0]: mk(H, 3 * H) * s, names[1]: mk(H, 3 * H) * s, names[2]: mk(3 * H) * 0.5, names[3]: mk(3 * H) * 0.5}
+    leaves = [t.clone().requires_grad_(True) for t in (m, h, *[p[n] for n in names])]
+    ref = O.gru_update(dict(zip(names, leaves[2:])), leaves[0], leaves[1], mask.view(-1, 1))
+    gref = torch.autograd.grad((ref * cot).sum(), leaves)
+    dl = [t.clone().to(dev).requires_grad_(True) for t in (m, h, *[p[n] for n in names])]
+    out = ops.gru_update(dl[0], dl[1], mask.to(dev), *dl[2:])
+    ggpu = torch.autograd.grad((out * cot.to(dev)).sum(), dl)
+    for a, b, name in zip(ggpu, gref, ("dm", "dh") + names):
+        assert _rel(a.cpu(), b) < 2e-5, (name, _rel(a.cpu(), b))
+
+
+@pytest.mark.parametrize("nf,mf,K,V", [(8, 8, 4, 60), (22, 22, 5, 333), (64, 64, 4, 3000), (128, 128, 4, 700),
+                                       (256, 256, 3, 300), (64, 32, 2, 500)])
+@pytest.mark.parametrize("gated", [False, True])
+def test_edge_message_backward(dev, nf, mf, K, V, gated):
+    from mpnn_amd import ops
+    from mpnn_amd.graph import MolGraph
+    rng = np.random.default_rng(nf + mf + K + V)
+    deg = rng.integers(0, 6, V)
+    row_ptr = np.zeros(V + 1, np.int32)
+    np.cumsum(deg, out=row_ptr[1:])
+    E = int(row_ptr[-1])
+    col = rng.integers(0, V, E).astype(np.int32)
+    et = rng.integers(0, K, E).astype(np.int32)
+    h = torch.from_numpy(rng.standard_normal((V, nf)).astype(np.float32))
+    A = torch.from_numpy((rng.standard_normal((K, mf, nf)) / np.sqrt(nf)).astype(np.float32))
+    gate = torch.from_numpy(rng.random((E, nf)).astype(np.float32)) if gated else None
+    cot = torch.from_numpy(rng.standard_normal((E, mf)).astype(np.float32))
+    # CPU reference in float64
+    hd, Ad = h.double().requires_grad_(True), A.double().requires_grad_(True)
+    gd = gate.double().requires_grad_(True) if gated else None
+    x = hd[col.astype(np.int64)] * (gd if gated else 1.0)
+    ref = torch.einsum("emn,en->em", Ad[et.astype(np.int64)], x)
+    gref = torch.autograd.grad((ref * cot.double()).sum(), [hd, Ad] + ([gd] if gated else []))
+    t = lambda a: torch.from_numpy(a).to(dev)
+    g = MolGraph(t(row_ptr), t(col), None, t(et), torch.zeros(K, 1, device=dev),
+                 torch.tensor([0, V], dtype=torch.int32, device=dev))
+    hg, Ag = h.to(dev).requires_grad_(True), A.to(dev).requires_grad_(True)
+    gg = gate.to(dev).requires_grad_(True) if gated else None
+    out = ops.edge_message(hg, Ag, g, gate=gg)
+    ggpu = torch.autograd.grad((out * cot.to(dev)).sum(), [hg, Ag] + ([gg] if gated else []))
+    for a, b, name in zip(ggpu, gref, ("dh", "dA", "dgate")):
+        assert _rel(a.cpu(), b) < 2e-5, (name, _rel(a.cpu(), b))
+
+
+@pytest.mark.parametrize("tag,nf,ef", [("h8_rand", 8, 4), ("h22_rand", 22, 7), ("h8_cont", 8, 4)])
+def test_edge_network_backward(dev, tag, nf, ef):
+    """Gradients flow through the HIP message + aggregator AND back into the tower parameters
+    (dA from the kernel, tower by torch autograd on the K distinct rows)."""
+    from mpnn_amd.mpnn_functions import AdjMsgAgg, EdgeNetwork
+    # (a) per-pair form aggregated over real edges -- what BasicModel consumes
+    f = Fixture("edge_network_%s_pairagg" % tag)
+    m = EdgeNetwork(nf, ef, nf).to(dev)
+    m.load_state_dict(f.params)
+    m.pairwise = True
+    afm = f.inputs["afm"].to(dev).requires_grad_(True)
+    out = AdjMsgAgg(9)(m(afm, f.inputs["bfm"].to(dev)), f.inputs["adj"].to(dev))
+    (out * f.cot.to(dev)).sum().backward()
+    assert _rel(afm.grad.cpu(), f.gin["afm"]) < TOL
+    _check_param_grads(m, f, 2e-5)
+    # (b) HEAD-fused form (non-member pairs and message_bias included)
+    f = Fixture("edge_network_" + tag)
+    m = EdgeNetwork(nf, ef, nf).to(dev)
+    m.load_state_dict(f.params)
+    afm = f.inputs["afm"].to(dev).requires_grad_(True)
+    out = m(afm, f.inputs["bfm"].to(dev))
+    (out * f.cot.to(dev)).sum().backward()
+    assert _rel(afm.grad.cpu(), f.gin["afm"]) < 2e-5
+    _check_param_grads(m, f, 5e-5)
+
+
+@pytest.mark.parametrize("tag,nf,ef", [("h8", 8, 4), ("h22", 22, 7)])
+def test_att_edge_network_backward(dev, tag, nf, ef):
+    from mpnn_amd.mpnn_functions import AdjMsgAgg, AttEdgeNetwork
+    f = Fixture("att_edge_network_" + tag)
+    m = AttEdgeNetwork(nf, ef, nf).to(dev)
+    m.load_state_dict(f.params)
+    afm = f.inputs["afm"].to(dev).requires_grad_(True)
+    out = AdjMsgAgg(9)(m(afm, f.inputs["bfm"].to(dev)), f.inputs["adj"].to(dev))
+    (out * f.cot.to(dev)).sum().backward()
+    assert _rel(afm.grad.cpu(), f.gin["afm"]) < TOL
+    _check_param_grads(m, f, 2e-5)
+
+
+@pytest.mark.parametrize("tag,H,ef", [("h8", 8, 4), ("h22", 22, 7)])
+def test_basic_model_backward(dev, tag, H, ef):
+    from mpnn_amd.models.basic_model import BasicModel
+    from mpnn_amd.models.graph_model_wrapper import GraphWrapper
+    f = Fixture("model_basic_" + tag)
+    model = GraphWrapper(BasicModel(H, ef, H, 9, 6, message_opts={}, agg_opts={}, update_opts={},
+                                    readout_opts={})).to(dev)
+    model.load_state_dict(f.params)
+    batch = {k: v.to(dev) for k, v in f.inputs.items()}
+    batch["afm"].requires_grad_(True)
+    out = model(batch)
+    (out * f.cot.to(dev)).sum().backward()
+    assert _rel(batch["afm"].grad.cpu(), f.gin["afm"]) < 2e-5
+    _check_param_grads(model, f, 5e-5)
+
+
+def test_lipo_model_backward(dev):
+    from mpnn_amd.models.graph_norm_wrapper import GraphWrapper
+    from mpnn_amd.models.lipo_basic_model import BasicModel
+    f = Fixture("model_lipo_T3_train")
+    model = GraphWrapper(BasicModel(22, 7, 22, 9, 38, message_opts={}, agg_opts={}, update_opts={},
+                                    readout_opts={}, message_steps=3), 3).to(dev)
+    sd = dict(f.params)
+    sd.update(f.pre)
+    model.load_state_dict(sd)
+    model.train()
+    out = model({k: v.to(dev) for k, v in f.inputs.items()})
+    (out * f.cot.to(dev)).sum().backward()
+    _check_param_grads(model, f, 2e-4)      # six chained batch norms in the backward chain

@@ -112,7 +112,8 @@ def test_segsum_empty_and_long_rows(dev):
     np.cumsum(deg, out=row_ptr[1:])
     msg = torch.from_numpy(rng.standard_normal((int(row_ptr[-1]), 64)).astype(np.float32))
     out = ops.segsum_raw(msg.to(dev), torch.from_numpy(row_ptr).to(dev), None, 8)
-    assert max_err(out.cpu(), _segsum_oracle(msg, row_ptr, None)) < 5e-5     # 1500-term fp32 sums
+    ref = _segsum_oracle(msg, row_ptr, None)
+    assert max_err(out.cpu(), ref) < TOL * float(ref.abs().max())        # 1500-term fp32 sums, |sum| ~ 100
     z = ops.segsum_raw(torch.zeros(0, 64, device=dev), torch.zeros(5, dtype=torch.int32, device=dev), None, 4)
     assert z.shape == (4, 64) and float(z.abs().sum()) == 0.0
 

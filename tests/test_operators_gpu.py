@@ -169,7 +169,8 @@ def test_lipo_model_forward(dev, T, mode):
     if mode == "train":
         for k, v in model.state_dict().items():
             if "running_" in k:
-                assert max_err(v.cpu(), f.params[k]) < 1e-5, k
+                # messages of the 50-layer tower are O(500): compare relative to the statistic's scale
+                assert max_err(v.cpu(), f.params[k]) < 1e-5 * max(1.0, float(f.params[k].abs().max())), k
 
 
 def test_sparse_native_batch_equals_dense_batch(dev):
