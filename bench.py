@@ -146,20 +146,20 @@ def main():
     torch.manual_seed(317)                               # same weights on every rank
     model = BasicModel(hidden, 4, hidden, 50, 8, message_opts={}, agg_opts={}, update_opts={}, readout_opts={},
                        message_steps=T).to(dev)
-    params = [p for p in model.parameters() if p.requires_grad]
+    from mpnn_amd import parallel
+    hot = [p for n, p in model.named_parameters() if not n.startswith("of.")]   # readout is off the hot path
+    bucket = parallel.GradientBucket(hot) if args.mode == "train" else None
+    total_mols = parallel.global_count(mols, dev) if args.mode == "train" else float(mols)
 
     def step():
         if args.mode == "fwd":
             with torch.no_grad():
                 state, _ = model.message_passing(afm, graph, graph, mask)
             return state
-        for p in params:
-            p.grad = None
+        bucket.zero()
         state, _ = model.message_passing(afm, graph, graph, mask)
-        state.sum().backward()
-        if dist is not None:
-            flat = torch.cat([p.grad.reshape(-1) for p in params if p.grad is not None])
-            dist.all_reduce(flat)                        # one RCCL all-reduce of the flat gradient bucket
+        (state.sum() / total_mols).backward()            # this shard's share of a global mean loss
+        bucket.all_reduce()                              # ONE RCCL all-reduce of the flat gradient bucket
         return state
 
     def fence():

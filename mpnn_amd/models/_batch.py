@@ -1,5 +1,5 @@
 """Batch plumbing shared by the models: dense padded tensors or a sparse-native MolGraph."""
-from ..graph import MolGraph
+from mpnn_amd.graph import MolGraph
 
 
 def graph_of(afm, bfm, adj):

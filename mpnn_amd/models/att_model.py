@@ -4,7 +4,7 @@ hot path and not importable without rdkit); GraphLevelOutput is the default here
 import torch
 from torch import nn
 
-from ..mpnn_functions import AdjMsgAgg, AttEdgeNetwork, GraphLevelOutput, GRUUpdate
+from mpnn_amd.mpnn_functions import AdjMsgAgg, AttEdgeNetwork, GraphLevelOutput, GRUUpdate
 from ._batch import graph_of
 from .mask_batch_norm import MaskBatchNorm
 

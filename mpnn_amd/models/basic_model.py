@@ -13,8 +13,8 @@ the ORIGINAL atom features; `hoist_message=True` computes message+aggregate once
 import torch
 from torch import nn
 
-from ..graph import MolGraph
-from ..mpnn_functions import AdjMsgAgg, EdgeNetwork, GraphLevelOutput, GRUUpdate
+from mpnn_amd.graph import MolGraph
+from mpnn_amd.mpnn_functions import AdjMsgAgg, EdgeNetwork, GraphLevelOutput, GRUUpdate
 from ._batch import graph_of
 
 

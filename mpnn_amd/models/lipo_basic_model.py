@@ -4,8 +4,8 @@ Reference: models/lipo_basic_model.py:8-107 (forward :81-86, init_weights :88-10
 import torch
 from torch import nn
 
-from ..mpnn_functions import AdjMsgAgg, EdgeNetwork, GraphLevelOutput, GRUUpdate
-from ..mpnn_functions.message.ggnn_msg_pass import GGNNMsgPass  # noqa: F401  (re-exported like the reference)
+from mpnn_amd.mpnn_functions import AdjMsgAgg, EdgeNetwork, GraphLevelOutput, GRUUpdate
+from mpnn_amd.mpnn_functions.message.ggnn_msg_pass import GGNNMsgPass  # noqa: F401  (re-exported like the reference)
 from ._batch import graph_of
 from .mask_batch_norm import MaskBatchNorm1d
 

@@ -10,8 +10,8 @@ argument of mpnn_edge_message_f32.  Always returns per-pair messages (as the ref
 import torch
 from torch import nn
 
-from ... import ops
-from ...messages import EdgeMessages
+from mpnn_amd import ops
+from mpnn_amd.messages import EdgeMessages
 from .edge_network import EdgeNetwork
 
 

@@ -16,9 +16,9 @@ it returns the per-pair messages of the legacy contract (edge_network.py:40,52) 
 import torch
 from torch import nn
 
-from ... import ops
-from ...graph import MolGraph
-from ...messages import EdgeMessages
+from mpnn_amd import ops
+from mpnn_amd.graph import MolGraph
+from mpnn_amd.messages import EdgeMessages
 
 
 class EdgeEmbed:

@@ -9,8 +9,8 @@ of `adj_w`.
 import torch
 from torch import nn
 
-from ... import ops
-from ...graph import MolGraph, _i32
+from mpnn_amd import ops
+from mpnn_amd.graph import MolGraph, _i32
 
 
 class GGNNMsgPass(nn.Module):

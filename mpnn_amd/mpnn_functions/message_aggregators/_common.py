@@ -1,8 +1,8 @@
 """Shared plumbing of the three aggregators: turn (messages, adj) into CSR rows + per-edge weights."""
 import torch
 
-from ...graph import MolGraph
-from ...messages import EdgeMessages
+from mpnn_amd.graph import MolGraph
+from mpnn_amd.messages import EdgeMessages
 
 
 def edge_adjacency(msgs, adj):

@@ -6,8 +6,8 @@ adj == 0 contribute nothing, hence no non-member correction here.
 """
 from torch import nn
 
-from ... import ops
-from ...messages import EdgeMessages
+from mpnn_amd import ops
+from mpnn_amd.messages import EdgeMessages
 from ._common import dense_rows, edge_adjacency
 
 

@@ -8,8 +8,8 @@ act(b), so they enter through EdgeMessages.nonedge_sum().
 import torch
 from torch import nn
 
-from ... import ops
-from ...messages import EdgeMessages
+from mpnn_amd import ops
+from mpnn_amd.messages import EdgeMessages
 from ._common import dense_rows, edge_adjacency
 
 

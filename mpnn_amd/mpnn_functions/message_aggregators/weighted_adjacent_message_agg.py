@@ -8,8 +8,8 @@ and padded pairs weigh exp(0)/Z_i each, so with d_i member pairs in a row of pad
 import torch
 from torch import nn
 
-from ... import ops
-from ...messages import EdgeMessages
+from mpnn_amd import ops
+from mpnn_amd.messages import EdgeMessages
 from ._common import dense_rows, edge_adjacency
 
 

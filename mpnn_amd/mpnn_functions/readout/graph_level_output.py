@@ -7,8 +7,8 @@ graph_ptr as row_ptr.  Dense batches sum over dim 1 exactly as the reference doe
 import torch
 from torch import nn
 
-from ... import ops
-from ...graph import MolGraph
+from mpnn_amd import ops
+from mpnn_amd.graph import MolGraph
 
 
 class GraphLevelOutput(nn.Module):

@@ -8,7 +8,7 @@ reference makes the op well-formed only for message_features == node_features.
 import torch
 from torch import nn
 
-from ... import ops
+from mpnn_amd import ops
 
 
 class GRUCell(nn.Module):

@@ -88,3 +88,23 @@ def test_synthetic_molecules():
     assert np.diff(sk.row_ptr).max() > 12                        # heavy-tailed hubs
     d = synth.to_dense(synth.select(mb, [3, 1, 4]))
     assert d["adj"].shape[0] == 3 and (d["adj"] == d["adj"].transpose(0, 2, 1)).all()
+
+
+def test_reference_module_names_importable_with_package_dir_on_path():
+    """INTEGRATION.md level 1: with mpnn_amd/ on sys.path the reference's own import lines work."""
+    import subprocess
+    import sys
+    from conftest import REPO
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "from mpnn_functions import *\n"
+            "from mpnn_functions.message.ggnn_msg_pass import GGNNMsgPass\n"
+            "from models.basic_model import BasicModel\n"
+            "from models.graph_model_wrapper import GraphWrapper\n"
+            "from models.lipo_basic_model import BasicModel as Lipo\n"
+            "from models.mask_batch_norm import MaskBatchNorm1d\n"
+            "m = GraphWrapper(BasicModel(8, 4, 8, 9, 6, message_func=EdgeNetwork, message_agg_func=AdjMsgAgg,"
+            " update_func=GRUUpdate, readout_func=GraphLevelOutput))\n"
+            "print(len(m.state_dict()))\n") % (REPO + "/mpnn_amd", REPO)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.strip() == "63"
