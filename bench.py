@@ -6,7 +6,9 @@
 One process per GPU (N>1: launched by torch.distributed.run, RCCL backend).  A "step" is one pass
 of the hot path over one resident batch: T message-passing rounds of
 EdgeNetwork message -> AdjMsgAgg -> GRUUpdate through models.basic_model.BasicModel
-(`--mode train` adds the backward pass and the RCCL gradient all-reduce).  Inputs are resident
+plus, in the default `--mode train`, the backward pass and the ONE RCCL all-reduce of the flat gradient
+bucket (the data-parallel step BASELINE.json's multi-GPU config describes); the forward-only rate of the
+same batch is measured in the same run and reported under "forward".  Inputs are resident
 in HBM before the timed region.  Molecules shard by graph: every rank holds its own 100k-molecule
 batch (weak scaling), no data-path collective.
 
@@ -42,10 +44,28 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--mode", default="fwd", choices=["fwd", "train"])
+    ap.add_argument("--mode", default="train", choices=["fwd", "train"],
+                    help="train (default) = forward + backward + gradient all-reduce; fwd = inference pass only")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     return ap.parse_args()
+
+
+def pmc_traffic(workload):
+    """Per-launch HBM bytes of the aggregator from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
+    WRITE_SIZE in separate runs of this same command, corrected as MI355X_MICROARCH.md prescribes; see
+    tools/pmc_summary.py).  PMC collection needs the profiler, so it cannot happen inside this process; the
+    figure is a property of (kernel, workload) and is reported with its source, or None when no pass exists."""
+    path = os.path.join(REPO, "profiles", "r01_pmc_%s.json" % workload)
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        for k, v in d["kernels"].items():
+            if "segsum_kernel" in k:
+                return v["hbm_bytes"], "profiles/" + os.path.basename(path)
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, None
 
 
 def usable_cores():
@@ -140,22 +160,21 @@ def main():
     mask = torch.ones(mb.num_atoms, 1, device=dev)
     V, E = graph.num_nodes, graph.num_edges
     graph.order, graph.type_ptr                          # index arrays built once, outside the timed region
-    if args.mode == "train":
-        graph.transpose, graph.edge_dst
-
     torch.manual_seed(317)                               # same weights on every rank
     model = BasicModel(hidden, 4, hidden, 50, 8, message_opts={}, agg_opts={}, update_opts={}, readout_opts={},
                        message_steps=T).to(dev)
     from mpnn_amd import parallel
     hot = [p for n, p in model.named_parameters() if not n.startswith("of.")]   # readout is off the hot path
-    bucket = parallel.GradientBucket(hot) if args.mode == "train" else None
-    total_mols = parallel.global_count(mols, dev) if args.mode == "train" else float(mols)
+    graph.transpose, graph.edge_dst
+    bucket = parallel.GradientBucket(hot)
+    total_mols = parallel.global_count(mols, dev)
 
-    def step():
-        if args.mode == "fwd":
-            with torch.no_grad():
-                state, _ = model.message_passing(afm, graph, graph, mask)
-            return state
+    def step_fwd():
+        with torch.no_grad():
+            state, _ = model.message_passing(afm, graph, graph, mask)
+        return state
+
+    def step_train():
         bucket.zero()
         state, _ = model.message_passing(afm, graph, graph, mask)
         (state.sum() / total_mols).backward()            # this shard's share of a global mean loss
@@ -168,31 +187,41 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    timer = ops.KernelTimer(["segsum", "edge_message", "gru_update"])
-    ops.set_kernel_timer(timer)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    ops.set_kernel_timer(None)
+    def timed(step, timer):
+        """W untimed steps, then exactly K steps between barrier+synchronize fences; max over ranks."""
+        for _ in range(args.warmup):
+            step()
+        ops.set_kernel_timer(timer)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        ops.set_kernel_timer(None)
+        t_max = torch.tensor([dt], device=dev, dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        return float(t_max.item())
 
-    t_max = torch.tensor([dt], device=dev, dtype=torch.float64)
     edges = torch.tensor([float(E)], device=dev, dtype=torch.float64)
     if dist is not None:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dist.all_reduce(edges)
-    dt = float(t_max.item())
     total_edges = float(edges.item())
+    timer = ops.KernelTimer(["segsum", "edge_message", "gru_update"])
+    if args.mode == "train":
+        dt_fwd = timed(step_fwd, None)
+        dt = timed(step_train, timer)
+    else:
+        dt_fwd = None
+        dt = timed(step_fwd, timer)
 
     if rank == 0:
         F = hidden
         seg_ms = timer.mean_ms("segsum")
         alg_bytes = 4.0 * F * (E + V) + 4.0 * (V + 1) + 4.0 * E     # msg rows + out rows + row_ptr + edge weights
         achieved = alg_bytes / (seg_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(args.workload)
         out = {
             "metric": "edges/sec (message+aggregate+update)",
             "value": total_edges * T * args.steps / dt,
@@ -206,15 +235,19 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "%s: %s" % (args.workload, desc), "mode": args.mode, "mols_per_gpu": mols,
+            "config": {"workload": "%s: %s" % (args.workload, desc), "mode": ("train: forward + backward + flat-gradient all-reduce" if args.mode == "train" else "forward only"), "mols_per_gpu": mols,
                        "atoms_per_gpu": V, "edges_per_gpu": E, "hidden": hidden, "mp_steps": T,
                        "edge_features": 4, "edge_types": graph.num_types, "parallelism": "dp%d" % world,
                        "edges_counted": "directed edges x MP steps per pass"},
             "roofline": {"kernel": "segsum_kernel (aggregator, mpnn_segsum_f32)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "avg_launch_ms": seg_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                         "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": seg_ms, "algorithmic_bytes_per_launch": alg_bytes},
             "kernels_ms": {k: timer.mean_ms(k) for k in ("edge_message", "segsum", "gru_update")},
         }
+        if dt_fwd is not None:
+            out["forward"] = {"value": total_edges * T * args.steps / dt_fwd, "unit": "edges/s",
+                              "ms_per_step": dt_fwd / args.steps * 1e3,
+                              "note": "same batch, inference pass only (no backward, no all-reduce)"}
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(mb, hidden, T, args.mode, args.cpu_seconds)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

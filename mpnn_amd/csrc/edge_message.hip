@@ -140,6 +140,137 @@ __global__ void __launch_bounds__(256) edge_message_kernel(const float* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fast path (nf in {32, 64, 128}): matrix resident in LDS per type, no barrier inside a type.
+//
+// A block walks the K types in order.  For type k it stages A_k once (LDS image [n][k], stride
+// nf+4), then each of its 8 waves takes 32-edge tiles of that type on its own: the MFMA A-fragment
+// of lane (r,hi) is the contiguous half-row h[src(e_r)][hi*nf/2 ...] gathered straight from global
+// into registers (full 128-B segments, mostly L2 hits: a molecule's atoms are neighbouring rows),
+// the next tile's rows and the tile-after-next's indices are requested before the current tile is
+// multiplied.  Stores go to the destination-sorted slot e (one 128-B row segment per half-wave).
+template <int NF, int NB>
+__global__ void __launch_bounds__(512) edge_message_resident_kernel(
+    const float* __restrict__ h, const float* __restrict__ A, const int32_t* __restrict__ src,
+    const int32_t* __restrict__ order, const int32_t* __restrict__ type_ptr, const float* __restrict__ gate,
+    float* __restrict__ msg, int K, int mf) {
+    constexpr int LD = NF + 4;
+    constexpr int NF4 = NF / 8;                         // float4 fragments per lane
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* As = reinterpret_cast<float*>(smem_raw);     // [32*NB][LD]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 31, hi = lane >> 5;
+    const int gw = blockIdx.x * 8 + wv, nw = gridDim.x * 8;
+
+    for (int k = 0; k < K; ++k) {
+        const int tb = type_ptr[k], te = type_ptr[k + 1];
+        if (te == tb) continue;                         // uniform over the grid
+        __syncthreads();                                // everyone is done with the previous matrix
+        const float* Ak = A + (int64_t)k * mf * NF;
+        for (int idx = tid; idx < 32 * NB * (NF / 4); idx += 512) {
+            const int n = idx / (NF / 4), q = idx % (NF / 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (n < mf) v = *reinterpret_cast<const f32x4*>(Ak + (int64_t)n * NF + 4 * q);
+            *reinterpret_cast<f32x4*>(As + n * LD + 4 * q) = v;
+        }
+        __syncthreads();
+
+        const int tiles = (te - tb + 31) / 32;
+        int t = gw;
+        if (t >= tiles) continue;
+        // lane r owns edge slot tb + 32*t + r of the type-sorted list (slots past the end re-use the
+        // tile's first edge for loads and are skipped at the store)
+        auto edge_of = [&](int tile) {
+            const int pos = tb + 32 * tile + r;
+            return order[pos < te ? pos : tb + 32 * tile];
+        };
+        auto load_rows = [&](int s_row, int e_row, f32x4 (&f)[NF4]) {
+            const float* p = h + (int64_t)s_row * NF + hi * (NF / 2);
+#pragma unroll
+            for (int q = 0; q < NF4; ++q) f[q] = *reinterpret_cast<const f32x4*>(p + 4 * q);
+            if (gate) {
+                const float* g = gate + (int64_t)e_row * NF + hi * (NF / 2);
+#pragma unroll
+                for (int q = 0; q < NF4; ++q) f[q] *= *reinterpret_cast<const f32x4*>(g + 4 * q);
+            }
+        };
+        int e_cur = edge_of(t);
+        int s_cur = src[e_cur];
+        f32x4 f_cur[NF4], f_nxt[NF4];
+        load_rows(s_cur, e_cur, f_cur);
+        int e_nxt = e_cur, s_nxt = s_cur;
+        if (t + nw < tiles) { e_nxt = edge_of(t + nw); s_nxt = src[e_nxt]; }
+
+        for (; t < tiles; t += nw) {
+            const bool has1 = t + nw < tiles, has2 = t + 2 * nw < tiles;
+            if (has1) load_rows(s_nxt, e_nxt, f_nxt);            // next tile's rows: in flight under the MFMAs
+            int e_nn = e_nxt;
+            if (has2) e_nn = edge_of(t + 2 * nw);
+
+            f32x16 acc[NB];
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
+            const float* xb = As + r * LD + hi * (NF / 2);
+#pragma unroll
+            for (int q = 0; q < NF4; ++q) {
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(xb + 32 * n * LD + 4 * q);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f_cur[q].x, b.x, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f_cur[q].y, b.y, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f_cur[q].z, b.z, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f_cur[q].w, b.w, acc[n], 0, 0, 0);
+                }
+            }
+            int s_nn = s_nxt;
+            if (has2) s_nn = src[e_nn];                          // index of the tile after next
+
+            const int rows = min(32, te - tb - 32 * t);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = acc_row(i, lane);                // = const(i) + 4*hi
+                const int e_row = __shfl(e_cur, row);            // lane `row` holds that edge's id
+                if (row < rows) {
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) {
+                        const int col = 32 * n + r;
+                        if (col < mf) msg[(int64_t)e_row * mf + col] = acc[n][i];
+                    }
+                }
+            }
+            e_cur = e_nxt;
+            s_cur = s_nxt;
+            e_nxt = e_nn;
+            s_nxt = s_nn;
+#pragma unroll
+            for (int q = 0; q < NF4; ++q) f_cur[q] = f_nxt[q];
+        }
+    }
+}
+
+template <int NF, int NB>
+static int launch_message_resident(const float* h, const float* A, const int32_t* src, const int32_t* order,
+                                   const int32_t* type_ptr, const float* gate, float* msg, int64_t E, int K, int mf,
+                                   hipStream_t s) {
+    const size_t lds = (size_t)32 * NB * (NF + 4) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done && lds > 48 * 1024) {
+        (void)hipFuncSetAttribute((const void*)edge_message_resident_kernel<NF, NB>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    int64_t blocks = 512;                                   // 2 blocks of 8 waves per CU
+    const int64_t need = ceil_div(ceil_div(E, 32) + K, 8);
+    if (blocks > need) blocks = need;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((edge_message_resident_kernel<NF, NB>), dim3((unsigned)blocks), dim3(512), lds, s, h, A, src,
+                       order, type_ptr, gate, msg, K, mf);
+    return launch_status("mpnn_edge_message_f32(resident)");
+}
+
 static size_t message_lds_bytes(int nb) {
     return (size_t)(kTileEdges * kLD + 32 * nb * kLD) * sizeof(float) + 2 * kTileEdges * sizeof(int);
 }
@@ -164,6 +295,12 @@ extern "C" int mpnn_edge_message_f32(const float* h, const float* A, const int32
         MPNN_REQUIRE(al % 16 == 0, "mpnn_edge_message_f32: buffers must be 16-byte aligned");
     }
     const int nb = (mf + 31) / 32;
+    hipStream_t st = (hipStream_t)stream;
+    if (K <= 64) {      // resident-matrix fast path: the type loop is sequential, keep K small
+        if (nf == 64 && nb == 2) return launch_message_resident<64, 2>(h, A, src, order, type_ptr, gate, msg, E, K, mf, st);
+        if (nf == 64 && nb == 1) return launch_message_resident<64, 1>(h, A, src, order, type_ptr, gate, msg, E, K, mf, st);
+        if (nf == 32 && nb == 1) return launch_message_resident<32, 1>(h, A, src, order, type_ptr, gate, msg, E, K, mf, st);
+    }
     const int64_t tiles = ceil_div(E, kTileEdges) + K;   // upper bound; surplus blocks exit at once
     const dim3 grid((unsigned)tiles), block(256);
     hipStream_t s = (hipStream_t)stream;

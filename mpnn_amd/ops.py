@@ -219,7 +219,7 @@ class GRUUpdateFn(torch.autograd.Function):
     def forward(ctx, m, h, mask, W_ih, W_hh, b_ih, b_hh):
         m, h = m.contiguous(), h.contiguous()
         mask = mask.contiguous() if mask is not None else None
-        need = any(ctx.needs_input_grad)
+        need = torch.is_grad_enabled() and any(ctx.needs_input_grad)   # no gate dump on inference passes
         out, saved = gru_update_raw(m, h, mask, W_ih.contiguous(), W_hh.contiguous(), b_ih.contiguous(),
                                     b_hh.contiguous(), need)
         if need:

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, --kernel-trace only) of
+`bench.py` into per-launch HBM traffic for the mpnn kernels, with the gfx950 corrections of
+MI355X_MICROARCH.md "HBM": counters are in KiB; FETCH_SIZE reports exactly half of a wide
+(16 B/lane) coalesced read stream, WRITE_SIZE is exact for 16-B-per-lane stores.
+
+    python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_c2.json
+"""
+import csv
+import glob
+import json
+import sys
+
+
+def per_kernel(dirname, counter):
+    f = glob.glob(dirname + "/**/*counter_collection.csv", recursive=True)[0]
+    acc = {}
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter and "mpnn::" in r["Kernel_Name"]:
+            acc.setdefault(r["Kernel_Name"].split("(")[0].replace("void ", ""), []).append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+
+
+def main():
+    fetch, n = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write, _ = per_kernel(sys.argv[2], "WRITE_SIZE")
+    out = {"workload": "c2", "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) "
+                                        "-- python3 bench.py --steps 2 --warmup 1 --no-cpu --mode fwd",
+           "corrections": "KiB -> bytes (x1024); FETCH_SIZE x2 (gfx950 counts a 16 B/lane coalesced stream at half)",
+           "kernels": {}}
+    for k in fetch:
+        rd = fetch[k] * 1024 * 2
+        wr = write.get(k, 0.0) * 1024
+        out["kernels"][k] = {"launches": n[k], "fetch_size_kib_raw": fetch[k], "write_size_kib_raw": write.get(k),
+                             "hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes": rd + wr}
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    for k, v in out["kernels"].items():
+        print("%-60s read %.3f GB  write %.3f GB" % (k[:60], v["hbm_read_bytes"] / 1e9, v["hbm_write_bytes"] / 1e9))
+
+
+if __name__ == "__main__":
+    main()
