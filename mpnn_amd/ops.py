@@ -216,10 +216,12 @@ class EdgeMessage(torch.autograd.Function):
 
 class GRUUpdateFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, m, h, mask, W_ih, W_hh, b_ih, b_hh):
+    def forward(ctx, m, h, mask, W_ih, W_hh, b_ih, b_hh, grad_mode):
         m, h = m.contiguous(), h.contiguous()
         mask = mask.contiguous() if mask is not None else None
-        need = torch.is_grad_enabled() and any(ctx.needs_input_grad)   # no gate dump on inference passes
+        # `grad_mode` = torch.is_grad_enabled() of the CALLER (always False in here): no gate dump
+        # (4H floats per atom) on inference passes
+        need = grad_mode and any(ctx.needs_input_grad)
         out, saved = gru_update_raw(m, h, mask, W_ih.contiguous(), W_hh.contiguous(), b_ih.contiguous(),
                                     b_hh.contiguous(), need)
         if need:
@@ -231,7 +233,7 @@ class GRUUpdateFn(torch.autograd.Function):
         m, h, mask, W_ih, W_hh, saved = ctx.saved_tensors
         dm, dh, dW_ih, dW_hh, db_ih, db_hh = gru_update_bwd_raw(dout.contiguous(), m, h, mask,
                                                                  W_ih.contiguous(), W_hh.contiguous(), saved)
-        return dm, dh, None, dW_ih, dW_hh, db_ih, db_hh
+        return dm, dh, None, dW_ih, dW_hh, db_ih, db_hh, None
 
 
 def segsum(msg, row_ptr, w=None, num_rows=None):
@@ -269,4 +271,4 @@ def edge_message(h, A, graph, gate=None):
 
 
 def gru_update(m, h, mask, W_ih, W_hh, b_ih, b_hh):
-    return GRUUpdateFn.apply(m, h, mask, W_ih, W_hh, b_ih, b_hh)
+    return GRUUpdateFn.apply(m, h, mask, W_ih, W_hh, b_ih, b_hh, torch.is_grad_enabled())
