@@ -329,6 +329,11 @@ __global__ void __launch_bounds__(256) gru_gate_grad_kernel(const float* __restr
     }
 }
 
+// fused H = 64 path (gru_bwd.hip)
+int launch_gru_bwd_fused64(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
+                           const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
+                           float* db_ih, float* db_hh, int64_t V, hipStream_t s);
+
 }  // namespace mpnn
 
 using namespace mpnn;
@@ -382,6 +387,8 @@ extern "C" int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const 
     }
     MPNN_REQUIRE(V * 6 * (int64_t)H < (1ll << 40), "mpnn_gru_update_bwd_f32: V too large");
     hipStream_t s = (hipStream_t)stream;
+    if (H == 64)   // fused path: no (V,6H) workspace traffic
+        return launch_gru_bwd_fused64(dout, m, h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, V, s);
     float* ws = (float*)workspace;
     int64_t g = ceil_div(V * H, 256);
     if (g > 256 * 16) g = 256 * 16;
