@@ -329,6 +329,9 @@ __global__ void __launch_bounds__(256) gru_gate_grad_kernel(const float* __restr
     }
 }
 
+// resident-matrix dx path (edge_message.hip); returns 1 when the shape is not covered
+int launch_message_dx_resident(const float* dmsg, const float* A, const int32_t* order, const int32_t* type_ptr,
+                               float* dx, int64_t E, int K, int nf, int mf, hipStream_t s);
 // fused H = 64 path (gru_bwd.hip)
 int launch_gru_bwd_fused64(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
                            const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
@@ -352,7 +355,8 @@ extern "C" int mpnn_edge_message_bwd_f32(const float* h, const float* A, const i
     int rc = MPNN_OK;
     if (dx) {
         // dx[e, b] = sum_a dmsg[e, a] * A_k[a, b]  : X = dmsg (ld mf), B = A_k as [k=a][n=b]
-        rc = launch_rows_gemm<false, true>(dmsg, mf, order, type_ptr, K, A, (int64_t)mf * nf, nf, nullptr, dx, nf, E, mf,
+        rc = launch_message_dx_resident(dmsg, A, order, type_ptr, dx, E, K, nf, mf, s);
+        if (rc == 1) rc = launch_rows_gemm<false, true>(dmsg, mf, order, type_ptr, K, A, (int64_t)mf * nf, nf, nullptr, dx, nf, E, mf,
                                            nf, s, "mpnn_edge_message_bwd_f32(dx)");
         if (rc) return rc;
     }

@@ -149,7 +149,11 @@ __global__ void __launch_bounds__(256) edge_message_kernel(const float* __restri
 // into registers (full 128-B segments, mostly L2 hits: a molecule's atoms are neighbouring rows),
 // the next tile's rows and the tile-after-next's indices are requested before the current tile is
 // multiplied.  Stores go to the destination-sorted slot e (one 128-B row segment per half-wave).
-template <int NF, int NB>
+//
+// BWD = false: msg[e] = A_k . (gate[e] * h[src(e)])       rows gathered by source atom, image = A_k
+// BWD = true : dx[e]  = A_k^T . dmsg[e]                   rows indexed by edge id,     image = A_k^T
+//              (`h` is dmsg, `mf` the OUTPUT width nf_x, A_k is (NF, mf) read transposed)
+template <int NF, int NB, bool BWD>
 __global__ void __launch_bounds__(512) edge_message_resident_kernel(
     const float* __restrict__ h, const float* __restrict__ A, const int32_t* __restrict__ src,
     const int32_t* __restrict__ order, const int32_t* __restrict__ type_ptr, const float* __restrict__ gate,
@@ -168,11 +172,19 @@ __global__ void __launch_bounds__(512) edge_message_resident_kernel(
         if (te == tb) continue;                         // uniform over the grid
         __syncthreads();                                // everyone is done with the previous matrix
         const float* Ak = A + (int64_t)k * mf * NF;
-        for (int idx = tid; idx < 32 * NB * (NF / 4); idx += 512) {
-            const int n = idx / (NF / 4), q = idx % (NF / 4);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (n < mf) v = *reinterpret_cast<const f32x4*>(Ak + (int64_t)n * NF + 4 * q);
-            *reinterpret_cast<f32x4*>(As + n * LD + 4 * q) = v;
+        if (!BWD) {
+            for (int idx = tid; idx < 32 * NB * (NF / 4); idx += 512) {
+                const int n = idx / (NF / 4), q = idx % (NF / 4);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (n < mf) v = *reinterpret_cast<const f32x4*>(Ak + (int64_t)n * NF + 4 * q);
+                *reinterpret_cast<f32x4*>(As + n * LD + 4 * q) = v;
+            }
+        } else {
+            // A_k is (NF rows a) x (mf cols b); image As[b][a] = A_k[a][b]  (once per type per block)
+            for (int idx = tid; idx < NF * 32 * NB; idx += 512) {
+                const int a = idx / (32 * NB), b = idx % (32 * NB);
+                As[b * LD + a] = (b < mf) ? Ak[(int64_t)a * mf + b] : 0.f;
+            }
         }
         __syncthreads();
 
@@ -195,12 +207,13 @@ __global__ void __launch_bounds__(512) edge_message_resident_kernel(
                 for (int q = 0; q < NF4; ++q) f[q] *= *reinterpret_cast<const f32x4*>(g + 4 * q);
             }
         };
+        auto src_of = [&](int e) { return BWD ? e : src[e]; };
         int e_cur = edge_of(t);
-        int s_cur = src[e_cur];
+        int s_cur = src_of(e_cur);
         f32x4 f_cur[NF4], f_nxt[NF4];
         load_rows(s_cur, e_cur, f_cur);
         int e_nxt = e_cur, s_nxt = s_cur;
-        if (t + nw < tiles) { e_nxt = edge_of(t + nw); s_nxt = src[e_nxt]; }
+        if (t + nw < tiles) { e_nxt = edge_of(t + nw); s_nxt = src_of(e_nxt); }
 
         for (; t < tiles; t += nw) {
             const bool has1 = t + nw < tiles, has2 = t + 2 * nw < tiles;
@@ -226,7 +239,7 @@ __global__ void __launch_bounds__(512) edge_message_resident_kernel(
                 }
             }
             int s_nn = s_nxt;
-            if (has2) s_nn = src[e_nn];                          // index of the tile after next
+            if (has2) s_nn = src_of(e_nn);                       // index of the tile after next
 
             const int rows = min(32, te - tb - 32 * t);
 #pragma unroll
@@ -251,14 +264,14 @@ __global__ void __launch_bounds__(512) edge_message_resident_kernel(
     }
 }
 
-template <int NF, int NB>
+template <int NF, int NB, bool BWD>
 static int launch_message_resident(const float* h, const float* A, const int32_t* src, const int32_t* order,
                                    const int32_t* type_ptr, const float* gate, float* msg, int64_t E, int K, int mf,
                                    hipStream_t s) {
     const size_t lds = (size_t)32 * NB * (NF + 4) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
-        (void)hipFuncSetAttribute((const void*)edge_message_resident_kernel<NF, NB>,
+        (void)hipFuncSetAttribute((const void*)edge_message_resident_kernel<NF, NB, BWD>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
@@ -266,13 +279,24 @@ static int launch_message_resident(const float* h, const float* A, const int32_t
     const int64_t need = ceil_div(ceil_div(E, 32) + K, 8);
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((edge_message_resident_kernel<NF, NB>), dim3((unsigned)blocks), dim3(512), lds, s, h, A, src,
+    hipLaunchKernelGGL((edge_message_resident_kernel<NF, NB, BWD>), dim3((unsigned)blocks), dim3(512), lds, s, h, A, src,
                        order, type_ptr, gate, msg, K, mf);
     return launch_status("mpnn_edge_message_f32(resident)");
 }
 
 static size_t message_lds_bytes(int nb) {
     return (size_t)(kTileEdges * kLD + 32 * nb * kLD) * sizeof(float) + 2 * kTileEdges * sizeof(int);
+}
+
+// dx[e] = A_type(e)^T dmsg[e] on the resident-matrix kernel; returns 1 when the shape has no fast path
+int launch_message_dx_resident(const float* dmsg, const float* A, const int32_t* order, const int32_t* type_ptr,
+                               float* dx, int64_t E, int K, int nf, int mf, hipStream_t s) {
+    if (K > 64) return 1;
+    if (mf == 64 && nf == 64)
+        return launch_message_resident<64, 2, true>(dmsg, A, nullptr, order, type_ptr, nullptr, dx, E, K, nf, s);
+    if (mf == 32 && nf == 32)
+        return launch_message_resident<32, 1, true>(dmsg, A, nullptr, order, type_ptr, nullptr, dx, E, K, nf, s);
+    return 1;
 }
 
 }  // namespace mpnn
@@ -297,9 +321,9 @@ extern "C" int mpnn_edge_message_f32(const float* h, const float* A, const int32
     const int nb = (mf + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
     if (K <= 64) {      // resident-matrix fast path: the type loop is sequential, keep K small
-        if (nf == 64 && nb == 2) return launch_message_resident<64, 2>(h, A, src, order, type_ptr, gate, msg, E, K, mf, st);
-        if (nf == 64 && nb == 1) return launch_message_resident<64, 1>(h, A, src, order, type_ptr, gate, msg, E, K, mf, st);
-        if (nf == 32 && nb == 1) return launch_message_resident<32, 1>(h, A, src, order, type_ptr, gate, msg, E, K, mf, st);
+        if (nf == 64 && nb == 2) return launch_message_resident<64, 2, false>(h, A, src, order, type_ptr, gate, msg, E, K, mf, st);
+        if (nf == 64 && nb == 1) return launch_message_resident<64, 1, false>(h, A, src, order, type_ptr, gate, msg, E, K, mf, st);
+        if (nf == 32 && nb == 1) return launch_message_resident<32, 1, false>(h, A, src, order, type_ptr, gate, msg, E, K, mf, st);
     }
     const int64_t tiles = ceil_div(E, kTileEdges) + K;   // upper bound; surplus blocks exit at once
     const dim3 grid((unsigned)tiles), block(256);

@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256) gru_update_kernel(const float* __restrict
 // the lane's own contiguous half-row of m / h (lane (r,hi) holds X[row r][hi*H/2 ...]), loaded
 // straight from global into registers -- no LDS image, no __syncthreads in the loop -- with the
 // next operand block requested before the current one is multiplied.
-template <int H, int NCS, int NW>   // NW waves per block (8 = two per SIMD; 4 when the fragments need >256 VGPRs)
+template <int H, int NCS, int NW, bool HAS_MASK>   // NW waves per block (8 = two per SIMD)
 __global__ void __launch_bounds__(64 * NW) gru_update_resident_kernel(
     const float* __restrict__ m, const float* __restrict__ h, const float* __restrict__ mask,
     const float* __restrict__ W_ih, const float* __restrict__ W_hh, const float* __restrict__ b_ih,
@@ -252,26 +252,42 @@ __global__ void __launch_bounds__(64 * NW) gru_update_resident_kernel(
                 }
             }
         }
+        // epilogue in 4 groups of 4 consecutive atoms: every load is unconditional (row clamped) and
+        // issued before the group's math, only the stores are predicated -- no branch holds a load
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int64_t row = t * 32 + acc_row(i, lane);
-            if (row >= V) continue;
-            const float mk = mask ? mask[row] : 1.0f;
+        for (int g = 0; g < 4; ++g) {
+            float mk4[4], hv4[4][NCS];
 #pragma unroll
-            for (int s = 0; s < NCS; ++s) {
-                const int col = c0 + 32 * s + r;
-                const float hv = h[row * H + col];
-                const float rg = sigmoidf_(acc_r[s][i] + br[s]) * mk;
-                const float zg = sigmoidf_(acc_z[s][i] + bz[s]) * mk;
-                const float nh = acc_nh[s][i] + bnh[s];
-                const float ng = tanhf_(acc_ni[s][i] + bni[s] + rg * nh) * mk;
-                out[row * H + col] = ((1.0f - zg) * ng + zg * hv) * mk;
-                if (saved) {
-                    float* sv = saved + row * 4 * H + col;
-                    sv[0] = rg;
-                    sv[H] = zg;
-                    sv[2 * H] = ng;
-                    sv[3 * H] = nh;
+            for (int u = 0; u < 4; ++u) {
+                int64_t row = t * 32 + 8 * g + 4 * hi + u;
+                if (row >= V) row = V - 1;
+                mk4[u] = HAS_MASK ? mask[row] : 1.0f;
+#pragma unroll
+                for (int s = 0; s < NCS; ++s) hv4[u][s] = h[row * H + c0 + 32 * s + r];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = 4 * g + u;
+                const int64_t row = t * 32 + 8 * g + 4 * hi + u;
+                const float mk = mk4[u];
+#pragma unroll
+                for (int s = 0; s < NCS; ++s) {
+                    const int col = c0 + 32 * s + r;
+                    const float rg = sigmoidf_(acc_r[s][i] + br[s]) * mk;
+                    const float zg = sigmoidf_(acc_z[s][i] + bz[s]) * mk;
+                    const float nh = acc_nh[s][i] + bnh[s];
+                    const float ng = tanhf_(acc_ni[s][i] + bni[s] + rg * nh) * mk;
+                    const float o = ((1.0f - zg) * ng + zg * hv4[u][s]) * mk;
+                    if (row < V) {
+                        out[row * H + col] = o;
+                        if (saved) {
+                            float* sv = saved + row * 4 * H + col;
+                            sv[0] = rg;
+                            sv[H] = zg;
+                            sv[2 * H] = ng;
+                            sv[3 * H] = nh;
+                        }
+                    }
                 }
             }
         }
@@ -287,7 +303,9 @@ static int launch_gru_resident(const float* m, const float* h, const float* mask
     const size_t lds = (size_t)2 * H * 3 * CS * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gru_update_resident_kernel<H, NCS, NW>,
+        (void)hipFuncSetAttribute((const void*)gru_update_resident_kernel<H, NCS, NW, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gru_update_resident_kernel<H, NCS, NW, false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
@@ -295,8 +313,12 @@ static int launch_gru_resident(const float* m, const float* h, const float* mask
     int64_t pblocks = (256 + slices - 1) / slices;        // one block per CU (LDS-bound residency)
     if (pblocks * NW > tiles) pblocks = (tiles + NW - 1) / NW;
     if (pblocks < 1) pblocks = 1;
-    hipLaunchKernelGGL((gru_update_resident_kernel<H, NCS, NW>), dim3((unsigned)(pblocks * slices)), dim3(64 * NW), lds, s, m,
-                       h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, slices);
+    if (mask)
+        hipLaunchKernelGGL((gru_update_resident_kernel<H, NCS, NW, true>), dim3((unsigned)(pblocks * slices)),
+                           dim3(64 * NW), lds, s, m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, slices);
+    else
+        hipLaunchKernelGGL((gru_update_resident_kernel<H, NCS, NW, false>), dim3((unsigned)(pblocks * slices)),
+                           dim3(64 * NW), lds, s, m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, slices);
     return launch_status("mpnn_gru_update_f32(resident)");
 }
 

@@ -34,7 +34,7 @@ __device__ __forceinline__ void gate_grads4(const f32x4& dout, const f32x4& hv, 
 }
 
 // ------------------------------------------------------------------------------------------ K1
-template <int H, int NW>
+template <int H, int NW, bool HAS_MASK>
 __global__ void __launch_bounds__(64 * NW) gru_bwd_dx_kernel(const float* __restrict__ dout, const float* __restrict__ h,
                                                              const float* __restrict__ mask,
                                                              const float* __restrict__ W_ih,
@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(64 * NW) gru_bwd_dx_kernel(const float* __rest
     for (int64_t t = (int64_t)blockIdx.x * NW + wv; t < tiles; t += stride) {
         int64_t row = t * 32 + r;
         if (row >= V) row = V - 1;
-        const float mk = mask ? mask[row] : 1.0f;
+        const float mk = HAS_MASK ? mask[row] : 1.0f;
         const float* p_do = dout + row * H + hi * (H / 2);
         const float* p_h = h + row * H + hi * (H / 2);
         const float* p_sv = saved + row * 4 * H + hi * (H / 2);
@@ -117,16 +117,31 @@ __global__ void __launch_bounds__(64 * NW) gru_bwd_dx_kernel(const float* __rest
             c_do = n_do; c_h = n_h; c_r = n_r; c_z = n_z; c_n = n_n; c_nh = n_nh;
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int64_t orow = t * 32 + acc_row(i, lane);
-            if (orow >= V) continue;
-            const float omk = mask ? mask[orow] : 1.0f;
+        for (int g = 0; g < 4; ++g) {
+            float dir4[4][NB];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const int col = 32 * b + r;
-                const float direct = dout[orow * H + col] * omk * saved[orow * 4 * H + H + col];   // g*z
-                dm[orow * H + col] = acc_m[b][i];
-                dh[orow * H + col] = acc_h[b][i] + direct;
+            for (int u = 0; u < 4; ++u) {
+                int64_t orow = t * 32 + 8 * g + 4 * hi + u;
+                if (orow >= V) orow = V - 1;
+                const float omk = HAS_MASK ? mask[orow] : 1.0f;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const int col = 32 * b + r;
+                    dir4[u][b] = dout[orow * H + col] * omk * saved[orow * 4 * H + H + col];   // g*z
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = 4 * g + u;
+                const int64_t orow = t * 32 + 8 * g + 4 * hi + u;
+                if (orow < V) {
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const int col = 32 * b + r;
+                        dm[orow * H + col] = acc_m[b][i];
+                        dh[orow * H + col] = acc_h[b][i] + dir4[u][b];
+                    }
+                }
             }
         }
     }
@@ -250,14 +265,20 @@ int launch_gru_bwd_fused64(const float* dout, const float* m, const float* h, co
         const size_t lds = (size_t)2 * H * (3 * H + 4) * sizeof(float);
         static bool attr_done = false;
         if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)gru_bwd_dx_kernel<H, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds);
+            (void)hipFuncSetAttribute((const void*)gru_bwd_dx_kernel<H, NW, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)gru_bwd_dx_kernel<H, NW, false>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_done = true;
         }
         int64_t blocks = 256;
         if (blocks * NW > tiles) blocks = (tiles + NW - 1) / NW;
-        hipLaunchKernelGGL((gru_bwd_dx_kernel<H, NW>), dim3((unsigned)blocks), dim3(64 * NW), lds, s, dout, h, mask, W_ih,
-                           W_hh, saved, dm, dh, V);
+        if (mask)
+            hipLaunchKernelGGL((gru_bwd_dx_kernel<H, NW, true>), dim3((unsigned)blocks), dim3(64 * NW), lds, s, dout, h,
+                               mask, W_ih, W_hh, saved, dm, dh, V);
+        else
+            hipLaunchKernelGGL((gru_bwd_dx_kernel<H, NW, false>), dim3((unsigned)blocks), dim3(64 * NW), lds, s, dout, h,
+                               mask, W_ih, W_hh, saved, dm, dh, V);
         int rc = launch_status("mpnn_gru_update_bwd_f32(dx)");
         if (rc) return rc;
     }
