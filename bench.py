@@ -219,7 +219,8 @@ def main():
     if rank == 0:
         F = hidden
         seg_ms = timer.mean_ms("segsum")
-        alg_bytes = 4.0 * F * (E + V) + 4.0 * (V + 1) + 4.0 * E     # msg rows + out rows + row_ptr + edge weights
+        weighted = graph.agg_weight is not None
+        alg_bytes = 4.0 * F * (E + V) + 4.0 * (V + 1) + (4.0 * E if weighted else 0.0)   # msg rows + out rows + row_ptr (+ weights)
         achieved = alg_bytes / (seg_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(args.workload)
         out = {

@@ -8,8 +8,8 @@
 // Mapping: a row of F floats is covered by LPR lanes x VEC floats (16 lanes x float4 at
 // F=64), so one wave64 reduces 64/LPR destination atoms side by side.  Edges of one atom
 // are contiguous (CSR by destination) and atoms of one wave are adjacent, so the wave's
-// loads walk one contiguous span of `msg`.  The edge loop is unrolled x4 with the adds kept
-// in edge order, which keeps the sum deterministic and order-identical to a serial loop.
+// loads walk one contiguous span of `msg`.  The edge loop runs in predicated batches of 4 rows
+// (all loads of a batch in flight together) with the adds kept in edge order: deterministic.
 #include "common.h"
 
 namespace mpnn {
@@ -50,27 +50,34 @@ __global__ void __launch_bounds__(256) segsum_kernel(const float* __restrict__ m
         for (int c = lig * VEC; c < F; c += LPR * VEC) {
             Row<VEC> acc;
             acc.zero();
-            int e = e0;
-            for (; e + 4 <= e1; e += 4) {
+            // edges in batches of 4 with the loads predicated on the row's length: the (typical) atom of
+            // degree <= 4 costs ONE memory round trip, all its rows in flight together; rows past the
+            // end contribute an exact +0 so the sum keeps edge order and stays deterministic
+            for (int e = e0; e < e1; e += 4) {
+                const int n = e1 - e;
                 Row<VEC> r0, r1, r2, r3;
+                r1.zero(); r2.zero(); r3.zero();
+                float w0 = 1.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
                 int64_t s0 = e, s1 = e + 1, s2 = e + 2, s3 = e + 3;
-                if (GATHER && idx) { s0 = idx[e]; s1 = idx[e + 1]; s2 = idx[e + 2]; s3 = idx[e + 3]; }
+                if (GATHER && idx) {
+                    s0 = idx[e];
+                    if (n > 1) s1 = idx[e + 1];
+                    if (n > 2) s2 = idx[e + 2];
+                    if (n > 3) s3 = idx[e + 3];
+                }
                 r0.load(msg + s0 * F + c);
-                r1.load(msg + s1 * F + c);
-                r2.load(msg + s2 * F + c);
-                r3.load(msg + s3 * F + c);
+                if (n > 1) r1.load(msg + s1 * F + c);
+                if (n > 2) r2.load(msg + s2 * F + c);
+                if (n > 3) r3.load(msg + s3 * F + c);
                 if (w) {
-                    acc.fma(r0, w[e]); acc.fma(r1, w[e + 1]); acc.fma(r2, w[e + 2]); acc.fma(r3, w[e + 3]);
+                    w0 = w[e];
+                    if (n > 1) w1 = w[e + 1];
+                    if (n > 2) w2 = w[e + 2];
+                    if (n > 3) w3 = w[e + 3];
+                    acc.fma(r0, w0); acc.fma(r1, w1); acc.fma(r2, w2); acc.fma(r3, w3);
                 } else {
                     acc.add(r0); acc.add(r1); acc.add(r2); acc.add(r3);
                 }
-            }
-            for (; e < e1; ++e) {
-                Row<VEC> r;
-                int64_t s = e;
-                if (GATHER && idx) s = idx[e];
-                r.load(msg + s * F + c);
-                if (w) acc.fma(r, w[e]); else acc.add(r);
             }
             acc.store(out + i * F + c);
         }

@@ -9,6 +9,8 @@ def edge_adjacency(msgs, adj):
     """adj value of every member pair of `msgs.graph` (E,)."""
     g = msgs.graph
     if isinstance(adj, MolGraph) or adj is None:
+        if g.edge_weight is None:
+            return torch.ones(g.num_edges, device=g.device)
         return g.edge_weight
     if g.dense_shape is None:
         raise ValueError("a dense adj tensor cannot be matched to a compact batch")
@@ -23,3 +25,13 @@ def dense_rows(messages, adj):
     B, N = messages.shape[0], messages.shape[1]
     row_ptr = torch.arange(0, B * N * N + 1, N, dtype=torch.int32, device=messages.device)
     return messages.reshape(B * N * N, messages.shape[-1]), row_ptr, (B, N)
+
+
+def adjacency_multiplier(msgs, adj):
+    """Per-edge weights for a plain adjacency-weighted sum, or None when they are all exactly 1."""
+    g = msgs.graph
+    if isinstance(adj, MolGraph) or adj is None:
+        return g.agg_weight
+    if g.dense_shape is not None and adj.data_ptr() == g._adj_ptr:
+        return g.agg_weight                 # the graph was built from this very tensor
+    return edge_adjacency(msgs, adj)

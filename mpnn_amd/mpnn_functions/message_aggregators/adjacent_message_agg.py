@@ -8,7 +8,7 @@ from torch import nn
 
 from mpnn_amd import ops
 from mpnn_amd.messages import EdgeMessages
-from ._common import dense_rows, edge_adjacency
+from ._common import adjacency_multiplier, dense_rows
 
 
 class AdjMsgAgg(nn.Module):
@@ -18,6 +18,6 @@ class AdjMsgAgg(nn.Module):
     def forward(self, messages, adj):
         if isinstance(messages, EdgeMessages):
             g = messages.graph
-            return g.node_unview(ops.segsum(messages.values, g.row_ptr, edge_adjacency(messages, adj)))
+            return g.node_unview(ops.segsum(messages.values, g.row_ptr, adjacency_multiplier(messages, adj)))
         rows, row_ptr, (B, N) = dense_rows(messages, adj)
         return ops.segsum(rows, row_ptr, adj.reshape(-1).contiguous().float()).view(B, N, -1)

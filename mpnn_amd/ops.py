@@ -105,13 +105,13 @@ def edge_message_raw(h, A, graph, gate=None):
     return msg
 
 
-def edge_message_bwd_raw(h, A, graph, gate, dmsg):
+def edge_message_bwd_raw(h, A, graph, gate, dmsg, need_dx=True, need_dA=True):
     lib = _lib.load()
     K, mf, nf = (int(s) for s in A.shape)
     E = graph.num_edges
-    dx = _empty((E, nf), h)
-    dA = torch.zeros_like(A)
-    if E == 0:
+    dx = _empty((E, nf), h) if need_dx else None
+    dA = torch.zeros_like(A) if need_dA else None
+    if E == 0 or not (need_dx or need_dA):
         return dx, dA
     _lib.check(lib.mpnn_edge_message_bwd_f32(_lib.fptr(h), _lib.fptr(A), _lib.iptr(graph.col_idx),
                                              _lib.iptr(graph.order), _lib.iptr(graph.type_ptr), _lib.fptr(gate),
@@ -202,7 +202,11 @@ class EdgeMessage(torch.autograd.Function):
     def backward(ctx, dmsg):
         h, A, gate = ctx.saved_tensors
         g = ctx.graph
-        dx, dA = edge_message_bwd_raw(h, A, g, gate, dmsg.contiguous())     # dx = A^T dmsg per edge
+        need_dx = ctx.needs_input_grad[0] or (gate is not None and ctx.needs_input_grad[2])
+        dx, dA = edge_message_bwd_raw(h, A, g, gate, dmsg.contiguous(), need_dx=need_dx,
+                                      need_dA=ctx.needs_input_grad[1])    # dx = A^T dmsg per edge
+        if not need_dx:      # e.g. BasicModel: the message input is the constant afm
+            return None, dA, None, None
         t_row_ptr, t_eid = g.transpose
         dgate = None
         if gate is not None:
