@@ -10,6 +10,8 @@
 // are contiguous (CSR by destination) and atoms of one wave are adjacent, so the wave's
 // loads walk one contiguous span of `msg`.  The edge loop runs in predicated batches of 4 rows
 // (all loads of a batch in flight together) with the adds kept in edge order: deterministic.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace mpnn {
@@ -84,6 +86,76 @@ __global__ void __launch_bounds__(256) segsum_kernel(const float* __restrict__ m
     }
 }
 
+// Variant 2: each lane group reduces TWO adjacent atoms per pass (their rows are one contiguous
+// span [e0,e2)), up to 8 row loads in flight per group, and the next pass's three row_ptr values are
+// requested before the current rows are summed (one dependent round trip per pass instead of two).
+template <int VEC, int LPR>
+__global__ void __launch_bounds__(256) segsum_pair_kernel(const float* __restrict__ msg,
+                                                          const int32_t* __restrict__ row_ptr,
+                                                          const float* __restrict__ w, float* __restrict__ out,
+                                                          int64_t V, int F) {
+    constexpr int GPB = 256 / LPR;
+    const int lig = threadIdx.x % LPR;
+    const int grp = threadIdx.x / LPR;
+    const int c = lig * VEC;
+    const int64_t step = 2 * (int64_t)gridDim.x * GPB;
+    int64_t i = 2 * ((int64_t)blockIdx.x * GPB + grp);
+    if (i >= V) return;
+    int e0 = row_ptr[i], e1 = row_ptr[i + 1], e2 = (i + 1 < V) ? row_ptr[i + 2] : e1;
+    for (; i < V; i += step) {
+        const int64_t in = i + step;
+        int n0 = 0, n1 = 0, n2 = 0;
+        if (in < V) {                                   // prefetch the next pass's row pointers
+            n0 = row_ptr[in];
+            n1 = row_ptr[in + 1];
+            n2 = (in + 1 < V) ? row_ptr[in + 2] : n1;
+        }
+        if (c < F) {
+            Row<VEC> accA, accB;
+            accA.zero();
+            accB.zero();
+            int a = e0, b = e1;
+            while (a < e1 || b < e2) {
+                const int na = e1 - a, nb = e2 - b;
+                Row<VEC> ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+                ra0.zero(); ra1.zero(); ra2.zero(); ra3.zero();
+                rb0.zero(); rb1.zero(); rb2.zero(); rb3.zero();
+                float wa0 = 0.f, wa1 = 0.f, wa2 = 0.f, wa3 = 0.f, wb0 = 0.f, wb1 = 0.f, wb2 = 0.f, wb3 = 0.f;
+                if (na > 0) ra0.load(msg + (int64_t)(a + 0) * F + c);
+                if (na > 1) ra1.load(msg + (int64_t)(a + 1) * F + c);
+                if (na > 2) ra2.load(msg + (int64_t)(a + 2) * F + c);
+                if (na > 3) ra3.load(msg + (int64_t)(a + 3) * F + c);
+                if (nb > 0) rb0.load(msg + (int64_t)(b + 0) * F + c);
+                if (nb > 1) rb1.load(msg + (int64_t)(b + 1) * F + c);
+                if (nb > 2) rb2.load(msg + (int64_t)(b + 2) * F + c);
+                if (nb > 3) rb3.load(msg + (int64_t)(b + 3) * F + c);
+                if (w) {
+                    if (na > 0) wa0 = w[a];
+                    if (na > 1) wa1 = w[a + 1];
+                    if (na > 2) wa2 = w[a + 2];
+                    if (na > 3) wa3 = w[a + 3];
+                    if (nb > 0) wb0 = w[b];
+                    if (nb > 1) wb1 = w[b + 1];
+                    if (nb > 2) wb2 = w[b + 2];
+                    if (nb > 3) wb3 = w[b + 3];
+                    accA.fma(ra0, wa0); accA.fma(ra1, wa1); accA.fma(ra2, wa2); accA.fma(ra3, wa3);
+                    accB.fma(rb0, wb0); accB.fma(rb1, wb1); accB.fma(rb2, wb2); accB.fma(rb3, wb3);
+                } else {
+                    accA.add(ra0); accA.add(ra1); accA.add(ra2); accA.add(ra3);
+                    accB.add(rb0); accB.add(rb1); accB.add(rb2); accB.add(rb3);
+                }
+                a += 4;
+                b += 4;
+            }
+            accA.store(out + i * F + c);
+            if (i + 1 < V) accB.store(out + (i + 1) * F + c);
+        }
+        e0 = n0;
+        e1 = n1;
+        e2 = n2;
+    }
+}
+
 template <int VEC, int LPR>
 __global__ void __launch_bounds__(256) segsum_bwd_kernel(const float* __restrict__ dout,
                                                          const int32_t* __restrict__ row_ptr,
@@ -127,6 +199,17 @@ static int launch_segsum(const float* msg, const int32_t* row_ptr, const int32_t
     const bool v4 = (F % 4 == 0) && ((reinterpret_cast<uintptr_t>(msg) | reinterpret_cast<uintptr_t>(out)) % 16 == 0);
     const int lpr = pick_lpr(F, v4 ? 4 : 1);
     const dim3 grid(grid_for(V, lpr)), block(256);
+    static const int variant = getenv("MPNN_SEGSUM_VARIANT") ? atoi(getenv("MPNN_SEGSUM_VARIANT")) : 1;
+    if (!GATHER && variant == 2 && v4 && lpr * 4 >= F) {
+        const dim3 g2(grid_for((V + 1) / 2, lpr));
+        switch (lpr) {
+            case 16: hipLaunchKernelGGL((segsum_pair_kernel<4, 16>), g2, block, 0, s, msg, row_ptr, w, out, V, F); break;
+            case 32: hipLaunchKernelGGL((segsum_pair_kernel<4, 32>), g2, block, 0, s, msg, row_ptr, w, out, V, F); break;
+            case 64: hipLaunchKernelGGL((segsum_pair_kernel<4, 64>), g2, block, 0, s, msg, row_ptr, w, out, V, F); break;
+            default: hipLaunchKernelGGL((segsum_pair_kernel<4, 8>), g2, block, 0, s, msg, row_ptr, w, out, V, F); break;
+        }
+        return launch_status("mpnn_segsum(pair)");
+    }
 #define MPNN_SEGSUM_CASE(VEC, LPR)                                                                              \
     hipLaunchKernelGGL((segsum_kernel<VEC, LPR, GATHER>), grid, block, 0, s, msg, row_ptr, idx, w, out, V, F); \
     break;

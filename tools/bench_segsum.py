@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""A/B of aggregator variants on the c2 graph (run each variant in its own process: the variant is
+read once per process from MPNN_SEGSUM_VARIANT).  Prints ms and algorithmic GB/s."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mpnn_amd import ops, synth  # noqa: E402
+from mpnn_amd.graph import MolGraph  # noqa: E402
+
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+dist = sys.argv[2] if len(sys.argv) > 2 else "drug"
+mols = int(sys.argv[3]) if len(sys.argv) > 3 else 100_000
+dev = torch.device("cuda:0")
+mb = synth.make_molecules(mols, 4, seed=317, dist=dist)
+g = MolGraph.from_molbatch(mb, dev)
+E, V = g.num_edges, g.num_nodes
+msg = torch.randn(E, F, device=dev)
+w = torch.rand(E, device=dev)
+for weights in (None, w):
+    for _ in range(5):
+        ops.segsum_raw(msg, g.row_ptr, weights, V)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 50
+    a.record()
+    for _ in range(n):
+        ops.segsum_raw(msg, g.row_ptr, weights, V)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / n
+    by = 4.0 * F * (E + V) + 4.0 * (V + 1) + (4.0 * E if weights is not None else 0)
+    print("variant=%s F=%d dist=%s weights=%s  %.4f ms  %.0f GB/s" % (os.environ.get("MPNN_SEGSUM_VARIANT", "1"), F, dist,
+          weights is not None, ms, by / ms / 1e6))
