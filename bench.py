@@ -32,6 +32,7 @@ WORKLOADS = {
     # name: (mols per GPU, hidden, MP steps, size distribution, description)
     "c2": (100_000, 64, 3, "drug", "100k synthetic mols/GPU, ~30 atoms/60 edges, hidden=64, 3 MP steps, sum aggregator"),
     "c4": (125_000, 128, 3, "drug", "125k synthetic mols/GPU (1M over 8), hidden=128, 3 MP steps"),
+    "c2h128": (100_000, 128, 3, "drug", "c2 graphs at hidden=128"),
     "c5": (50_000, 256, 3, "skewed", "50k mols 10-200 atoms, preferential attachment, hidden=256"),
     "tiny": (2_000, 64, 3, "drug", "2k mols (plumbing check)"),
 }
@@ -141,12 +142,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("MPNN_DIST_BACKEND", "nccl")      # "gloo": rehearsal with ranks sharing one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     from mpnn_amd import ops, synth
@@ -240,7 +246,7 @@ def main():
                        "atoms_per_gpu": V, "edges_per_gpu": E, "hidden": hidden, "mp_steps": T,
                        "edge_features": 4, "edge_types": graph.num_types, "parallelism": "dp%d" % world,
                        "edges_counted": "directed edges x MP steps per pass"},
-            "roofline": {"kernel": "segsum_kernel (aggregator, mpnn_segsum_f32)", "bound": "hbm",
+            "roofline": {"kernel": "segsum_pair_kernel (aggregator, mpnn_segsum_f32)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": seg_ms, "algorithmic_bytes_per_launch": alg_bytes},
             "kernels_ms": {k: timer.mean_ms(k) for k in ("edge_message", "segsum", "gru_update")},

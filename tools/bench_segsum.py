@@ -35,3 +35,19 @@ for weights in (None, w):
     by = 4.0 * F * (E + V) + 4.0 * (V + 1) + (4.0 * E if weights is not None else 0)
     print("variant=%s F=%d dist=%s weights=%s  %.4f ms  %.0f GB/s" % (os.environ.get("MPNN_SEGSUM_VARIANT", "1"), F, dist,
           weights is not None, ms, by / ms / 1e6))
+
+# calibration: plain streaming kernels of the same read:write mix (torch elementwise), same bytes
+n = (E + V) * F // 3
+x, y, z = (torch.randn(n, device=dev) for _ in range(3))
+for name, fn, nbytes in (("copy (1R:1W)", lambda: z.copy_(x), 8.0 * n), ("add (2R:1W)", lambda: torch.add(x, y, out=z), 12.0 * n)):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(50):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / 50
+    print("calibration %-14s %.4f ms  %.0f GB/s" % (name, ms, nbytes / ms / 1e6))
