@@ -62,7 +62,7 @@ def pmc_traffic(workload):
         with open(path) as f:
             d = json.load(f)
         for k, v in d["kernels"].items():
-            if "segsum_kernel" in k:
+            if "segsum" in k and "bwd" not in k:
                 return v["hbm_bytes"], "profiles/" + os.path.basename(path)
     except (OSError, ValueError, KeyError):
         pass
