@@ -31,6 +31,7 @@ sys.path.insert(0, REPO)
 WORKLOADS = {
     # name: (mols per GPU, hidden, MP steps, size distribution, description)
     "c2": (100_000, 64, 3, "drug", "100k synthetic mols/GPU, ~30 atoms/60 edges, hidden=64, 3 MP steps, sum aggregator"),
+    "c3": (100_000, 128, 5, "drug", "att_model: AttEdgeNetwork feature gate + AdjMsgAgg + GRU + MaskBatchNorm, hidden=128, 5 MP steps"),
     "c4": (125_000, 128, 3, "drug", "125k synthetic mols/GPU (1M over 8), hidden=128, 3 MP steps"),
     "c2h128": (100_000, 128, 3, "drug", "c2 graphs at hidden=128"),
     "c5": (50_000, 256, 3, "skewed", "50k mols 10-200 atoms, preferential attachment, hidden=256"),
@@ -44,7 +45,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS),
+                    help="c2 = BASELINE.json configs[1] (the headline); c3/c4/c5 = configs[2..4] shapes")
     ap.add_argument("--mode", default="train", choices=["fwd", "train"],
                     help="train (default) = forward + backward + gradient all-reduce; fwd = inference pass only")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
@@ -167,8 +169,13 @@ def main():
     V, E = graph.num_nodes, graph.num_edges
     graph.order, graph.type_ptr                          # index arrays built once, outside the timed region
     torch.manual_seed(317)                               # same weights on every rank
-    model = BasicModel(hidden, 4, hidden, 50, 8, message_opts={}, agg_opts={}, update_opts={}, readout_opts={},
-                       message_steps=T).to(dev)
+    if args.workload == "c3":
+        from mpnn_amd.models.att_model import BasicModel as AttModel
+        model = AttModel(hidden, 4, hidden, 50, 8, message_opts={}, agg_opts={}, update_opts={}, readout_opts={},
+                         message_steps=T).to(dev)
+    else:
+        model = BasicModel(hidden, 4, hidden, 50, 8, message_opts={}, agg_opts={}, update_opts={}, readout_opts={},
+                           message_steps=T).to(dev)
     from mpnn_amd import parallel
     hot = [p for n, p in model.named_parameters() if not n.startswith("of.")]   # readout is off the hot path
     graph.transpose, graph.edge_dst
