@@ -12,6 +12,9 @@
 // and h-products into one accumulator (K = 2H), gi_n / gh_n stay apart because of r*gh_n.
 // Blocks that share an atom tile (the H/32 column slices) are dealt to the same XCD so the
 // tile's second read hits that XCD's L2.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 
 namespace mpnn {
@@ -322,6 +325,10 @@ static int launch_gru_resident(const float* m, const float* h, const float* mask
     return launch_status("mpnn_gru_update_f32(resident)");
 }
 
+// split-precision (bf16x6) forward, gru_split.hip; returns 1 when the width is not covered
+int launch_gru_split(const float* m, const float* h, const float* mask, const float* W_ih, const float* W_hh,
+                     const float* b_ih, const float* b_hh, float* out, float* saved, int64_t V, int H, hipStream_t s);
+
 }  // namespace mpnn
 
 using namespace mpnn;
@@ -339,6 +346,13 @@ extern "C" int mpnn_gru_update_f32(const float* m, const float* h, const float* 
         MPNN_REQUIRE(al % 16 == 0, "mpnn_gru_update_f32: buffers must be 16-byte aligned");
     }
     hipStream_t st = (hipStream_t)stream;
+    // MPNN_GRU_MATH=fp32 keeps the GEMMs on v_mfma_f32_32x32x2_f32; default: bf16 pipe with 3-way operand
+    // splitting (fp32-equivalent accuracy, see gru_split.hip)
+    static const bool fp32_only = getenv("MPNN_GRU_MATH") && !strcmp(getenv("MPNN_GRU_MATH"), "fp32");
+    if (!fp32_only) {
+        const int rc = launch_gru_split(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, H, st);
+        if (rc != 1) return rc;
+    }
     if (H == 64) return launch_gru_resident<64, 2, 8>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, st);
     if (H == 128) return launch_gru_resident<128, 1, 4>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, st);
     if (H == 32) return launch_gru_resident<32, 1, 8>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, st);
