@@ -296,6 +296,93 @@ __global__ void __launch_bounds__(256) tn_accumulate_kernel(const float* __restr
     if (colsum && a0 == 0 && tid < 64 && b0 + tid < N && t_hi > t_lo) atomicAdd(colsum + b0 + tid, cs);
 }
 
+// ------------------------------------------------------------------------------------ dA, register-direct
+// dA[k][a][b] += sum_{e of type k} dmsg[e][a] * (gate[e][b] *) h[src e][b]        (mf = nf = 64)
+//
+// For a transposed product the MFMA operand layouts ARE coalesced global loads: step s of a 32-edge
+// tile needs A[i=a][k=row] = dmsg[row][a] and B[k=row][j=b] = x[row][b] with the feature index on the
+// lane -- one dword load per lane, 128 contiguous bytes per half-wave -- so nothing is staged in LDS
+// and there is no barrier per tile.  One wave owns the whole 64x64 output (four 32x32 accumulators)
+// and therefore reads every dmsg / x element exactly once.  Waves take 32-edge tiles of the
+// type-sorted list on their own; per type the block's 8 partial tiles are combined in LDS (ds_add)
+// and leave through one float-atomic flush per block.
+__global__ void __launch_bounds__(512) edge_dA_direct64_kernel(const float* __restrict__ dmsg,
+                                                               const float* __restrict__ h,
+                                                               const int32_t* __restrict__ src,
+                                                               const int32_t* __restrict__ order,
+                                                               const int32_t* __restrict__ type_ptr,
+                                                               const float* __restrict__ gate, float* dA, int K) {
+    constexpr int F = 64;
+    __shared__ float red[F * F];                        // block-level partial of the current type
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i = lane & 31, hi = lane >> 5;
+    const int gw = blockIdx.x * 8 + wv, nw = gridDim.x * 8;
+
+    for (int k = 0; k < K; ++k) {
+        const int tb = type_ptr[k], te = type_ptr[k + 1];
+        if (te == tb) continue;                         // uniform over the grid
+        for (int idx = tid; idx < F * F; idx += 512) red[idx] = 0.f;
+        __syncthreads();
+
+        f32x16 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int z = 0; z < 16; ++z) acc[q][z] = 0.f;
+        const int tiles = (te - tb + 31) / 32;
+        bool any = false;
+        for (int t = gw; t < tiles; t += nw) {
+            any = true;
+            const int pos = tb + 32 * t + i;            // both lane halves hold the tile's 32 edge ids
+            const bool ok = pos < te;
+            const int e_l = ok ? order[pos] : order[tb + 32 * t];
+            const int s_l = src[e_l];
+            const int rows = min(32, te - tb - 32 * t);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                // this step multiplies rows s (lanes 0-31) and 16+s (lanes 32-63)
+                const int e_lo = __builtin_amdgcn_readlane(e_l, s), e_hi = __builtin_amdgcn_readlane(e_l, 16 + s);
+                const int s_lo = __builtin_amdgcn_readlane(s_l, s), s_hi = __builtin_amdgcn_readlane(s_l, 16 + s);
+                const int e_r = hi ? e_hi : e_lo;
+                const int s_r = hi ? s_hi : s_lo;
+                const bool live = (hi ? 16 + s : s) < rows;
+                const float* pa = dmsg + (int64_t)e_r * F + i;
+                const float* pb = h + (int64_t)s_r * F + i;
+                float a0 = pa[0], a1 = pa[32];
+                float b0 = pb[0], b1 = pb[32];
+                if (gate) {
+                    const float* pg = gate + (int64_t)e_r * F + i;
+                    b0 *= pg[0];
+                    b1 *= pg[32];
+                }
+                if (!live) { a0 = 0.f; a1 = 0.f; }
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[3], 0, 0, 0);
+            }
+        }
+        if (any) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = 32 * (q & 1) + i;
+#pragma unroll
+                for (int z = 0; z < 16; ++z) {
+                    const int row = 32 * (q >> 1) + acc_row(z, lane);
+                    atomicAdd(&red[row * F + col], acc[q][z]);          // LDS float add
+                }
+            }
+        }
+        __syncthreads();
+        float* out = dA + (int64_t)k * F * F;
+        for (int idx = tid; idx < F * F; idx += 512) {
+            const float v = red[idx];
+            if (v != 0.f) atomicAdd(out + idx, v);
+        }
+        __syncthreads();                                // red is re-zeroed for the next type
+    }
+}
+
 // ------------------------------------------------------------------------------------ GRU gate gradients
 // From dout and the saved forward gates (r, z, n, gh_n) to the pre-activation gradients
 //   ws[row] = [ dgi_r dgi_z dgi_n | dgh_r dgh_z dgh_n ]   (6H floats)   and   dh_direct = dout*mask*z.
@@ -360,7 +447,14 @@ extern "C" int mpnn_edge_message_bwd_f32(const float* h, const float* A, const i
                                            nf, s, "mpnn_edge_message_bwd_f32(dx)");
         if (rc) return rc;
     }
-    if (dA) {
+    if (dA && mf == 64 && nf == 64 && K <= 64) {
+        int64_t gx = 512;                               // 2 blocks of 8 waves per CU
+        const int64_t need = ceil_div(ceil_div(E, 32) + K, 8);
+        if (gx > need) gx = need;
+        hipLaunchKernelGGL(edge_dA_direct64_kernel, dim3((unsigned)gx), dim3(512), 0, s, dmsg, h, src, order, type_ptr,
+                           gate, dA, K);
+        rc = launch_status("mpnn_edge_message_bwd_f32(dA direct)");
+    } else if (dA) {
         const int pairs = (int)(ceil_div(mf, 64) * ceil_div(nf, 64));
         int64_t gx = ceil_div(E, kBT) + K;
         if (gx > 1024) gx = 1024;
