@@ -318,20 +318,32 @@ __global__ void __launch_bounds__(512) gru_bwd_fused_kernel(const float* __restr
     }
     float colsum = 0.f;                                   // threads 256..511: column (tid-256) of dar|daz|dan|dnh
 
-    auto stage = [&](int64_t t, float* G, float* X) {
-        const int64_t row = t * 32 + srow;
-        f32x4 dar = {0.f, 0.f, 0.f, 0.f}, daz = dar, dan = dar, dnh = dar, gz = dar, vm = dar, vh = dar;
-        if (row < V) {
-            const float mk = HAS_MASK ? mask[row] : 1.0f;
-            const f32x4 v_do = *reinterpret_cast<const f32x4*>(dout + row * H + sc4);
-            vh = *reinterpret_cast<const f32x4*>(h + row * H + sc4);
-            vm = *reinterpret_cast<const f32x4*>(m + row * H + sc4);
-            const float* sv = saved + row * 4 * H + sc4;
-            const f32x4 v_z = *reinterpret_cast<const f32x4*>(sv + H);
-            gate_grads4(v_do, vh, *reinterpret_cast<const f32x4*>(sv), v_z, *reinterpret_cast<const f32x4*>(sv + 2 * H),
-                        *reinterpret_cast<const f32x4*>(sv + 3 * H), mk, dar, daz, dan, dnh);
-            gz = v_do * mk * v_z;
-        }
+    // staging is split (issue-early / write-late): the next tile's seven 16-byte loads are issued
+    // BEFORE this tile's MFMAs and only consumed (gate math + LDS writes) after them, so their HBM
+    // latency hides under the matrix work instead of stalling every wave at the top of the tile
+    struct Staged { f32x4 v_do, vh, vm, v_r, v_z, v_n, v_nh; float mk; bool ok; };
+    auto stage_load = [&](int64_t t) {
+        Staged q;
+        int64_t row = t * 32 + srow;
+        q.ok = row < V;
+        if (!q.ok) row = V - 1;                           // clamped: loads unconditional, result zeroed later
+        q.mk = HAS_MASK ? mask[row] : 1.0f;
+        q.v_do = *reinterpret_cast<const f32x4*>(dout + row * H + sc4);
+        q.vh = *reinterpret_cast<const f32x4*>(h + row * H + sc4);
+        q.vm = *reinterpret_cast<const f32x4*>(m + row * H + sc4);
+        const float* sv = saved + row * 4 * H + sc4;
+        q.v_r = *reinterpret_cast<const f32x4*>(sv);
+        q.v_z = *reinterpret_cast<const f32x4*>(sv + H);
+        q.v_n = *reinterpret_cast<const f32x4*>(sv + 2 * H);
+        q.v_nh = *reinterpret_cast<const f32x4*>(sv + 3 * H);
+        return q;
+    };
+    auto stage_write = [&](const Staged& q, float* G, float* X) {
+        f32x4 dar, daz, dan, dnh;
+        const float mk = q.ok ? q.mk : 0.0f;              // rows past V contribute exact zeros
+        gate_grads4(q.v_do, q.vh, q.v_r, q.v_z, q.v_n, q.v_nh, mk, dar, daz, dan, dnh);
+        const f32x4 gz = q.v_do * mk * q.v_z;
+        const float live = q.ok ? 1.0f : 0.0f;
         float* g = G + srow * LDG + sc4;
         *reinterpret_cast<f32x4*>(g) = dar;
         *reinterpret_cast<f32x4*>(g + H) = daz;
@@ -339,21 +351,23 @@ __global__ void __launch_bounds__(512) gru_bwd_fused_kernel(const float* __restr
         *reinterpret_cast<f32x4*>(g + 3 * H) = dnh;
         *reinterpret_cast<f32x4*>(g + 4 * H) = gz;
         float* x = X + srow * LDX + sc4;
-        *reinterpret_cast<f32x4*>(x) = vm;
-        *reinterpret_cast<f32x4*>(x + H) = vh;
+        *reinterpret_cast<f32x4*>(x) = q.vm * live;
+        *reinterpret_cast<f32x4*>(x + H) = q.vh * live;
     };
 
     int64_t t = blockIdx.x;
     int cur = 0;
-    if (t < tiles) stage(t, buf, buf + 32 * LDG);
+    if (t < tiles) {
+        const Staged q0 = stage_load(t);
+        stage_write(q0, buf, buf + 32 * LDG);
+    }
     for (; t < tiles; t += gridDim.x) {
         __syncthreads();                                  // tile `cur` staged; the other buffer is free again
         float* G = buf + cur * TILE_F;
         float* X = G + 32 * LDG;
-        if (t + gridDim.x < tiles) {
-            float* Gn = buf + (cur ^ 1) * TILE_F;
-            stage(t + gridDim.x, Gn, Gn + 32 * LDG);
-        }
+        const bool more = t + gridDim.x < tiles;
+        Staged nxt;
+        if (more) nxt = stage_load(t + gridDim.x);        // in flight during the MFMAs below
         if (dw_role) {
             // dW[mat][32*iblk + i'][32*jb + j'] += sum_rows X[row][mat*H + 32*iblk + i'] * Gm[row][col(jb) + j']
             const float* xa = X + hi * 16 * LDX + mat * H + 32 * iblk + i;
@@ -405,6 +419,10 @@ __global__ void __launch_bounds__(512) gru_bwd_fused_kernel(const float* __restr
 #pragma unroll 8
             for (int rr = 0; rr < 32; ++rr) part += G[rr * LDG + c];
             colsum += part;
+        }
+        if (more) {
+            float* Gn = buf + (cur ^ 1) * TILE_F;
+            stage_write(nxt, Gn, Gn + 32 * LDG);
         }
         cur ^= 1;
     }
