@@ -17,7 +17,10 @@
 //     computed/staged ONCE into a double-buffered LDS tile shared by the 8 waves, each wave owning
 //     3 of the 24 (32x32) tiles of dW_ih|dW_hh in registers for the block's whole life; partial
 //     sums leave through one float-atomic flush per block (dW is 2 x 48 KB).
-#include "common.h"
+#include <stdlib.h>
+#include <string.h>
+
+#include "split_math.h"
 
 namespace mpnn {
 
@@ -451,6 +454,211 @@ __global__ void __launch_bounds__(512) gru_bwd_fused_kernel(const float* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------ fused, bf16x6
+// Same structure as gru_bwd_fused_kernel (shared double-buffered fp32 LDS tile, dW waves + dx waves)
+// with every GEMM on the bf16 pipe through 3-way operand splitting (split_math.h):
+//   dx waves  B operand = their slice of W_ih / W_hh, split ONCE into 36 bf16x8 register fragments;
+//             A operand = 8 consecutive k of one LDS row (two ds_read_b128), split before use.
+//   dW waves  both operands are columns of the LDS tile (the contraction runs over atom rows):
+//             8 ds_read_b32 down a column per fragment, split before use.
+// 72 bf16 MFMAs (2,304 pipe cycles) per wave per tile instead of 96 fp32 MFMAs (6,144).
+template <int H, bool HAS_MASK>
+__global__ void __launch_bounds__(512) gru_bwd_fused_split_kernel(
+    const float* __restrict__ dout, const float* __restrict__ m, const float* __restrict__ h,
+    const float* __restrict__ mask, const float* __restrict__ W_ih, const float* __restrict__ W_hh,
+    const float* __restrict__ saved, float* __restrict__ dm, float* __restrict__ dh, float* dW_ih, float* dW_hh,
+    float* db_ih, float* db_hh, int64_t V) {
+    static_assert(H == 64, "role split below is laid out for H = 64");
+    constexpr int LDG = 5 * H + 4;
+    constexpr int LDX = 2 * H;
+    constexpr int TILE_F = 32 * (LDG + LDX);
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* buf = reinterpret_cast<float*>(smem_raw);
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i = lane & 31, hi = lane >> 5;
+    const int srow = tid >> 4, sc4 = (tid & 15) * 4;
+    const bool dw_role = wv < 4;
+    const int64_t tiles = (V + 31) / 32;
+    const int mat = (wv >> 1) & 1, iblk = wv & 1;
+    const int which = ((wv - 4) >> 1) & 1, nb = (wv - 4) & 1;
+
+    // ONE 144-register set per wave: dW waves use R[0..5] as their six accumulators; dx waves keep the
+    // 36 bf16x8 fragments (3 gates x 4 K-steps x 3 pieces) of their weight slice in it.
+    f32x16 R[9];
+    auto wfrag = [&](int g, int st, int piece) {
+        const int p = (g * 4 + st) * 3 + piece;           // 0..35, four fragments per f32x16
+        const f32x4 v = {R[p >> 2][(p & 3) * 4 + 0], R[p >> 2][(p & 3) * 4 + 1], R[p >> 2][(p & 3) * 4 + 2],
+                         R[p >> 2][(p & 3) * 4 + 3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    if (dw_role) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) R[j][q] = 0.f;
+    } else {
+        const float* Wsrc = (which == 0 ? W_ih : W_hh) + (int64_t)(32 * nb + i) * 3 * H + hi * (H / 2);
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wsrc + g * H + 8 * st);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(Wsrc + g * H + 8 * st + 4);
+                bf16x8 ph, pm, pl;
+                split8(w0, w1, ph, pm, pl);
+                const bf16x8 pc[3] = {ph, pm, pl};
+#pragma unroll
+                for (int piece = 0; piece < 3; ++piece) {
+                    const int p = (g * 4 + st) * 3 + piece;
+                    const f32x4 v = __builtin_bit_cast(f32x4, pc[piece]);
+                    R[p >> 2][(p & 3) * 4 + 0] = v.x;
+                    R[p >> 2][(p & 3) * 4 + 1] = v.y;
+                    R[p >> 2][(p & 3) * 4 + 2] = v.z;
+                    R[p >> 2][(p & 3) * 4 + 3] = v.w;
+                }
+            }
+    }
+    float colsum = 0.f;
+
+    struct Staged { f32x4 v_do, vh, vm, v_r, v_z, v_n, v_nh; float mk; bool ok; };
+    auto stage_load = [&](int64_t t) {
+        Staged q;
+        int64_t row = t * 32 + srow;
+        q.ok = row < V;
+        if (!q.ok) row = V - 1;
+        q.mk = HAS_MASK ? mask[row] : 1.0f;
+        q.v_do = *reinterpret_cast<const f32x4*>(dout + row * H + sc4);
+        q.vh = *reinterpret_cast<const f32x4*>(h + row * H + sc4);
+        q.vm = *reinterpret_cast<const f32x4*>(m + row * H + sc4);
+        const float* sv = saved + row * 4 * H + sc4;
+        q.v_r = *reinterpret_cast<const f32x4*>(sv);
+        q.v_z = *reinterpret_cast<const f32x4*>(sv + H);
+        q.v_n = *reinterpret_cast<const f32x4*>(sv + 2 * H);
+        q.v_nh = *reinterpret_cast<const f32x4*>(sv + 3 * H);
+        return q;
+    };
+    auto stage_write = [&](const Staged& q, float* G, float* X) {
+        f32x4 dar, daz, dan, dnh;
+        const float mk = q.ok ? q.mk : 0.0f;
+        gate_grads4(q.v_do, q.vh, q.v_r, q.v_z, q.v_n, q.v_nh, mk, dar, daz, dan, dnh);
+        const f32x4 gz = q.v_do * mk * q.v_z;
+        const float live = q.ok ? 1.0f : 0.0f;
+        float* g = G + srow * LDG + sc4;
+        *reinterpret_cast<f32x4*>(g) = dar;
+        *reinterpret_cast<f32x4*>(g + H) = daz;
+        *reinterpret_cast<f32x4*>(g + 2 * H) = dan;
+        *reinterpret_cast<f32x4*>(g + 3 * H) = dnh;
+        *reinterpret_cast<f32x4*>(g + 4 * H) = gz;
+        float* x = X + srow * LDX + sc4;
+        *reinterpret_cast<f32x4*>(x) = q.vm * live;
+        *reinterpret_cast<f32x4*>(x + H) = q.vh * live;
+    };
+    // 8 consecutive rows of one LDS column (the K=16 fragment of a row-contraction), split in 3
+    auto column_frag = [&](const float* base, int ld, bf16x8& ph, bf16x8& pm, bf16x8& pl) {
+        const f32x4 x0 = {base[0], base[ld], base[2 * ld], base[3 * ld]};
+        const f32x4 x1 = {base[4 * ld], base[5 * ld], base[6 * ld], base[7 * ld]};
+        split8(x0, x1, ph, pm, pl);
+    };
+
+    int64_t t = blockIdx.x;
+    int cur = 0;
+    if (t < tiles) {
+        const Staged q0 = stage_load(t);
+        stage_write(q0, buf, buf + 32 * LDG);
+    }
+    for (; t < tiles; t += gridDim.x) {
+        __syncthreads();
+        float* G = buf + cur * TILE_F;
+        float* X = G + 32 * LDG;
+        const bool more = t + gridDim.x < tiles;
+        Staged nxt;
+        if (more) nxt = stage_load(t + gridDim.x);
+        if (dw_role) {
+            const int noff = mat == 0 ? 2 * H : 3 * H;    // W_ih's n-gate column uses dan, W_hh's uses dnh
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const int row0 = 16 * st + 8 * hi;        // this lane half's 8 rows of the K=16 step
+                bf16x8 ah, am, al, bh, bm, bl;
+                column_frag(X + row0 * LDX + mat * H + 32 * iblk + i, LDX, ah, am, al);
+                const float* gcol = G + row0 * LDG + i;
+                column_frag(gcol, LDG, bh, bm, bl);
+                mma6(R[0], ah, am, al, bh, bm, bl);
+                column_frag(gcol + 32, LDG, bh, bm, bl);
+                mma6(R[1], ah, am, al, bh, bm, bl);
+                column_frag(gcol + H, LDG, bh, bm, bl);
+                mma6(R[2], ah, am, al, bh, bm, bl);
+                column_frag(gcol + H + 32, LDG, bh, bm, bl);
+                mma6(R[3], ah, am, al, bh, bm, bl);
+                column_frag(gcol + noff, LDG, bh, bm, bl);
+                mma6(R[4], ah, am, al, bh, bm, bl);
+                column_frag(gcol + noff + 32, LDG, bh, bm, bl);
+                mma6(R[5], ah, am, al, bh, bm, bl);
+            }
+        } else {
+            f32x16 d;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) d[q] = 0.f;
+            const float* ga = G + i * LDG + hi * (H / 2);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const int seg = (g == 2 && which == 1) ? 3 : g;
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(ga + seg * H + 8 * st);
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(ga + seg * H + 8 * st + 4);
+                    bf16x8 ah, am, al;
+                    split8(a0, a1, ah, am, al);
+                    mma6(d, ah, am, al, wfrag(g, st, 0), wfrag(g, st, 1), wfrag(g, st, 2));
+                }
+            }
+            float* outp = which == 0 ? dm : dh;
+            const int col = 32 * nb + i;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int rl = acc_row(q, lane);
+                const int64_t row = t * 32 + rl;
+                float v = d[q];
+                if (which == 1) v += G[rl * LDG + 4 * H + col];
+                if (row < V) outp[row * H + col] = v;
+            }
+            const int c = tid - 256;
+            float part = 0.f;
+#pragma unroll 8
+            for (int rr = 0; rr < 32; ++rr) part += G[rr * LDG + c];
+            colsum += part;
+        }
+        if (more) {
+            float* Gn = buf + (cur ^ 1) * TILE_F;
+            stage_write(nxt, Gn, Gn + 32 * LDG);
+        }
+        cur ^= 1;
+    }
+    if (dw_role) {
+        float* dW = mat == 0 ? dW_ih : dW_hh;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int col = 32 * j + i;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = 32 * iblk + acc_row(q, lane);
+                atomicAdd(dW + (int64_t)row * 3 * H + col, R[j][q]);
+            }
+        }
+    } else if (blockIdx.x < tiles) {
+        const int c = tid - 256;
+        const int seg = c / H, cc = c % H;
+        if (seg < 2) {
+            atomicAdd(db_ih + seg * H + cc, colsum);
+            atomicAdd(db_hh + seg * H + cc, colsum);
+        } else if (seg == 2) {
+            atomicAdd(db_ih + 2 * H + cc, colsum);
+        } else {
+            atomicAdd(db_hh + 2 * H + cc, colsum);
+        }
+    }
+}
+
 int launch_gru_bwd_fused64(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
                            const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
                            float* db_ih, float* db_hh, int64_t V, hipStream_t s) {
@@ -467,6 +675,24 @@ int launch_gru_bwd_fused64(const float* dout, const float* m, const float* h, co
     }
     int64_t blocks = 256;                                  // one 8-wave block per CU (116 KB of LDS)
     if (blocks > tiles) blocks = tiles;
+    static const bool fp32_only = getenv("MPNN_GRU_MATH") && !strcmp(getenv("MPNN_GRU_MATH"), "fp32");
+    if (!fp32_only) {
+        static bool attr2 = false;
+        if (!attr2) {
+            (void)hipFuncSetAttribute((const void*)gru_bwd_fused_split_kernel<H, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)gru_bwd_fused_split_kernel<H, false>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr2 = true;
+        }
+        if (mask)
+            hipLaunchKernelGGL((gru_bwd_fused_split_kernel<H, true>), dim3((unsigned)blocks), dim3(512), lds, s, dout, m,
+                               h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, V);
+        else
+            hipLaunchKernelGGL((gru_bwd_fused_split_kernel<H, false>), dim3((unsigned)blocks), dim3(512), lds, s, dout, m,
+                               h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, V);
+        return launch_status("mpnn_gru_update_bwd_f32(fused bf16x6)");
+    }
     if (mask)
         hipLaunchKernelGGL((gru_bwd_fused_kernel<H, true>), dim3((unsigned)blocks), dim3(512), lds, s, dout, m, h, mask,
                            W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, V);

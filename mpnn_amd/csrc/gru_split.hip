@@ -16,11 +16,9 @@
 //     k contiguous: a B fragment of one piece = one ds_read_b128), 16-byte chunks XOR-swizzled by the
 //     column so the 16-lane read groups are conflict-free;
 //   * activations are split in registers right before use (8 floats -> 3 x bf16x8 per K=16 step).
-#include "common.h"
+#include "split_math.h"
 
 namespace mpnn {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float sigmoid_fast(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x));
@@ -29,41 +27,11 @@ __device__ __forceinline__ float tanh_fast(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681472f * x));
 }
 
-__device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l) {
-    h = (__bf16)v;
-    const float r1 = v - (float)h;      // exact
-    m = (__bf16)r1;
-    const float r2 = r1 - (float)m;     // exact
-    l = (__bf16)r2;
-}
-
-__device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, bf16x8& ph, bf16x8& pm, bf16x8& pl) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        __bf16 h, m, l;
-        split3(x0[j], h, m, l);
-        ph[j] = h; pm[j] = m; pl[j] = l;
-        split3(x1[j], h, m, l);
-        ph[4 + j] = h; pm[4 + j] = m; pl[4 + j] = l;
-    }
-}
-
 template <int H>
 __device__ __forceinline__ int col_swizzle(int col) {
     // rows are H bf16 = H/2 dwords: 32 dwords (H=64) alternate between the two halves of the 64 banks,
     // 64 dwords (H=128) all start on bank 0
     return H == 64 ? ((col >> 1) & 7) : (col & 15);
-}
-
-// six partial products of one K=16 step into one accumulator, small terms first
-__device__ __forceinline__ void mma6(f32x16& acc, const bf16x8& ah, const bf16x8& am, const bf16x8& al,
-                                     const bf16x8& bh, const bf16x8& bm, const bf16x8& bl) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
 }
 
 template <int H, int NCS, int NW, bool HAS_MASK>
