@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(512) gru_bwd_fused_split_kernel(
     const float* __restrict__ dout, const float* __restrict__ m, const float* __restrict__ h,
     const float* __restrict__ mask, const float* __restrict__ W_ih, const float* __restrict__ W_hh,
     const float* __restrict__ saved, float* __restrict__ dm, float* __restrict__ dh, float* dW_ih, float* dW_hh,
-    float* db_ih, float* db_hh, int64_t V) {
+    float* db_ih, float* db_hh, int64_t V, int ablate /* timing experiments only: 1 = no GEMMs, 2 = no tile loads */) {
     static_assert(H == 64, "role split below is laid out for H = 64");
     constexpr int LDG = 5 * H + 4;
     constexpr int LDX = 2 * H;
@@ -573,8 +573,9 @@ __global__ void __launch_bounds__(512) gru_bwd_fused_split_kernel(
         float* X = G + 32 * LDG;
         const bool more = t + gridDim.x < tiles;
         Staged nxt;
-        if (more) nxt = stage_load(t + gridDim.x);
-        if (dw_role) {
+        if (more) nxt = stage_load(ablate == 2 ? (int64_t)blockIdx.x : t + gridDim.x);
+        if (ablate == 1) {
+        } else if (dw_role) {
             const int noff = mat == 0 ? 2 * H : 3 * H;    // W_ih's n-gate column uses dan, W_hh's uses dnh
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
@@ -676,6 +677,7 @@ int launch_gru_bwd_fused64(const float* dout, const float* m, const float* h, co
     int64_t blocks = 256;                                  // one 8-wave block per CU (116 KB of LDS)
     if (blocks > tiles) blocks = tiles;
     static const bool fp32_only = getenv("MPNN_GRU_MATH") && !strcmp(getenv("MPNN_GRU_MATH"), "fp32");
+    static const int ablate = getenv("MPNN_GRU_BWD_ABLATE") ? atoi(getenv("MPNN_GRU_BWD_ABLATE")) : 0;
     if (!fp32_only) {
         static bool attr2 = false;
         if (!attr2) {
@@ -687,10 +689,10 @@ int launch_gru_bwd_fused64(const float* dout, const float* m, const float* h, co
         }
         if (mask)
             hipLaunchKernelGGL((gru_bwd_fused_split_kernel<H, true>), dim3((unsigned)blocks), dim3(512), lds, s, dout, m,
-                               h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, V);
+                               h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, V, ablate);
         else
             hipLaunchKernelGGL((gru_bwd_fused_split_kernel<H, false>), dim3((unsigned)blocks), dim3(512), lds, s, dout, m,
-                               h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, V);
+                               h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, V, ablate);
         return launch_status("mpnn_gru_update_bwd_f32(fused bf16x6)");
     }
     if (mask)
