@@ -475,9 +475,12 @@ __global__ void __launch_bounds__(512) gru_bwd_fused_split_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* buf = reinterpret_cast<float*>(smem_raw);
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: role branches become s_cbranch
     const int i = lane & 31, hi = lane >> 5;
-    const int srow = tid >> 4, sc4 = (tid & 15) * 4;
+    // staging is done by the dW waves only (threads 0..255, two rows each): the dx waves spend their
+    // registers on the resident weight fragments instead
+    const int srow = (tid & 255) >> 4, sc4 = (tid & 15) * 4;
     const bool dw_role = wv < 4;
     const int64_t tiles = (V + 31) / 32;
     const int mat = (wv >> 1) & 1, iblk = wv & 1;
@@ -522,9 +525,9 @@ __global__ void __launch_bounds__(512) gru_bwd_fused_split_kernel(
     float colsum = 0.f;
 
     struct Staged { f32x4 v_do, vh, vm, v_r, v_z, v_n, v_nh; float mk; bool ok; };
-    auto stage_load = [&](int64_t t) {
+    auto stage_load = [&](int64_t t, int half) {
         Staged q;
-        int64_t row = t * 32 + srow;
+        int64_t row = t * 32 + srow + 16 * half;
         q.ok = row < V;
         if (!q.ok) row = V - 1;
         q.mk = HAS_MASK ? mask[row] : 1.0f;
@@ -538,19 +541,20 @@ __global__ void __launch_bounds__(512) gru_bwd_fused_split_kernel(
         q.v_nh = *reinterpret_cast<const f32x4*>(sv + 3 * H);
         return q;
     };
-    auto stage_write = [&](const Staged& q, float* G, float* X) {
+    auto stage_write = [&](const Staged& q, int half, float* G, float* X) {
         f32x4 dar, daz, dan, dnh;
         const float mk = q.ok ? q.mk : 0.0f;
         gate_grads4(q.v_do, q.vh, q.v_r, q.v_z, q.v_n, q.v_nh, mk, dar, daz, dan, dnh);
         const f32x4 gz = q.v_do * mk * q.v_z;
         const float live = q.ok ? 1.0f : 0.0f;
-        float* g = G + srow * LDG + sc4;
+        const int lrow = srow + 16 * half;
+        float* g = G + lrow * LDG + sc4;
         *reinterpret_cast<f32x4*>(g) = dar;
         *reinterpret_cast<f32x4*>(g + H) = daz;
         *reinterpret_cast<f32x4*>(g + 2 * H) = dan;
         *reinterpret_cast<f32x4*>(g + 3 * H) = dnh;
         *reinterpret_cast<f32x4*>(g + 4 * H) = gz;
-        float* x = X + srow * LDX + sc4;
+        float* x = X + lrow * LDX + sc4;
         *reinterpret_cast<f32x4*>(x) = q.vm * live;
         *reinterpret_cast<f32x4*>(x + H) = q.vh * live;
     };
@@ -563,18 +567,23 @@ __global__ void __launch_bounds__(512) gru_bwd_fused_split_kernel(
 
     int64_t t = blockIdx.x;
     int cur = 0;
-    if (t < tiles) {
-        const Staged q0 = stage_load(t);
-        stage_write(q0, buf, buf + 32 * LDG);
+    if (t < tiles && dw_role) {
+        const Staged q0 = stage_load(t, 0), q1 = stage_load(t, 1);
+        stage_write(q0, 0, buf, buf + 32 * LDG);
+        stage_write(q1, 1, buf, buf + 32 * LDG);
     }
     for (; t < tiles; t += gridDim.x) {
         __syncthreads();
         float* G = buf + cur * TILE_F;
         float* X = G + 32 * LDG;
         const bool more = t + gridDim.x < tiles;
-        Staged nxt;
-        if (more) nxt = stage_load(ablate == 2 ? (int64_t)blockIdx.x : t + gridDim.x);
-        if (ablate == 1) {
+        Staged nx0, nx1;
+        if (more && dw_role) {
+            const int64_t tn = ablate == 2 ? (int64_t)blockIdx.x : t + gridDim.x;
+            nx0 = stage_load(tn, 0);
+            nx1 = stage_load(tn, 1);
+        }
+        if (ablate == 1 || (ablate == 3 && !dw_role) || (ablate == 4 && dw_role)) {
         } else if (dw_role) {
             const int noff = mat == 0 ? 2 * H : 3 * H;    // W_ih's n-gate column uses dan, W_hh's uses dnh
 #pragma unroll
@@ -615,13 +624,14 @@ __global__ void __launch_bounds__(512) gru_bwd_fused_split_kernel(
             }
             float* outp = which == 0 ? dm : dh;
             const int col = 32 * nb + i;
+            if (which == 1) {                             // scalar branch; the 16 LDS reads go out together
+#pragma unroll
+                for (int q = 0; q < 16; ++q) d[q] += G[acc_row(q, lane) * LDG + 4 * H + col];
+            }
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const int rl = acc_row(q, lane);
-                const int64_t row = t * 32 + rl;
-                float v = d[q];
-                if (which == 1) v += G[rl * LDG + 4 * H + col];
-                if (row < V) outp[row * H + col] = v;
+                const int64_t row = t * 32 + acc_row(q, lane);
+                if (row < V) outp[row * H + col] = d[q];
             }
             const int c = tid - 256;
             float part = 0.f;
@@ -629,9 +639,10 @@ __global__ void __launch_bounds__(512) gru_bwd_fused_split_kernel(
             for (int rr = 0; rr < 32; ++rr) part += G[rr * LDG + c];
             colsum += part;
         }
-        if (more) {
+        if (more && dw_role) {
             float* Gn = buf + (cur ^ 1) * TILE_F;
-            stage_write(nxt, Gn, Gn + 32 * LDG);
+            stage_write(nx0, 0, Gn, Gn + 32 * LDG);
+            stage_write(nx1, 1, Gn, Gn + 32 * LDG);
         }
         cur ^= 1;
     }
@@ -649,6 +660,203 @@ __global__ void __launch_bounds__(512) gru_bwd_fused_split_kernel(
     } else if (blockIdx.x < tiles) {
         const int c = tid - 256;
         const int seg = c / H, cc = c % H;
+        if (seg < 2) {
+            atomicAdd(db_ih + seg * H + cc, colsum);
+            atomicAdd(db_hh + seg * H + cc, colsum);
+        } else if (seg == 2) {
+            atomicAdd(db_ih + 2 * H + cc, colsum);
+        } else {
+            atomicAdd(db_hh + 2 * H + cc, colsum);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ fused, uniform waves
+// Third arrangement of the same fused backward (shared double-buffered fp32 LDS tile): all 8 waves run
+// the SAME program, so register allocation is not the union of two roles and every wave carries the
+// same load.  Per 32-atom tile each wave
+//   * advances its 3 of the 24 (32x32) tiles of dW_ih|dW_hh on v_mfma_f32_32x32x2_f32 (exact fp32; both
+//     operands are single ds_read_b32 of the LDS tile, no splitting), 48 MFMAs;
+//   * computes one 16-column unit of dm|dh (32 atoms x 16 columns, K = 192) on the bf16 pipe with 3-way
+//     operand splitting (v_mfma_f32_16x16x32_bf16, split_math.h): its 72-register slice of W_ih / W_hh is
+//     split once and stays in registers, the A rows come from the LDS tile, 72 MFMAs of 16 cycles.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void mma6_16(f32x4& acc, const bf16x8& ah, const bf16x8& am, const bf16x8& al,
+                                        const bf16x8& bh, const bf16x8& bm, const bf16x8& bl) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+}
+
+template <int H, bool HAS_MASK>
+__global__ void __launch_bounds__(512) gru_bwd_uniform_kernel(
+    const float* __restrict__ dout, const float* __restrict__ m, const float* __restrict__ h,
+    const float* __restrict__ mask, const float* __restrict__ W_ih, const float* __restrict__ W_hh,
+    const float* __restrict__ saved, float* __restrict__ dm, float* __restrict__ dh, float* dW_ih, float* dW_hh,
+    float* db_ih, float* db_hh, int64_t V) {
+    static_assert(H == 64, "tile ownership below is laid out for H = 64");
+    constexpr int LDG = 5 * H + 4;        // dar | daz | dan | dnh | g*z
+    constexpr int LDX = 2 * H;            // m | h
+    constexpr int TILE_F = 32 * (LDG + LDX);
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* buf = reinterpret_cast<float*>(smem_raw);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int srow = tid >> 4, sc4 = (tid & 15) * 4;      // staging: (row, 4 columns)
+    const int64_t tiles = (V + 31) / 32;
+
+    // dW ownership (32x32x2 f32): matrix, 32-row block of dW, three 32-column blocks
+    const int mat = wv >> 2, iblk = (wv >> 1) & 1, jbase = (wv & 1) * 3;
+    const int i32 = lane & 31, hi = lane >> 5;
+    f32x16 acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+    int goff[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int jb = jbase + j;                          // 0..5: gate = jb/2, column half = jb%2
+        goff[j] = (jb >> 1) * H + (jb & 1) * 32 + ((mat == 1 && (jb >> 1) == 2) ? H : 0);   // W_hh's n column: dnh
+    }
+
+    // dx ownership (16x16x32 bf16x6): product (0: dm via W_ih, 1: dh via W_hh), 16-column block
+    const int which = wv >> 2, cb = wv & 3;
+    const int r16 = lane & 15, kq = lane >> 4;
+    bf16x8 wh[6], wm[6], wl[6];                            // B operand: W[16cb + r16][k = 32s + 8kq + j]
+    {
+        const float* Wsrc = (which == 0 ? W_ih : W_hh) + (int64_t)(16 * cb + r16) * 3 * H + 8 * kq;
+#pragma unroll
+        for (int s2 = 0; s2 < 6; ++s2) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wsrc + 32 * s2);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(Wsrc + 32 * s2 + 4);
+            split8(w0, w1, wh[s2], wm[s2], wl[s2]);
+        }
+    }
+    float colsum = 0.f;                                    // threads 0..255: column tid of dar|daz|dan|dnh
+
+    struct Staged { f32x4 v_do, vh, vm, v_r, v_z, v_n, v_nh; float mk; bool ok; };
+    auto stage_load = [&](int64_t t) {
+        Staged q;
+        int64_t row = t * 32 + srow;
+        q.ok = row < V;
+        if (!q.ok) row = V - 1;
+        q.mk = HAS_MASK ? mask[row] : 1.0f;
+        q.v_do = *reinterpret_cast<const f32x4*>(dout + row * H + sc4);
+        q.vh = *reinterpret_cast<const f32x4*>(h + row * H + sc4);
+        q.vm = *reinterpret_cast<const f32x4*>(m + row * H + sc4);
+        const float* sv = saved + row * 4 * H + sc4;
+        q.v_r = *reinterpret_cast<const f32x4*>(sv);
+        q.v_z = *reinterpret_cast<const f32x4*>(sv + H);
+        q.v_n = *reinterpret_cast<const f32x4*>(sv + 2 * H);
+        q.v_nh = *reinterpret_cast<const f32x4*>(sv + 3 * H);
+        return q;
+    };
+    auto stage_write = [&](const Staged& q, float* G, float* X) {
+        f32x4 dar, daz, dan, dnh;
+        const float mk = q.ok ? q.mk : 0.0f;
+        gate_grads4(q.v_do, q.vh, q.v_r, q.v_z, q.v_n, q.v_nh, mk, dar, daz, dan, dnh);
+        const f32x4 gz = q.v_do * mk * q.v_z;
+        const float live = q.ok ? 1.0f : 0.0f;
+        float* g = G + srow * LDG + sc4;
+        *reinterpret_cast<f32x4*>(g) = dar;
+        *reinterpret_cast<f32x4*>(g + H) = daz;
+        *reinterpret_cast<f32x4*>(g + 2 * H) = dan;
+        *reinterpret_cast<f32x4*>(g + 3 * H) = dnh;
+        *reinterpret_cast<f32x4*>(g + 4 * H) = gz;
+        float* x = X + srow * LDX + sc4;
+        *reinterpret_cast<f32x4*>(x) = q.vm * live;
+        *reinterpret_cast<f32x4*>(x + H) = q.vh * live;
+    };
+
+    int64_t t = blockIdx.x;
+    int cur = 0;
+    if (t < tiles) {
+        const Staged q0 = stage_load(t);
+        stage_write(q0, buf, buf + 32 * LDG);
+    }
+    for (; t < tiles; t += gridDim.x) {
+        __syncthreads();
+        float* G = buf + cur * TILE_F;
+        float* X = G + 32 * LDG;
+        const bool more = t + gridDim.x < tiles;
+        Staged nxt;
+        if (more) nxt = stage_load(t + gridDim.x);         // in flight under the matrix work below
+
+        // ---- dW: three fp32 accumulators, contraction over the tile's 32 atoms ----
+        {
+            const float* xa = X + hi * 16 * LDX + mat * H + 32 * iblk + i32;
+            const float* gb = G + hi * 16 * LDG + i32;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float av = xa[s * LDX];
+                const float* gs = gb + s * LDG;
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, gs[goff[0]], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, gs[goff[1]], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, gs[goff[2]], acc[2], 0, 0, 0);
+            }
+        }
+        // ---- dx: one 16-column unit of dm | dh for both 16-atom halves of the tile ----
+        {
+            f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
+#pragma unroll
+            for (int s2 = 0; s2 < 6; ++s2) {
+                const int g = s2 >> 1;                     // gate of this K=32 step
+                const int seg = (g == 2 && which == 1) ? 3 : g;
+                const float* ga = G + r16 * LDG + seg * H + (s2 & 1) * 32 + 8 * kq;
+                bf16x8 ah, am, al;
+                split8(*reinterpret_cast<const f32x4*>(ga), *reinterpret_cast<const f32x4*>(ga + 4), ah, am, al);
+                mma6_16(d0, ah, am, al, wh[s2], wm[s2], wl[s2]);
+                const float* gb2 = ga + 16 * LDG;
+                split8(*reinterpret_cast<const f32x4*>(gb2), *reinterpret_cast<const f32x4*>(gb2 + 4), ah, am, al);
+                mma6_16(d1, ah, am, al, wh[s2], wm[s2], wl[s2]);
+            }
+            // C/D of 16x16: col = lane&15, row = (lane>>4)*4 + reg
+            float* outp = which == 0 ? dm : dh;
+            const int col = 16 * cb + r16;
+            if (which == 1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    d0[q] += G[(4 * kq + q) * LDG + 4 * H + col];
+                    d1[q] += G[(16 + 4 * kq + q) * LDG + 4 * H + col];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t row0 = t * 32 + 4 * kq + q, row1 = row0 + 16;
+                if (row0 < V) outp[row0 * H + col] = d0[q];
+                if (row1 < V) outp[row1 * H + col] = d1[q];
+            }
+        }
+        if (tid < 4 * H) {
+            float part = 0.f;
+#pragma unroll 8
+            for (int rr = 0; rr < 32; ++rr) part += G[rr * LDG + tid];
+            colsum += part;
+        }
+        if (more) {
+            float* Gn = buf + (cur ^ 1) * TILE_F;
+            stage_write(nxt, Gn, Gn + 32 * LDG);
+        }
+        cur ^= 1;
+    }
+    float* dW = mat == 0 ? dW_ih : dW_hh;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int col = 32 * (jbase + j) + i32;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = 32 * iblk + acc_row(q, lane);
+            atomicAdd(dW + (int64_t)row * 3 * H + col, acc[j][q]);
+        }
+    }
+    if (tid < 4 * H && blockIdx.x < tiles) {
+        const int seg = tid / H, cc = tid % H;            // 0 dar, 1 daz, 2 dan, 3 dnh
         if (seg < 2) {
             atomicAdd(db_ih + seg * H + cc, colsum);
             atomicAdd(db_hh + seg * H + cc, colsum);
@@ -678,6 +886,24 @@ int launch_gru_bwd_fused64(const float* dout, const float* m, const float* h, co
     if (blocks > tiles) blocks = tiles;
     static const bool fp32_only = getenv("MPNN_GRU_MATH") && !strcmp(getenv("MPNN_GRU_MATH"), "fp32");
     static const int ablate = getenv("MPNN_GRU_BWD_ABLATE") ? atoi(getenv("MPNN_GRU_BWD_ABLATE")) : 0;
+    static const bool roles = getenv("MPNN_GRU_BWD_ROLES") != nullptr;      // A/B: the dW-waves/dx-waves arrangement
+    if (!fp32_only && !roles) {
+        static bool attr3 = false;
+        if (!attr3) {
+            (void)hipFuncSetAttribute((const void*)gru_bwd_uniform_kernel<H, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)gru_bwd_uniform_kernel<H, false>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr3 = true;
+        }
+        if (mask)
+            hipLaunchKernelGGL((gru_bwd_uniform_kernel<H, true>), dim3((unsigned)blocks), dim3(512), lds, s, dout, m, h,
+                               mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, V);
+        else
+            hipLaunchKernelGGL((gru_bwd_uniform_kernel<H, false>), dim3((unsigned)blocks), dim3(512), lds, s, dout, m, h,
+                               mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, V);
+        return launch_status("mpnn_gru_update_bwd_f32(uniform)");
+    }
     if (!fp32_only) {
         static bool attr2 = false;
         if (!attr2) {
