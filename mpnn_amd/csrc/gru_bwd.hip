@@ -8,15 +8,14 @@
 //   dm  = dgi W_ih^T      dh  = dgh W_hh^T + g*z
 //   dW_ih = m^T dgi       dW_hh = h^T dgh      db_ih = colsum(dgi)     db_hh = colsum(dgh)
 //
-// Two kernels, neither materialises the (V, 6H) pre-activation gradients in HBM:
-//
-//  K1 gru_bwd_dx_kernel   persistent waves, W_ih / W_hh resident in LDS as [n][k] images.  The gate
-//     gradients are computed elementwise directly in the MFMA A-fragment layout (lane = atom row,
-//     4 consecutive columns per step), so they feed v_mfma_f32_32x32x2_f32 from registers.
-//  K2 gru_bwd_dw_kernel   persistent blocks; each 32-atom tile's gate gradients and m/h rows are
-//     computed/staged ONCE into a double-buffered LDS tile shared by the 8 waves, each wave owning
-//     3 of the 24 (32x32) tiles of dW_ih|dW_hh in registers for the block's whole life; partial
-//     sums leave through one float-atomic flush per block (dW is 2 x 48 KB).
+// One fused kernel; the (V, 6H) pre-activation gradients are never materialised in HBM.  Three
+// arrangements of the same structure live here (all parity-tested):
+//   gru_bwd_fused_split_kernel   default: dW waves + dx waves, bf16x6 GEMMs            (2.5 ms on c2)
+//   gru_bwd_uniform_kernel       MPNN_GRU_BWD_UNIFORM=1: all waves identical           (2.8 ms)
+//   gru_bwd_fused_kernel         MPNN_GRU_MATH=fp32: fp32 MFMA throughout              (3.0 ms)
+// History (measured, dropped): separate elementwise + 4 generic GEMM launches with a (V,6H) workspace
+// 8.8 ms; a per-lane-row kernel computing gate gradients directly in fragment layout 5.3 ms (every
+// 128-B line touched 16 B at a time, microseconds apart -> refetched from beyond L2).
 #include <stdlib.h>
 #include <string.h>
 
@@ -34,228 +33,6 @@ __device__ __forceinline__ void gate_grads4(const f32x4& dout, const f32x4& hv, 
     dar = dan * nh * mk * r * (1.0f - r);
     daz = dz * mk * z * (1.0f - z);
     dnh = dan * r;
-}
-
-// ------------------------------------------------------------------------------------------ K1
-template <int H, int NW, bool HAS_MASK>
-__global__ void __launch_bounds__(64 * NW) gru_bwd_dx_kernel(const float* __restrict__ dout, const float* __restrict__ h,
-                                                             const float* __restrict__ mask,
-                                                             const float* __restrict__ W_ih,
-                                                             const float* __restrict__ W_hh,
-                                                             const float* __restrict__ saved, float* __restrict__ dm,
-                                                             float* __restrict__ dh, int64_t V) {
-    constexpr int NB = H / 32;            // output column blocks
-    constexpr int LD = 3 * H + 4;         // [n][k] image stride: conflict-free ds_read_b128
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* Wi = reinterpret_cast<float*>(smem_raw);   // [H][LD]   Wi[n][k] = W_ih[n][k]
-    float* Wh = Wi + H * LD;                          // [H][LD]
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int idx = tid; idx < H * (3 * H / 4); idx += 64 * NW) {
-        const int n = idx / (3 * H / 4), q = idx % (3 * H / 4);
-        *reinterpret_cast<f32x4*>(Wi + n * LD + 4 * q) = *reinterpret_cast<const f32x4*>(W_ih + (int64_t)n * 3 * H + 4 * q);
-        *reinterpret_cast<f32x4*>(Wh + n * LD + 4 * q) = *reinterpret_cast<const f32x4*>(W_hh + (int64_t)n * 3 * H + 4 * q);
-    }
-    __syncthreads();
-
-    const int r = lane & 31, hi = lane >> 5;
-    const int64_t tiles = (V + 31) / 32;
-    const int64_t stride = (int64_t)gridDim.x * NW;
-    const float* wi_lane = Wi + r * LD + hi * (H / 2);
-    const float* wh_lane = Wh + r * LD + hi * (H / 2);
-
-    for (int64_t t = (int64_t)blockIdx.x * NW + wv; t < tiles; t += stride) {
-        int64_t row = t * 32 + r;
-        if (row >= V) row = V - 1;
-        const float mk = HAS_MASK ? mask[row] : 1.0f;
-        const float* p_do = dout + row * H + hi * (H / 2);
-        const float* p_h = h + row * H + hi * (H / 2);
-        const float* p_sv = saved + row * 4 * H + hi * (H / 2);
-
-        f32x16 acc_m[NB], acc_h[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { acc_m[b][i] = 0.f; acc_h[b][i] = 0.f; }
-
-        // chunk loop kept rolled (one 4-column chunk = 48 MFMAs) with the next chunk's six operand
-        // loads issued before the current chunk's MFMAs: bounded registers, loads always one chunk ahead
-        f32x4 c_do = *reinterpret_cast<const f32x4*>(p_do);
-        f32x4 c_h = *reinterpret_cast<const f32x4*>(p_h);
-        f32x4 c_r = *reinterpret_cast<const f32x4*>(p_sv);
-        f32x4 c_z = *reinterpret_cast<const f32x4*>(p_sv + H);
-        f32x4 c_n = *reinterpret_cast<const f32x4*>(p_sv + 2 * H);
-        f32x4 c_nh = *reinterpret_cast<const f32x4*>(p_sv + 3 * H);
-#pragma unroll 1
-        for (int q = 0; q < H / 8; ++q) {
-            const int qn = (q + 1 < H / 8) ? q + 1 : q;
-            const f32x4 n_do = *reinterpret_cast<const f32x4*>(p_do + 4 * qn);
-            const f32x4 n_h = *reinterpret_cast<const f32x4*>(p_h + 4 * qn);
-            const f32x4 n_r = *reinterpret_cast<const f32x4*>(p_sv + 4 * qn);
-            const f32x4 n_z = *reinterpret_cast<const f32x4*>(p_sv + H + 4 * qn);
-            const f32x4 n_n = *reinterpret_cast<const f32x4*>(p_sv + 2 * H + 4 * qn);
-            const f32x4 n_nh = *reinterpret_cast<const f32x4*>(p_sv + 3 * H + 4 * qn);
-            f32x4 dar, daz, dan, dnh;
-            gate_grads4(c_do, c_h, c_r, c_z, c_n, c_nh, mk, dar, daz, dan, dnh);
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const float* bi = wi_lane + 32 * b * LD + 4 * q;
-                const float* bh = wh_lane + 32 * b * LD + 4 * q;
-                const f32x4 wir = *reinterpret_cast<const f32x4*>(bi);
-                const f32x4 wiz = *reinterpret_cast<const f32x4*>(bi + H);
-                const f32x4 win = *reinterpret_cast<const f32x4*>(bi + 2 * H);
-                const f32x4 whr = *reinterpret_cast<const f32x4*>(bh);
-                const f32x4 whz = *reinterpret_cast<const f32x4*>(bh + H);
-                const f32x4 whn = *reinterpret_cast<const f32x4*>(bh + 2 * H);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    acc_m[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(dar[c], wir[c], acc_m[b], 0, 0, 0);
-                    acc_h[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(dar[c], whr[c], acc_h[b], 0, 0, 0);
-                    acc_m[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(daz[c], wiz[c], acc_m[b], 0, 0, 0);
-                    acc_h[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(daz[c], whz[c], acc_h[b], 0, 0, 0);
-                    acc_m[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(dan[c], win[c], acc_m[b], 0, 0, 0);
-                    acc_h[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(dnh[c], whn[c], acc_h[b], 0, 0, 0);
-                }
-            }
-            c_do = n_do; c_h = n_h; c_r = n_r; c_z = n_z; c_n = n_n; c_nh = n_nh;
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float dir4[4][NB];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int64_t orow = t * 32 + 8 * g + 4 * hi + u;
-                if (orow >= V) orow = V - 1;
-                const float omk = HAS_MASK ? mask[orow] : 1.0f;
-#pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    const int col = 32 * b + r;
-                    dir4[u][b] = dout[orow * H + col] * omk * saved[orow * 4 * H + H + col];   // g*z
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = 4 * g + u;
-                const int64_t orow = t * 32 + 8 * g + 4 * hi + u;
-                if (orow < V) {
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) {
-                        const int col = 32 * b + r;
-                        dm[orow * H + col] = acc_m[b][i];
-                        dh[orow * H + col] = acc_h[b][i] + dir4[u][b];
-                    }
-                }
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------ K2
-template <int H>
-__global__ void __launch_bounds__(512) gru_bwd_dw_kernel(const float* __restrict__ dout, const float* __restrict__ m,
-                                                         const float* __restrict__ h, const float* __restrict__ mask,
-                                                         const float* __restrict__ saved, float* dW_ih, float* dW_hh,
-                                                         float* db_ih, float* db_hh, int64_t V) {
-    static_assert(H == 64, "tile ownership below is laid out for H = 64 (24 tiles over 8 waves)");
-    constexpr int LDG = 4 * H;            // G[row][ dar | daz | dan | dnh ]
-    constexpr int LDX = 2 * H;            // X[row][ m | h ]
-    constexpr int TILE_F = 32 * (LDG + LDX);
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* buf = reinterpret_cast<float*>(smem_raw);      // 2 x (G tile + X tile)
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int i = lane & 31, hi = lane >> 5;
-    // staging role: thread -> (row, 4 columns)
-    const int srow = tid >> 4, sc4 = (tid & 15) * 4;
-    // MFMA role: wave -> matrix, 32-row block of dW (input feature), three 32-col blocks (gate columns)
-    const int mat = wv >> 2, iblk = (wv >> 1) & 1, jbase = (wv & 1) * 3;
-
-    f32x16 acc[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
-    float colsum = 0.f;                                   // threads 0..255: column tid of G
-
-    const int64_t tiles = (V + 31) / 32;
-    auto stage = [&](int64_t t, float* G, float* X) {
-        const int64_t row = t * 32 + srow;
-        f32x4 dar = {0.f, 0.f, 0.f, 0.f}, daz = dar, dan = dar, dnh = dar, vm = dar, vh = dar;
-        if (row < V) {
-            const float mk = mask ? mask[row] : 1.0f;
-            const f32x4 v_do = *reinterpret_cast<const f32x4*>(dout + row * H + sc4);
-            vh = *reinterpret_cast<const f32x4*>(h + row * H + sc4);
-            vm = *reinterpret_cast<const f32x4*>(m + row * H + sc4);
-            const float* sv = saved + row * 4 * H + sc4;
-            gate_grads4(v_do, vh, *reinterpret_cast<const f32x4*>(sv), *reinterpret_cast<const f32x4*>(sv + H),
-                        *reinterpret_cast<const f32x4*>(sv + 2 * H), *reinterpret_cast<const f32x4*>(sv + 3 * H), mk, dar,
-                        daz, dan, dnh);
-        }
-        float* g = G + srow * LDG + sc4;
-        *reinterpret_cast<f32x4*>(g) = dar;
-        *reinterpret_cast<f32x4*>(g + H) = daz;
-        *reinterpret_cast<f32x4*>(g + 2 * H) = dan;
-        *reinterpret_cast<f32x4*>(g + 3 * H) = dnh;
-        float* x = X + srow * LDX + sc4;
-        *reinterpret_cast<f32x4*>(x) = vm;
-        *reinterpret_cast<f32x4*>(x + H) = vh;
-    };
-
-    int64_t t = blockIdx.x;
-    int cur = 0;
-    if (t < tiles) stage(t, buf, buf + 32 * LDG);
-    for (; t < tiles; t += gridDim.x) {
-        __syncthreads();                                   // tile `cur` is staged; the other buffer is free
-        float* G = buf + cur * TILE_F;
-        float* X = G + 32 * LDG;
-        if (t + gridDim.x < tiles) {
-            float* Gn = buf + (cur ^ 1) * TILE_F;
-            stage(t + gridDim.x, Gn, Gn + 32 * LDG);        // next tile's loads overlap this tile's MFMAs
-        }
-        // dW[mat][32*iblk + i][32*jb + j] += sum_rows X[row][mat*H + 32*iblk + i] * Gm[row][col(jb) + j]
-        const float* xa = X + hi * 16 * LDX + mat * H + 32 * iblk + i;
-        const float* gb = G + hi * 16 * LDG + i;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float av = xa[s * LDX];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int jb = jbase + j;                  // 0..5: gate = jb/2, column half = jb%2
-                int goff = (jb >> 1) * H + (jb & 1) * 32;  // dar | daz | dan
-                if (mat == 1 && (jb >> 1) == 2) goff += H; // W_hh's n-gate column takes dnh
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, gb[s * LDG + goff], acc[j], 0, 0, 0);
-            }
-        }
-        if (tid < 4 * H) {
-            float part = 0.f;
-#pragma unroll 8
-            for (int rr = 0; rr < 32; ++rr) part += G[rr * LDG + tid];
-            colsum += part;
-        }
-        cur ^= 1;
-    }
-    // flush: one float atomic per owned element
-    float* dW = mat == 0 ? dW_ih : dW_hh;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int col = 32 * (jbase + j) + i;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int row = 32 * iblk + acc_row(q, lane);
-            atomicAdd(dW + (int64_t)row * 3 * H + col, acc[j][q]);
-        }
-    }
-    if (tid < 4 * H && blockIdx.x < tiles) {
-        const int seg = tid / H, c = tid % H;              // 0 dar, 1 daz, 2 dan, 3 dnh
-        if (seg < 2) {
-            atomicAdd(db_ih + seg * H + c, colsum);
-            atomicAdd(db_hh + seg * H + c, colsum);
-        } else if (seg == 2) {
-            atomicAdd(db_ih + 2 * H + c, colsum);
-        } else {
-            atomicAdd(db_hh + 2 * H + c, colsum);
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------ fused
@@ -886,8 +663,8 @@ int launch_gru_bwd_fused64(const float* dout, const float* m, const float* h, co
     if (blocks > tiles) blocks = tiles;
     static const bool fp32_only = getenv("MPNN_GRU_MATH") && !strcmp(getenv("MPNN_GRU_MATH"), "fp32");
     static const int ablate = getenv("MPNN_GRU_BWD_ABLATE") ? atoi(getenv("MPNN_GRU_BWD_ABLATE")) : 0;
-    static const bool roles = getenv("MPNN_GRU_BWD_ROLES") != nullptr;      // A/B: the dW-waves/dx-waves arrangement
-    if (!fp32_only && !roles) {
+    static const bool uniform = getenv("MPNN_GRU_BWD_UNIFORM") != nullptr;  // A/B: all-waves-identical arrangement
+    if (!fp32_only && uniform) {
         static bool attr3 = false;
         if (!attr3) {
             (void)hipFuncSetAttribute((const void*)gru_bwd_uniform_kernel<H, true>,
