@@ -92,6 +92,13 @@ class MolGraph:
         return self._transpose
 
     @property
+    def edge_features(self):
+        """(E, ef) bond-feature row of every edge (materialised from the type table on first use)."""
+        if self.edge_feat is None:
+            self.edge_feat = self.type_feat[self.edge_type.to(torch.int64)].contiguous()
+        return self.edge_feat
+
+    @property
     def agg_weight(self):
         """Per-edge multiplier for AdjMsgAgg, or None when every adjacency value is exactly 1 (the
         kernel then skips the weight stream: 4*E fewer bytes and one load less per edge)."""

@@ -30,8 +30,8 @@ class AttEdgeNetwork(EdgeNetwork):
         h = g.node_view(afm)
         W_h, W_e = self.attn.weight[:, :self.nf], self.attn.weight[:, self.nf:]
         z_atom = h @ W_h.t() + self.attn.bias                 # (V, nf): destination-atom part
-        z_type = g.type_feat @ W_e.t()                        # (K, nf): bond-feature part
-        dst = g.edge_dst.to(torch.int64)
-        gate = self.attn_act(z_atom[dst] + z_type[g.edge_type.to(torch.int64)])
+        # per-edge logits: the atom part is broadcast along CSR rows (backward = the aggregator kernel),
+        # the bond part is a thin GEMM on the edge features (backward = a GEMM) -- no index_put backward
+        gate = self.attn_act(ops.expand_rows(z_atom, g) + g.edge_features @ W_e.t())
         values = ops.edge_message(h, emb.A, g, gate=gate)
         return EdgeMessages(values, g, h, emb.A0, row_gate=self.attn_act(z_atom))
