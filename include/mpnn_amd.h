@@ -83,6 +83,21 @@ int mpnn_edge_message_bwd_f32(const float* h, const float* A, const int32_t* src
                               const float* dmsg, float* dx, float* dA,
                               int64_t V, int64_t E, int K, int nf, int mf, void* stream);
 
+/* ------------------------------------------------------------------ edge tower ----- */
+/*
+ * The run of n_layers aliased Linear(L, L, bias=False) + ReLU blocks of the bond-feature tower
+ * replaces: mpnn_functions/message/edge_network.py:20 (`[Sequential(Linear, act)] * 50`), evaluated
+ * on the R distinct bond-feature rows of a batch.
+ *   x [R, L], W [L, L] (out, in)  ->  acts [(n_layers+1), R, L]: acts[0] = x, acts[l+1] = relu(acts[l] W^T)
+ * Backward of the chain for dout = d/d acts[n_layers]:
+ *   dys [n_layers, R, L] (gradient at each layer's pre-activation), dx [R, L];
+ *   the weight gradient is dW = sum_l dys[l]^T acts[l], one GEMM left to the caller.
+ * L <= 256.
+ */
+int mpnn_tower_chain_f32(const float* x, const float* W, float* acts, int R, int L, int n_layers, void* stream);
+int mpnn_tower_chain_bwd_f32(const float* dout, const float* W, const float* acts, float* dys, float* dx,
+                             int R, int L, int n_layers, void* stream);
+
 /* ------------------------------------------------------------------ aggregator ----- */
 /*
  * out[i, :] = sum_{e in row i} w[e] * msg[e, :]      (w == NULL: plain sum)

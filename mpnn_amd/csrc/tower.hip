@@ -1,0 +1,131 @@
+// The edge tower's 50 aliased layers as ONE kernel (forward) + ONE kernel (backward dx chain).
+//
+// Reference: EdgeNetwork.__init__ builds `[Sequential(Linear(L, L, bias=False), act)] * 50`
+// (mpnn_functions/message/edge_network.py:20): fifty applications of the SAME L x L matrix.  With bond
+// features de-duplicated the tower runs on R = K+1 rows (R ~ 5), so each layer is a 5 x 256 x 256
+// product: as separate library GEMM + ReLU launches that is ~100 launches of ~9 us of pure latency per
+// pass.  Here the shared matrix is loaded ONCE into registers -- 1024 threads x 64 weights = the whole
+// 256 x 256 matrix -- and the chain runs inside one block per 8 rows with two barriers per layer.
+//
+//   forward   acts[0] = x ;  acts[l+1] = relu(acts[l] W^T)                 (all activations kept: backward)
+//   backward  g_n = dout ;   dy_l = g_{l+1} * (acts[l+1] > 0) ;  g_l = dy_l W     (dys kept)
+//             dW = sum_l dy_l^T acts[l] is ONE (n*R x L)^T (n*R x L) GEMM left to the caller.
+//
+// Thread (o, q) = (tid >> 2, tid & 3): output (forward) / input (backward) feature o, quarter q of the
+// contraction; the 4 quarters of one feature sit in adjacent lanes and are combined with two shuffles.
+// The running activation lives in LDS as [row][quarter][64+4] so the four quarter reads of a wave hit
+// four different bank groups (broadcast within a quarter).
+#include "common.h"
+
+namespace mpnn {
+
+constexpr int kTowerRows = 8;       // rows per block
+constexpr int kTowerQ = 68;         // padded quarter stride (floats)
+constexpr int kTowerLd = 4 * kTowerQ;
+
+__device__ __forceinline__ int tower_slot(int i) { return (i >> 6) * kTowerQ + (i & 63); }
+
+template <bool BWD>
+__global__ void __launch_bounds__(1024) tower_chain_kernel(const float* __restrict__ xin,   // fwd: x [R,L]; bwd: dout [R,L]
+                                                           const float* __restrict__ W,     // [L,L] (out, in)
+                                                           float* __restrict__ acts,        // [(n+1),R,L] (fwd: written; bwd: read)
+                                                           float* __restrict__ dys,         // bwd: [n,R,L]
+                                                           float* __restrict__ dx0,         // bwd: [R,L]
+                                                           int R, int L, int n) {
+    __shared__ __attribute__((aligned(16))) float xs[2][kTowerRows][kTowerLd];
+    const int tid = threadIdx.x, q = tid & 3, o = tid >> 2;
+    const int r0 = blockIdx.x * kTowerRows;
+    const int nr = min(kTowerRows, R - r0);
+
+    // this thread's 64 weights: forward W[o][64q + j]; backward W[64q + j][o]
+    float w[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        const int k = 64 * q + j;
+        float v = 0.f;
+        if (o < L && k < L) v = BWD ? W[(int64_t)k * L + o] : W[(int64_t)o * L + k];
+        w[j] = v;
+    }
+    // stage the chain's input rows (zero-padded to 256 columns / 8 rows)
+    for (int idx = tid; idx < kTowerRows * 256; idx += 1024) {
+        const int r = idx >> 8, i = idx & 255;
+        float v = 0.f;
+        if (r < nr && i < L) v = xin[(int64_t)(r0 + r) * L + i];
+        xs[0][r][tower_slot(i)] = v;
+        if (!BWD && r < nr && i < L) acts[(int64_t)(r0 + r) * L + i] = v;
+    }
+    int cur = 0;
+    for (int l = 0; l < n; ++l) {
+        const int layer = BWD ? n - 1 - l : l;
+        if (BWD) {
+            // dy = g * (acts[layer+1] > 0), in place in LDS, and kept for dW
+            __syncthreads();
+            for (int idx = tid; idx < kTowerRows * 256; idx += 1024) {
+                const int r = idx >> 8, i = idx & 255;
+                if (r < nr && i < L) {
+                    const int64_t at = ((int64_t)(layer + 1) * R + r0 + r) * L + i;
+                    const float dy = acts[at] > 0.f ? xs[cur][r][tower_slot(i)] : 0.f;
+                    xs[cur][r][tower_slot(i)] = dy;
+                    dys[((int64_t)layer * R + r0 + r) * L + i] = dy;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kTowerRows; ++r) {
+            const float* xr = &xs[cur][r][q * kTowerQ];
+            float acc = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + 4 * jj);
+                acc += w[4 * jj + 0] * xv.x;
+                acc += w[4 * jj + 1] * xv.y;
+                acc += w[4 * jj + 2] * xv.z;
+                acc += w[4 * jj + 3] * xv.w;
+            }
+            acc += __shfl_xor(acc, 1);
+            acc += __shfl_xor(acc, 2);
+            if (q == 0) {
+                const float y = BWD ? acc : fmaxf(acc, 0.f);
+                xs[cur ^ 1][r][tower_slot(o)] = (o < L) ? y : 0.f;
+                if (!BWD && r < nr && o < L) acts[((int64_t)(layer + 1) * R + r0 + r) * L + o] = y;
+            }
+        }
+        cur ^= 1;
+    }
+    if (BWD) {
+        __syncthreads();
+        for (int idx = tid; idx < kTowerRows * 256; idx += 1024) {
+            const int r = idx >> 8, i = idx & 255;
+            if (r < nr && i < L) dx0[(int64_t)(r0 + r) * L + i] = xs[cur][r][tower_slot(i)];
+        }
+    }
+}
+
+}  // namespace mpnn
+
+using namespace mpnn;
+
+extern "C" int mpnn_tower_chain_f32(const float* x, const float* W, float* acts, int R, int L, int n_layers,
+                                    void* stream) {
+    MPNN_REQUIRE(R >= 0 && n_layers >= 0, "mpnn_tower_chain_f32: negative size");
+    MPNN_REQUIRE(L > 0 && L <= 256, "mpnn_tower_chain_f32: width L=%d unsupported (1..256)", L);
+    if (R == 0) return MPNN_OK;
+    MPNN_REQUIRE(x && W && acts, "mpnn_tower_chain_f32: NULL buffer");
+    const int blocks = (R + kTowerRows - 1) / kTowerRows;
+    hipLaunchKernelGGL((tower_chain_kernel<false>), dim3(blocks), dim3(1024), 0, (hipStream_t)stream, x, W, acts,
+                       (float*)nullptr, (float*)nullptr, R, L, n_layers);
+    return launch_status("mpnn_tower_chain_f32");
+}
+
+extern "C" int mpnn_tower_chain_bwd_f32(const float* dout, const float* W, const float* acts, float* dys, float* dx,
+                                        int R, int L, int n_layers, void* stream) {
+    MPNN_REQUIRE(R >= 0 && n_layers >= 0, "mpnn_tower_chain_bwd_f32: negative size");
+    MPNN_REQUIRE(L > 0 && L <= 256, "mpnn_tower_chain_bwd_f32: width L=%d unsupported (1..256)", L);
+    if (R == 0) return MPNN_OK;
+    MPNN_REQUIRE(dout && W && acts && dys && dx, "mpnn_tower_chain_bwd_f32: NULL buffer");
+    const int blocks = (R + kTowerRows - 1) / kTowerRows;
+    hipLaunchKernelGGL((tower_chain_kernel<true>), dim3(blocks), dim3(1024), 0, (hipStream_t)stream, dout, W,
+                       const_cast<float*>(acts), dys, dx, R, L, n_layers);
+    return launch_status("mpnn_tower_chain_bwd_f32");
+}

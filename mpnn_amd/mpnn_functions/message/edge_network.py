@@ -71,9 +71,30 @@ class EdgeNetwork(nn.Module):
             return g
         return MolGraph.from_dense(None, bfm)
 
+    def _run_tower(self, rows):
+        """edge_map(rows); the run of aliased `Sequential(Linear(L, L, bias=False), ReLU)` blocks (the SAME
+        module object repeated, edge_network.py:20) goes through the fused chain kernel."""
+        mods = list(self.edge_map)
+        x, i = rows, 0
+        while i < len(mods):
+            m = mods[i]
+            fusable = (isinstance(m, nn.Sequential) and len(m) == 2 and isinstance(m[0], nn.Linear)
+                       and m[0].bias is None and type(m[1]) is nn.ReLU and x.is_cuda
+                       and m[0].in_features == m[0].out_features <= 256)
+            if fusable:
+                n = 1
+                while i + n < len(mods) and mods[i + n] is m:
+                    n += 1
+                x = ops.tower_chain(x, m[0].weight, n)
+                i += n
+            else:
+                x = m(x)
+                i += 1
+        return x
+
     def _edge_matrices(self, graph):
         rows = torch.cat([graph.type_feat.new_zeros(1, self.ef), graph.type_feat], dim=0)
-        table = self.edge_map(rows).view(-1, self.mf, self.nf)
+        table = self._run_tower(rows).view(-1, self.mf, self.nf)
         return table[1:], table[0]
 
     def _precompute_edge_embed(self, bfm):

@@ -290,6 +290,40 @@ def expand_rows(x, graph):
     return _ExpandRows.apply(x, graph)
 
 
+class TowerChain(torch.autograd.Function):
+    """n applications of relu(x W^T) with ONE shared W (the tower's 50 aliased layers) in one kernel."""
+
+    @staticmethod
+    def forward(ctx, x, W, n):
+        lib = _lib.load()
+        x, W = x.contiguous(), W.contiguous()
+        R, L = int(x.shape[0]), int(x.shape[1])
+        acts = _empty((n + 1, R, L), x)
+        _lib.check(lib.mpnn_tower_chain_f32(_lib.fptr(x), _lib.fptr(W), _lib.fptr(acts), R, L, n, _lib.stream()),
+                   "mpnn_tower_chain_f32")
+        ctx.save_for_backward(acts, W)
+        ctx.n = n
+        return acts[n]
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        acts, W = ctx.saved_tensors
+        n = ctx.n
+        R, L = int(acts.shape[1]), int(acts.shape[2])
+        dys = _empty((n, R, L), acts)
+        dx = _empty((R, L), acts)
+        _lib.check(lib.mpnn_tower_chain_bwd_f32(_lib.fptr(dout.contiguous()), _lib.fptr(W), _lib.fptr(acts),
+                                                _lib.fptr(dys), _lib.fptr(dx), R, L, n, _lib.stream()),
+                   "mpnn_tower_chain_bwd_f32")
+        dW = dys.view(n * R, L).t() @ acts[:n].reshape(n * R, L) if ctx.needs_input_grad[1] else None
+        return dx, dW, None
+
+
+def tower_chain(x, W, n):
+    return TowerChain.apply(x, W, n)
+
+
 def edge_message(h, A, graph, gate=None):
     return EdgeMessage.apply(h, A, gate, graph)
 

@@ -217,3 +217,27 @@ def test_gru_random(dev, V, H):
                                 ("gru_cell.weight_ih", "gru_cell.weight_hh", "gru_cell.bias_ih", "gru_cell.bias_hh")),
                                 False)
     assert max_err(out.cpu(), ref) < TOL
+
+
+# ----------------------------------------------------------------------------- edge tower chain
+@pytest.mark.parametrize("R,L,n", [(5, 256, 50), (1, 16, 50), (9, 49, 50), (21, 200, 7), (64, 256, 3)])
+def test_tower_chain(dev, R, L, n):
+    """The 50 aliased Linear(L,L,bias=False)+ReLU layers in one kernel vs the layer-by-layer product,
+    forward and both gradients (float64 reference)."""
+    from mpnn_amd import ops
+    g = torch.Generator().manual_seed(R * 1000 + L + n)
+    W = (torch.rand(L, L, generator=g) * 2 - 1) * (1.9 / L) ** 0.5 * 1.7      # keeps activations O(1) over 50 layers
+    x = torch.rand(R, L, generator=g)
+    cot = torch.rand(R, L, generator=g) - 0.5
+    xd, Wd = x.double().requires_grad_(True), W.double().requires_grad_(True)
+    y = xd
+    for _ in range(n):
+        y = torch.relu(y @ Wd.t())
+    gx, gW = torch.autograd.grad((y * cot.double()).sum(), [xd, Wd])
+    xg, Wg = x.to(dev).requires_grad_(True), W.to(dev).requires_grad_(True)
+    out = ops.tower_chain(xg, Wg, n)
+    hx, hW = torch.autograd.grad((out * cot.to(dev)).sum(), [xg, Wg])
+    scale = max(1.0, float(y.abs().max()))
+    assert max_err(out.cpu(), y) < 2e-5 * scale
+    assert max_err(hx.cpu(), gx) < 2e-5 * max(1.0, float(gx.abs().max()))
+    assert max_err(hW.cpu(), gW) < 2e-5 * max(1.0, float(gW.abs().max()))
