@@ -29,6 +29,8 @@ _SIGNATURES = {
     "mpnn_edge_message_f32": (ctypes.c_int, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, i64, i64, i32, i32, i32, c_v]),
     "mpnn_edge_message_bwd_f32": (ctypes.c_int, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f,
                                                  i64, i64, i32, i32, i32, c_v]),
+    "mpnn_edge_message_agg_bwd_da_f32": (ctypes.c_int, [c_f, c_f, c_i, c_i, c_f, c_i, c_i, c_f, c_f,
+                                                        i64, i64, i32, i32, i32, c_v]),
     "mpnn_tower_chain_f32": (ctypes.c_int, [c_f, c_f, c_f, i32, i32, i32, c_v]),
     "mpnn_tower_chain_bwd_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, i32, i32, i32, c_v]),
     "mpnn_segsum_f32": (ctypes.c_int, [c_f, c_i, c_f, c_f, i64, i32, c_v]),

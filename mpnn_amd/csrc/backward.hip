@@ -306,12 +306,16 @@ __global__ void __launch_bounds__(256) tn_accumulate_kernel(const float* __restr
 // and therefore reads every dmsg / x element exactly once.  Waves take 32-edge tiles of the
 // type-sorted list on their own; per type the block's 8 partial tiles are combined in LDS (ds_add)
 // and leave through one float-atomic flush per block.
+// With `dst` given the left operand is NOT a materialised dmsg: row e is  w[e] * dagg[dst[e]]  (the
+// aggregator's backward folded into this kernel, saving the E x F write + read).
 __global__ void __launch_bounds__(512) edge_dA_direct64_kernel(const float* __restrict__ dmsg,
                                                                const float* __restrict__ h,
                                                                const int32_t* __restrict__ src,
                                                                const int32_t* __restrict__ order,
                                                                const int32_t* __restrict__ type_ptr,
-                                                               const float* __restrict__ gate, float* dA, int K) {
+                                                               const float* __restrict__ gate, float* dA, int K,
+                                                               const int32_t* __restrict__ dst,
+                                                               const float* __restrict__ w) {
     constexpr int F = 64;
     __shared__ float red[F * F];                        // block-level partial of the current type
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -337,6 +341,8 @@ __global__ void __launch_bounds__(512) edge_dA_direct64_kernel(const float* __re
             const bool ok = pos < te;
             const int e_l = ok ? order[pos] : order[tb + 32 * t];
             const int s_l = src[e_l];
+            const int d_l = dst ? dst[e_l] : e_l;        // row of the left operand
+            const float w_l = (dst && w) ? w[e_l] : 1.0f;
             const int rows = min(32, te - tb - 32 * t);
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
@@ -345,10 +351,18 @@ __global__ void __launch_bounds__(512) edge_dA_direct64_kernel(const float* __re
                 const int s_lo = __builtin_amdgcn_readlane(s_l, s), s_hi = __builtin_amdgcn_readlane(s_l, 16 + s);
                 const int e_r = hi ? e_hi : e_lo;
                 const int s_r = hi ? s_hi : s_lo;
+                const int d_lo = __builtin_amdgcn_readlane(d_l, s), d_hi = __builtin_amdgcn_readlane(d_l, 16 + s);
+                const int d_r = hi ? d_hi : d_lo;
                 const bool live = (hi ? 16 + s : s) < rows;
-                const float* pa = dmsg + (int64_t)e_r * F + i;
+                const float* pa = dmsg + (int64_t)d_r * F + i;
                 const float* pb = h + (int64_t)s_r * F + i;
                 float a0 = pa[0], a1 = pa[32];
+                if (dst && w) {
+                    const float w_lo = __builtin_amdgcn_readlane(w_l, s), w_hi = __builtin_amdgcn_readlane(w_l, 16 + s);
+                    const float w_r = hi ? w_hi : w_lo;
+                    a0 *= w_r;
+                    a1 *= w_r;
+                }
                 float b0 = pb[0], b1 = pb[32];
                 if (gate) {
                     const float* pg = gate + (int64_t)e_r * F + i;
@@ -452,7 +466,7 @@ extern "C" int mpnn_edge_message_bwd_f32(const float* h, const float* A, const i
         const int64_t need = ceil_div(ceil_div(E, 32) + K, 8);
         if (gx > need) gx = need;
         hipLaunchKernelGGL(edge_dA_direct64_kernel, dim3((unsigned)gx), dim3(512), 0, s, dmsg, h, src, order, type_ptr,
-                           gate, dA, K);
+                           gate, dA, K, (const int32_t*)nullptr, (const float*)nullptr);
         rc = launch_status("mpnn_edge_message_bwd_f32(dA direct)");
     } else if (dA) {
         const int pairs = (int)(ceil_div(mf, 64) * ceil_div(nf, 64));
@@ -511,4 +525,22 @@ extern "C" int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const 
                        6 * H, 3 * H, (const int32_t*)nullptr, (const int32_t*)nullptr, (const float*)nullptr,
                        (const int32_t*)nullptr, 1, dW_hh, db_hh, V);
     return launch_status("mpnn_gru_update_bwd_f32(dW)");
+}
+
+extern "C" int mpnn_edge_message_agg_bwd_da_f32(const float* dagg, const float* h, const int32_t* src,
+                                                const int32_t* dst, const float* w, const int32_t* order,
+                                                const int32_t* type_ptr, const float* gate, float* dA, int64_t V,
+                                                int64_t E, int K, int nf, int mf, void* stream) {
+    MPNN_REQUIRE(E >= 0 && V >= 0 && K >= 0, "mpnn_edge_message_agg_bwd_da_f32: negative size");
+    MPNN_REQUIRE(nf == 64 && mf == 64 && K <= 64,
+                 "mpnn_edge_message_agg_bwd_da_f32: only nf = mf = 64, K <= 64 (got %d, %d, %d)", nf, mf, K);
+    if (E == 0) return MPNN_OK;
+    MPNN_REQUIRE(dagg && h && src && dst && order && type_ptr && dA && K > 0,
+                 "mpnn_edge_message_agg_bwd_da_f32: NULL buffer");
+    int64_t gx = 512;
+    const int64_t need = ceil_div(ceil_div(E, 32) + K, 8);
+    if (gx > need) gx = need;
+    hipLaunchKernelGGL(edge_dA_direct64_kernel, dim3((unsigned)gx), dim3(512), 0, (hipStream_t)stream, dagg, h, src,
+                       order, type_ptr, gate, dA, K, dst, w);
+    return launch_status("mpnn_edge_message_agg_bwd_da_f32");
 }

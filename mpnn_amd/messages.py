@@ -12,12 +12,25 @@ from . import ops
 
 
 class EdgeMessages:
-    def __init__(self, values, graph, h, A0=None, row_gate=None):
-        self.values = values      # (E, mf) message of each member pair, destination-sorted
+    def __init__(self, values, graph, h, A0=None, row_gate=None, recipe=None):
+        self._values = values     # (E, mf) message of each member pair, destination-sorted (None = lazy)
         self.graph = graph
         self.h = h                # (V, nf) node features the messages were computed from
         self.A0 = A0              # (mf, nf) matrix of a zero bond-feature row, or None (== 0)
         self.row_gate = row_gate  # (V, nf) AttEdgeNetwork gate of atom i towards a zero-feature pair
+        self.recipe = recipe      # (A, gate): how to compute `values`; lets AdjMsgAgg run message+sum as one
+                                  # autograd node (ops.message_aggregate) whose backward skips the (E, mf) gradient
+
+    @property
+    def values(self):
+        if self._values is None:
+            A, gate = self.recipe
+            self._values = ops.edge_message(self.h, A, self.graph, gate=gate)
+        return self._values
+
+    @property
+    def num_features(self):
+        return int(self.recipe[0].shape[1]) if self._values is None else int(self._values.shape[-1])
 
     @property
     def shape(self):
@@ -25,13 +38,13 @@ class EdgeMessages:
         if g.dense_shape is None:
             raise RuntimeError("compact batches have no dense (B,N,N,mf) shape")
         B, N = g.dense_shape
-        return (B, N, N, self.values.shape[-1])
+        return (B, N, N, self.num_features)
 
     def nonedge_sum(self):
         """(V, mf): sum over the NON-member pairs (i, j) of molecule(i) of their message.
         = A0 . (gate_i0 * (S_mol(i) - sum_{e in row i} h_src(e)))   (padded atoms have h = 0)."""
         g = self.graph
-        mf = self.values.shape[-1]
+        mf = self.num_features
         if self.A0 is None:
             return torch.zeros(g.num_nodes, mf, device=self.h.device)
         rest = ops.molecule_sum(self.h, g)[g.node_graph] - ops.neighbour_sum(self.h, g)

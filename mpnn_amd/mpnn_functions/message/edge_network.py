@@ -104,7 +104,8 @@ class EdgeNetwork(nn.Module):
 
     # -- forward -------------------------------------------------------------------------
     def _pair_messages(self, h, emb):
-        return EdgeMessages(ops.edge_message(h, emb.A, emb.graph), emb.graph, h, emb.A0)
+        # lazy: the aggregator decides whether to materialise the rows or to run message+sum as one node
+        return EdgeMessages(None, emb.graph, h, emb.A0, recipe=(emb.A, None))
 
     def forward(self, afm, bfm, reuse_graph_tensors=False):
         if not reuse_graph_tensors or self.edge_embed is None:

@@ -18,6 +18,10 @@ class AdjMsgAgg(nn.Module):
     def forward(self, messages, adj):
         if isinstance(messages, EdgeMessages):
             g = messages.graph
-            return g.node_unview(ops.segsum(messages.values, g.row_ptr, adjacency_multiplier(messages, adj)))
+            w = adjacency_multiplier(messages, adj)
+            if messages._values is None:          # lazy messages: message + sum as one autograd node
+                A, gate = messages.recipe
+                return g.node_unview(ops.message_aggregate(messages.h, A, g, w, gate))
+            return g.node_unview(ops.segsum(messages.values, g.row_ptr, w))
         rows, row_ptr, (B, N) = dense_rows(messages, adj)
         return ops.segsum(rows, row_ptr, adj.reshape(-1).contiguous().float()).view(B, N, -1)

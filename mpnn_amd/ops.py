@@ -218,6 +218,58 @@ class EdgeMessage(torch.autograd.Function):
         return dh, (dA if ctx.needs_input_grad[1] else None), dgate, None
 
 
+class MessageAggregate(torch.autograd.Function):
+    """out[i] = sum_{e in row i} w[e] * (A[type e] . (gate[e] * h[src e])) -- the edge message followed by
+    the adjacency-weighted sum as ONE autograd node.  Forward launches the same two kernels as the
+    separate ops (message, then the segmented-sum aggregator); the node exists for the backward: when no
+    gradient is wanted for h / gate, dA is accumulated straight from dout[dst(e)] and the (E, mf) message
+    gradient is never written or read."""
+
+    @staticmethod
+    def forward(ctx, h, A, gate, w, graph):
+        h, A = h.contiguous(), A.contiguous()
+        gate = gate.contiguous() if gate is not None else None
+        ctx.graph = graph
+        ctx.save_for_backward(h, A, gate, w)
+        msg = edge_message_raw(h, A, graph, gate)
+        return segsum_raw(msg, graph.row_ptr, w, graph.num_nodes)
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, A, gate, w = ctx.saved_tensors
+        g = ctx.graph
+        dout = dout.contiguous()
+        need_dx = ctx.needs_input_grad[0] or (gate is not None and ctx.needs_input_grad[2])
+        K, mf, nf = (int(s) for s in A.shape)
+        if not need_dx and mf == 64 and nf == 64 and K <= 64:
+            if not ctx.needs_input_grad[1]:
+                return None, None, None, None, None
+            lib = _lib.load()
+            dA = torch.zeros_like(A)
+            if g.num_edges:
+                _lib.check(lib.mpnn_edge_message_agg_bwd_da_f32(
+                    _lib.fptr(dout), _lib.fptr(h), _lib.iptr(g.col_idx), _lib.iptr(g.edge_dst), _lib.fptr(w),
+                    _lib.iptr(g.order), _lib.iptr(g.type_ptr), _lib.fptr(gate), _lib.fptr(dA), g.num_nodes,
+                    g.num_edges, K, nf, mf, _lib.stream()), "mpnn_edge_message_agg_bwd_da_f32")
+            return None, dA, None, None, None
+        dmsg = segsum_bwd_raw(dout, g.row_ptr, w, g.num_edges)
+        dx, dA = edge_message_bwd_raw(h, A, g, gate, dmsg, need_dx=need_dx, need_dA=ctx.needs_input_grad[1])
+        if not need_dx:
+            return None, dA, None, None, None
+        t_row_ptr, t_eid = g.transpose
+        dgate = None
+        if gate is not None:
+            if ctx.needs_input_grad[2]:
+                dgate = dx * h[g.col_idx.to(torch.int64)]
+            dx = dx * gate
+        dh = segsum_gather_raw(dx, t_row_ptr, t_eid, None, g.num_nodes) if ctx.needs_input_grad[0] else None
+        return dh, dA, dgate, None, None
+
+
+def message_aggregate(h, A, graph, w=None, gate=None):
+    return MessageAggregate.apply(h, A, gate, w, graph)
+
+
 class GRUUpdateFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, m, h, mask, W_ih, W_hh, b_ih, b_hh, grad_mode):
