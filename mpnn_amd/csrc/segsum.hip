@@ -25,6 +25,9 @@ struct Row<4> {
     __device__ __forceinline__ void zero() { v = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const f32x4*>(p); }
     __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<f32x4*>(p) = v; }
+    // streamed once: keep the rows out of the way of reused data in L2 / Infinity Cache
+    __device__ __forceinline__ void load_nt(const float* p) { v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
+    __device__ __forceinline__ void store_nt(float* p) const { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); }
     __device__ __forceinline__ void fma(const Row& o, float s) { v += o.v * s; }
     __device__ __forceinline__ void add(const Row& o) { v += o.v; }
     __device__ __forceinline__ void scale(float s) { v *= s; }
@@ -35,6 +38,8 @@ struct Row<1> {
     __device__ __forceinline__ void zero() { v = 0.f; }
     __device__ __forceinline__ void load(const float* p) { v = *p; }
     __device__ __forceinline__ void store(float* p) const { *p = v; }
+    __device__ __forceinline__ void load_nt(const float* p) { v = __builtin_nontemporal_load(p); }
+    __device__ __forceinline__ void store_nt(float* p) const { __builtin_nontemporal_store(v, p); }
     __device__ __forceinline__ void fma(const Row& o, float s) { v += o.v * s; }
     __device__ __forceinline__ void add(const Row& o) { v += o.v; }
     __device__ __forceinline__ void scale(float s) { v *= s; }
@@ -90,7 +95,7 @@ __global__ void __launch_bounds__(256) segsum_kernel(const float* __restrict__ m
 // Variant 2: each lane group reduces TWO adjacent atoms per pass (their rows are one contiguous
 // span [e0,e2)), up to 8 row loads in flight per group, and the next pass's three row_ptr values are
 // requested before the current rows are summed (one dependent round trip per pass instead of two).
-template <int VEC, int LPR>
+template <int VEC, int LPR, bool NT>
 __global__ void __launch_bounds__(256) segsum_pair_kernel(const float* __restrict__ msg,
                                                           const int32_t* __restrict__ row_ptr,
                                                           const float* __restrict__ w, float* __restrict__ out,
@@ -122,14 +127,14 @@ __global__ void __launch_bounds__(256) segsum_pair_kernel(const float* __restric
                 ra0.zero(); ra1.zero(); ra2.zero(); ra3.zero();
                 rb0.zero(); rb1.zero(); rb2.zero(); rb3.zero();
                 float wa0 = 0.f, wa1 = 0.f, wa2 = 0.f, wa3 = 0.f, wb0 = 0.f, wb1 = 0.f, wb2 = 0.f, wb3 = 0.f;
-                if (na > 0) ra0.load(msg + (int64_t)(a + 0) * F + c);
-                if (na > 1) ra1.load(msg + (int64_t)(a + 1) * F + c);
-                if (na > 2) ra2.load(msg + (int64_t)(a + 2) * F + c);
-                if (na > 3) ra3.load(msg + (int64_t)(a + 3) * F + c);
-                if (nb > 0) rb0.load(msg + (int64_t)(b + 0) * F + c);
-                if (nb > 1) rb1.load(msg + (int64_t)(b + 1) * F + c);
-                if (nb > 2) rb2.load(msg + (int64_t)(b + 2) * F + c);
-                if (nb > 3) rb3.load(msg + (int64_t)(b + 3) * F + c);
+                if (na > 0) { if (NT) ra0.load_nt(msg + (int64_t)(a + 0) * F + c); else ra0.load(msg + (int64_t)(a + 0) * F + c); }
+                if (na > 1) { if (NT) ra1.load_nt(msg + (int64_t)(a + 1) * F + c); else ra1.load(msg + (int64_t)(a + 1) * F + c); }
+                if (na > 2) { if (NT) ra2.load_nt(msg + (int64_t)(a + 2) * F + c); else ra2.load(msg + (int64_t)(a + 2) * F + c); }
+                if (na > 3) { if (NT) ra3.load_nt(msg + (int64_t)(a + 3) * F + c); else ra3.load(msg + (int64_t)(a + 3) * F + c); }
+                if (nb > 0) { if (NT) rb0.load_nt(msg + (int64_t)(b + 0) * F + c); else rb0.load(msg + (int64_t)(b + 0) * F + c); }
+                if (nb > 1) { if (NT) rb1.load_nt(msg + (int64_t)(b + 1) * F + c); else rb1.load(msg + (int64_t)(b + 1) * F + c); }
+                if (nb > 2) { if (NT) rb2.load_nt(msg + (int64_t)(b + 2) * F + c); else rb2.load(msg + (int64_t)(b + 2) * F + c); }
+                if (nb > 3) { if (NT) rb3.load_nt(msg + (int64_t)(b + 3) * F + c); else rb3.load(msg + (int64_t)(b + 3) * F + c); }
                 if (w) {
                     if (na > 0) wa0 = w[a];
                     if (na > 1) wa1 = w[a + 1];
@@ -148,8 +153,13 @@ __global__ void __launch_bounds__(256) segsum_pair_kernel(const float* __restric
                 a += 4;
                 b += 4;
             }
-            accA.store(out + i * F + c);
-            if (i + 1 < V) accB.store(out + (i + 1) * F + c);
+            if (NT) {
+                accA.store_nt(out + i * F + c);
+                if (i + 1 < V) accB.store_nt(out + (i + 1) * F + c);
+            } else {
+                accA.store(out + i * F + c);
+                if (i + 1 < V) accB.store(out + (i + 1) * F + c);
+            }
         }
         e0 = n0;
         e1 = n1;
@@ -201,14 +211,20 @@ static int launch_segsum(const float* msg, const int32_t* row_ptr, const int32_t
     const int lpr = pick_lpr(F, v4 ? 4 : 1);
     const dim3 grid(grid_for(V, lpr)), block(256);
     static const int variant = getenv("MPNN_SEGSUM_VARIANT") ? atoi(getenv("MPNN_SEGSUM_VARIANT")) : 2;   // 1 = one atom per lane group (A/B)
-    if (!GATHER && variant == 2 && v4 && lpr * 4 >= F) {
+    if (!GATHER && (variant == 2 || variant == 3) && v4 && lpr * 4 >= F) {
         const dim3 g2(grid_for((V + 1) / 2, lpr));
+#define MPNN_PAIR(LPR)                                                                                              \
+    if (variant == 3)                                                                                               \
+        hipLaunchKernelGGL((segsum_pair_kernel<4, LPR, true>), g2, block, 0, s, msg, row_ptr, w, out, V, F);        \
+    else                                                                                                            \
+        hipLaunchKernelGGL((segsum_pair_kernel<4, LPR, false>), g2, block, 0, s, msg, row_ptr, w, out, V, F);
         switch (lpr) {
-            case 16: hipLaunchKernelGGL((segsum_pair_kernel<4, 16>), g2, block, 0, s, msg, row_ptr, w, out, V, F); break;
-            case 32: hipLaunchKernelGGL((segsum_pair_kernel<4, 32>), g2, block, 0, s, msg, row_ptr, w, out, V, F); break;
-            case 64: hipLaunchKernelGGL((segsum_pair_kernel<4, 64>), g2, block, 0, s, msg, row_ptr, w, out, V, F); break;
-            default: hipLaunchKernelGGL((segsum_pair_kernel<4, 8>), g2, block, 0, s, msg, row_ptr, w, out, V, F); break;
+            case 16: MPNN_PAIR(16) break;
+            case 32: MPNN_PAIR(32) break;
+            case 64: MPNN_PAIR(64) break;
+            default: MPNN_PAIR(8) break;
         }
+#undef MPNN_PAIR
         return launch_status("mpnn_segsum(pair)");
     }
 #define MPNN_SEGSUM_CASE(VEC, LPR)                                                                              \
