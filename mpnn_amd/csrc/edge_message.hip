@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(512) edge_message_resident_kernel(
 #pragma unroll
                     for (int n = 0; n < NB; ++n) {
                         const int col = 32 * n + r;
-                        if (col < mf) msg[(int64_t)e_row * mf + col] = acc[n][i];
+                        if (col < mf) __builtin_nontemporal_store(acc[n][i], msg + (int64_t)e_row * mf + col);   // write-once stream
                     }
                 }
             }

@@ -167,13 +167,13 @@ __global__ void __launch_bounds__(64 * NW) gru_update_split_kernel(
                     const float ng = tanh_fast(acc_ni[s][i] + bni[s] + rg * nh) * mk;
                     const float o = ((1.0f - zg) * ng + zg * hv4[u][s]) * mk;
                     if (row < V) {
-                        out[row * H + col] = o;
-                        if (saved) {
+                        __builtin_nontemporal_store(o, out + row * H + col);
+                        if (saved) {                     // 16*H bytes per atom, read back once by the backward
                             float* sv = saved + row * 4 * H + col;
-                            sv[0] = rg;
-                            sv[H] = zg;
-                            sv[2 * H] = ng;
-                            sv[3 * H] = nh;
+                            __builtin_nontemporal_store(rg, sv);
+                            __builtin_nontemporal_store(zg, sv + H);
+                            __builtin_nontemporal_store(ng, sv + 2 * H);
+                            __builtin_nontemporal_store(nh, sv + 3 * H);
                         }
                     }
                 }

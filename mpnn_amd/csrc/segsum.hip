@@ -7,7 +7,8 @@
 //
 // Mapping: a row of F floats is covered by LPR lanes x VEC floats (16 lanes x float4 at
 // F=64), so one wave64 reduces 64/LPR destination atoms side by side (the default
-// segsum_pair_kernel: two adjacent atoms per lane group per pass, 5.42 TB/s on c2 vs 5.1).  Edges of one atom
+// segsum_pair_kernel: two adjacent atoms per lane group per pass, 5.42 TB/s on c2 vs 5.1;
+// with nontemporal loads/stores -- every row is touched exactly once -- 5.93 TB/s).  Edges of one atom
 // are contiguous (CSR by destination) and atoms of one wave are adjacent, so the wave's
 // loads walk one contiguous span of `msg`.  The edge loop runs in predicated batches of 4 rows
 // (all loads of a batch in flight together) with the adds kept in edge order: deterministic.
@@ -210,7 +211,7 @@ static int launch_segsum(const float* msg, const int32_t* row_ptr, const int32_t
     const bool v4 = (F % 4 == 0) && ((reinterpret_cast<uintptr_t>(msg) | reinterpret_cast<uintptr_t>(out)) % 16 == 0);
     const int lpr = pick_lpr(F, v4 ? 4 : 1);
     const dim3 grid(grid_for(V, lpr)), block(256);
-    static const int variant = getenv("MPNN_SEGSUM_VARIANT") ? atoi(getenv("MPNN_SEGSUM_VARIANT")) : 2;   // 1 = one atom per lane group (A/B)
+    static const int variant = getenv("MPNN_SEGSUM_VARIANT") ? atoi(getenv("MPNN_SEGSUM_VARIANT")) : 3;   // 1 = one atom per lane group, 2 = pair kernel with cached loads/stores (A/B)
     if (!GATHER && (variant == 2 || variant == 3) && v4 && lpr * 4 >= F) {
         const dim3 g2(grid_for((V + 1) / 2, lpr));
 #define MPNN_PAIR(LPR)                                                                                              \
