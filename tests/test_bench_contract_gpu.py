@@ -1,0 +1,36 @@
+"""bench.py prints exactly ONE JSON line with the fields the driver's contract names."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def test_bench_contract_tiny_workload():
+    env = dict(os.environ)
+    env["MPNN_CPU_THREADS"] = "4"
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--workload", "tiny", "--steps", "2", "--warmup",
+                        "1", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert REQUIRED <= set(d)
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["scaling"] == "weak" and d["dtype"] == "f32"
+    assert "workload" in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == d["unit"]
+    assert d["forward"]["value"] > d["value"]                      # inference pass is faster than the training step
