@@ -154,6 +154,27 @@ int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const float* h, c
                             float* db_ih, float* db_hh, void* workspace, size_t workspace_bytes,
                             int64_t V, int H, void* stream);
 
+/* ------------------------------------------------------------------ masked batch norm */
+/*
+ * Batch normalisation over the real atoms of a batch; replaces: models/mask_batch_norm.py:5-15 (MaskBatchNorm,
+ * flags = MPNN_BN_EPS_INSIDE) and :18-38 (MaskBatchNorm1d, flags = MPNN_BN_MASKED_MEAN; eval mode adds
+ * MPNN_BN_USE_STATS and reads `mean` / `var` as the running statistics).
+ *   x, y [V,F]; mask [V] or NULL; weight, bias [F] or both NULL; mean, var [F] (batch statistics, written
+ *   unless USE_STATS; var is the biased masked variance); count_out: device scalar sum(mask), may be NULL.
+ * Backward (training mode only): dx [V,F], dweight / dbias [F] (may be NULL); `count` = device scalar.
+ */
+#define MPNN_BN_MASKED_MEAN 1
+#define MPNN_BN_EPS_INSIDE 2
+#define MPNN_BN_USE_STATS 4
+size_t mpnn_masked_bn_workspace_bytes(int F);
+int mpnn_masked_bn_fwd_f32(const float* x, const float* mask, const float* weight, const float* bias,
+                           float* y, float* mean, float* var, float* count_out, int64_t V, int F, float eps,
+                           int flags, void* workspace, size_t workspace_bytes, void* stream);
+int mpnn_masked_bn_bwd_f32(const float* dout, const float* x, const float* mask, const float* weight,
+                           const float* mean, const float* var, float* dx, float* dweight, float* dbias,
+                           int64_t V, int F, float eps, int flags, const float* count, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

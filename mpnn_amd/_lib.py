@@ -33,6 +33,11 @@ _SIGNATURES = {
                                                         i64, i64, i32, i32, i32, c_v]),
     "mpnn_tower_chain_f32": (ctypes.c_int, [c_f, c_f, c_f, i32, i32, i32, c_v]),
     "mpnn_tower_chain_bwd_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, i32, i32, i32, c_v]),
+    "mpnn_masked_bn_workspace_bytes": (usz, [i32]),
+    "mpnn_masked_bn_fwd_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, ctypes.c_float, i32,
+                                              c_v, usz, c_v]),
+    "mpnn_masked_bn_bwd_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, ctypes.c_float,
+                                              i32, c_f, c_v, usz, c_v]),
     "mpnn_segsum_f32": (ctypes.c_int, [c_f, c_i, c_f, c_f, i64, i32, c_v]),
     "mpnn_segsum_bwd_f32": (ctypes.c_int, [c_f, c_i, c_f, c_f, i64, i32, c_v]),
     "mpnn_segsum_gather_f32": (ctypes.c_int, [c_f, c_i, c_i, c_f, c_f, i64, i32, c_v]),

@@ -1,0 +1,246 @@
+// Masked batch normalisation over all atoms of a batch (the layers between message and GRU update in
+// the lipophilicity and attention models).
+//
+// Reference: models/mask_batch_norm.py.  Two variants, selected by flags:
+//   MaskBatchNorm1d (:18-38)  mean = sum(x*mask)/n ; var = sum(((x-mean)*mask)^2)/n (biased) ;
+//                             y = ((x-mean)/(sqrt(var)+eps) * weight + bias) * mask     -- eps OUTSIDE the root;
+//                             eval mode uses the running statistics the same way
+//   MaskBatchNorm   (:5-15)   mean = sum(x)/n (numerator NOT masked) ; c = (x-mean)*mask ; var = sum(c^2)/n ;
+//                             y = c / sqrt(var+eps)                                        -- eps inside
+// n = sum(mask).  The variance is taken around the mean in a second pass, as the reference does (not
+// E[x^2]-E[x]^2), so results agree to fp32 rounding.
+//
+// HBM-bound column reductions: a block walks a strip of rows, a thread owns one 16-byte column group of
+// every RL-th row, partials are combined across the block in LDS and leave through one float atomic per
+// column per block.  Forward = 2 reduction passes + 1 normalise pass (x read 3 times, y written once);
+// backward = 1 reduction pass (three column sums) + 1 elementwise pass.
+#include "common.h"
+
+namespace mpnn {
+
+constexpr int kBnMaskedMean = 1;   // mean numerator is masked (MaskBatchNorm1d)
+constexpr int kBnEpsInside = 2;    // sqrt(var + eps) instead of sqrt(var) + eps (MaskBatchNorm)
+constexpr int kBnUseStats = 4;     // eval mode: mean / var are given (running statistics)
+
+// workspace (floats): [0,F) sum1  [F,2F) sum2  [2F,3F) sum3  [3F] count
+template <int MODE>   // 0: sum1 = sum x*(mask|1), count ; 1: sum2 = sum ((x-mean)*mask)^2 ; 2: backward sums
+__global__ void __launch_bounds__(256) bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                                        const float* __restrict__ dout, const float* __restrict__ mean_in,
+                                                        float* __restrict__ ws, int64_t V, int F, int flags) {
+    __shared__ float red[3][256];
+    const int tid = threadIdx.x;
+    const int cg = (F + 3) / 4;                       // column groups of 4 floats
+    const int tpr = cg < 256 ? cg : 256;              // threads per row
+    const int rl = 256 / tpr;                         // row lanes per block
+    const int c4 = tid % tpr, lane_row = tid / tpr;
+    const bool vec = (F & 3) == 0;
+    const float cnt = (MODE == 0) ? 0.f : ws[3 * F];
+    float count_part = 0.f;
+    for (int cbase = c4; cbase < cg; cbase += tpr) {  // usually one pass (F <= 1024)
+        const int c = 4 * cbase;
+        f32x4 mu = {0.f, 0.f, 0.f, 0.f};
+        if (MODE != 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c + j < F) mu[j] = mean_in ? mean_in[c + j] : ws[c + j] / cnt;
+        }
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, s3 = s1;
+        if (lane_row < rl) {
+            for (int64_t row = (int64_t)blockIdx.x * rl + lane_row; row < V; row += (int64_t)gridDim.x * rl) {
+                const float mk = mask ? mask[row] : 1.0f;
+                f32x4 xv = {0.f, 0.f, 0.f, 0.f}, dv = xv;
+                const float* px = x + row * F + c;
+                if (vec) {
+                    xv = *reinterpret_cast<const f32x4*>(px);
+                    if (MODE == 2) dv = *reinterpret_cast<const f32x4*>(dout + row * F + c);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (c + j < F) {
+                            xv[j] = px[j];
+                            if (MODE == 2) dv[j] = dout[row * F + c + j];
+                        }
+                }
+                if (MODE == 0) {
+                    s1 += xv * ((flags & kBnMaskedMean) ? mk : 1.0f);
+                    if (cbase == c4 && c4 == 0) count_part += mk;
+                } else if (MODE == 1) {
+                    const f32x4 cen = (xv - mu) * mk;
+                    s2 += cen * cen;
+                } else {
+                    const f32x4 u = xv - mu;
+                    const f32x4 g = dv * mk;
+                    s1 += g;                           // S_b = sum dout*mask
+                    s2 += g * u;                       // S_g = sum dout*mask*(x-mean)
+                    s3 += u * (mk * mk);               // S_c = sum (x-mean)*mask^2
+                }
+            }
+        }
+        // block reduction over the row lanes of each column, one component at a time
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __syncthreads();
+            red[0][tid] = s1[j];
+            red[1][tid] = s2[j];
+            red[2][tid] = s3[j];
+            __syncthreads();
+            if (lane_row == 0 && c + j < F) {
+                float a = 0.f, b = 0.f, d = 0.f;
+                for (int q = 0; q < rl; ++q) {
+                    a += red[0][q * tpr + c4];
+                    b += red[1][q * tpr + c4];
+                    d += red[2][q * tpr + c4];
+                }
+                if (MODE == 0) {
+                    atomicAdd(ws + c + j, a);
+                } else if (MODE == 1) {
+                    atomicAdd(ws + F + c + j, b);
+                } else {
+                    atomicAdd(ws + c + j, a);
+                    atomicAdd(ws + F + c + j, b);
+                    atomicAdd(ws + 2 * F + c + j, d);
+                }
+            }
+        }
+    }
+    if (MODE == 0) {
+        __syncthreads();
+        red[0][tid] = count_part;
+        __syncthreads();
+        if (tid == 0) {
+            float a = 0.f;
+            for (int q = 0; q < 256; ++q) a += red[0][q];
+            atomicAdd(ws + 3 * F, a);
+        }
+    }
+}
+
+__device__ __forceinline__ float bn_scale(float var, float eps, int flags) {
+    return (flags & kBnEpsInside) ? sqrtf(var + eps) : sqrtf(var) + eps;
+}
+
+__global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                                       const float* __restrict__ weight, const float* __restrict__ bias,
+                                                       const float* __restrict__ ws, float* __restrict__ y,
+                                                       float* __restrict__ mean_io, float* __restrict__ var_io,
+                                                       float* __restrict__ count_out, int64_t V, int F, float eps,
+                                                       int flags) {
+    const int64_t total = V * F;
+    const bool given = flags & kBnUseStats;
+    const float cnt = given ? 1.f : ws[3 * F];
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t row = idx / F;
+        const int c = (int)(idx - row * F);
+        const float mean = given ? mean_io[c] : ws[c] / cnt;
+        const float var = given ? var_io[c] : ws[F + c] / cnt;
+        const float mk = mask ? mask[row] : 1.0f;
+        float v = (x[idx] - mean) / bn_scale(var, eps, flags);
+        if (weight) v = weight[c] * v + bias[c];
+        y[idx] = v * mk;
+    }
+    if (!given && blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < F; c += 256) {
+            mean_io[c] = ws[c] / cnt;
+            var_io[c] = ws[F + c] / cnt;
+        }
+        if (threadIdx.x == 0 && count_out) *count_out = cnt;
+    }
+}
+
+// dx and (by block 0) dweight / dbias from the three column sums
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ x,
+                                                           const float* __restrict__ mask,
+                                                           const float* __restrict__ weight, const float* __restrict__ mean,
+                                                           const float* __restrict__ var, const float* __restrict__ ws,
+                                                           float* __restrict__ dx, float* __restrict__ dweight,
+                                                           float* __restrict__ dbias, int64_t V, int F, float eps,
+                                                           int flags, const float* __restrict__ count_dev) {
+    const int64_t total = V * F;
+    const float count = *count_dev;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t row = idx / F;
+        const int c = (int)(idx - row * F);
+        const float mk = mask ? mask[row] : 1.0f;
+        const float gamma = weight ? weight[c] : 1.0f;
+        const float s = bn_scale(var[c], eps, flags), rs = 1.0f / s;
+        const float Sb = ws[c], Sg = ws[F + c], Sc = ws[2 * F + c];
+        const float u = x[idx] - mean[c];
+        // d/ds = -gamma*Sg/s^2 ; ds/dvar = 1/(2*sqrt(var)) (eps outside) or 1/(2*s) (eps inside)
+        const float root = (flags & kBnEpsInside) ? s : sqrtf(var[c]);
+        const float dvar = (root > 0.f) ? (-gamma * Sg * rs * rs) / (2.0f * root) : 0.f;
+        const float du = dout[idx] * mk * gamma * rs + dvar * 2.0f * u * mk * mk / count;
+        const float dmu = -(gamma * Sb * rs + dvar * 2.0f * Sc / count);
+        dx[idx] = du + dmu * ((flags & kBnMaskedMean) ? mk : 1.0f) / count;
+    }
+    if (blockIdx.x == 0 && dweight)
+        for (int c = threadIdx.x; c < F; c += 256) {
+            dweight[c] = ws[F + c] / bn_scale(var[c], eps, flags);     // sum dout*mask*xhat
+            dbias[c] = ws[c];
+        }
+}
+
+static int bn_grid(int64_t V, int F) {
+    const int cg = (F + 3) / 4, tpr = cg < 256 ? cg : 256, rl = 256 / tpr;
+    int64_t g = ceil_div(V, (int64_t)rl * 8);
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace mpnn
+
+using namespace mpnn;
+
+extern "C" size_t mpnn_masked_bn_workspace_bytes(int F) { return F > 0 ? (size_t)(3 * F + 4) * sizeof(float) : 0; }
+
+extern "C" int mpnn_masked_bn_fwd_f32(const float* x, const float* mask, const float* weight, const float* bias,
+                                      float* y, float* mean, float* var, float* count_out, int64_t V, int F,
+                                      float eps, int flags, void* workspace, size_t workspace_bytes, void* stream) {
+    MPNN_REQUIRE(V >= 0 && F > 0 && F <= 1024, "mpnn_masked_bn_fwd_f32: V=%lld F=%d out of range", (long long)V, F);
+    if (V == 0) return MPNN_OK;
+    MPNN_REQUIRE(x && y && mean && var, "mpnn_masked_bn_fwd_f32: NULL buffer");
+    MPNN_REQUIRE((weight == nullptr) == (bias == nullptr), "mpnn_masked_bn_fwd_f32: weight and bias go together");
+    if (!workspace || workspace_bytes < mpnn_masked_bn_workspace_bytes(F)) {
+        set_error("mpnn_masked_bn_fwd_f32: workspace %zu < %zu", workspace_bytes, mpnn_masked_bn_workspace_bytes(F));
+        return MPNN_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    int64_t ag = ceil_div(V * F, 256);
+    if (ag > 256 * 32) ag = 256 * 32;
+    if (!(flags & kBnUseStats)) {
+        (void)hipMemsetAsync(ws, 0, mpnn_masked_bn_workspace_bytes(F), s);
+        const int g = bn_grid(V, F);
+        hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(g), dim3(256), 0, s, x, mask, (const float*)nullptr,
+                           (const float*)nullptr, ws, V, F, flags);
+        hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(g), dim3(256), 0, s, x, mask, (const float*)nullptr,
+                           (const float*)nullptr, ws, V, F, flags);
+    }
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)ag), dim3(256), 0, s, x, mask, weight, bias, ws, y, mean, var,
+                       count_out, V, F, eps, flags);
+    return launch_status("mpnn_masked_bn_fwd_f32");
+}
+
+extern "C" int mpnn_masked_bn_bwd_f32(const float* dout, const float* x, const float* mask, const float* weight,
+                                      const float* mean, const float* var, float* dx, float* dweight, float* dbias,
+                                      int64_t V, int F, float eps, int flags, const float* count, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+    MPNN_REQUIRE(V >= 0 && F > 0 && F <= 1024, "mpnn_masked_bn_bwd_f32: V=%lld F=%d out of range", (long long)V, F);
+    MPNN_REQUIRE(!(flags & kBnUseStats), "mpnn_masked_bn_bwd_f32: eval-mode backward is a plain scale (not provided)");
+    if (V == 0) return MPNN_OK;
+    MPNN_REQUIRE(dout && x && mean && var && dx && count, "mpnn_masked_bn_bwd_f32: NULL buffer");
+    if (!workspace || workspace_bytes < mpnn_masked_bn_workspace_bytes(F)) {
+        set_error("mpnn_masked_bn_bwd_f32: workspace %zu < %zu", workspace_bytes, mpnn_masked_bn_workspace_bytes(F));
+        return MPNN_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    (void)hipMemsetAsync(ws, 0, mpnn_masked_bn_workspace_bytes(F), s);
+    // the reduction kernel reads `count` from ws[3F] only for the mean; here the mean is given
+    hipLaunchKernelGGL((bn_reduce_kernel<2>), dim3(bn_grid(V, F)), dim3(256), 0, s, x, mask, dout, mean, ws, V, F, flags);
+    int64_t ag = ceil_div(V * F, 256);
+    if (ag > 256 * 32) ag = 256 * 32;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)ag), dim3(256), 0, s, dout, x, mask, weight, mean, var, ws, dx,
+                       dweight, dbias, V, F, eps, flags, count);
+    return launch_status("mpnn_masked_bn_bwd_f32");
+}

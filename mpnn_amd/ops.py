@@ -270,6 +270,69 @@ def message_aggregate(h, A, graph, w=None, gate=None):
     return MessageAggregate.apply(h, A, gate, w, graph)
 
 
+BN_MASKED_MEAN, BN_EPS_INSIDE, BN_USE_STATS = 1, 2, 4
+
+
+class MaskedBatchNorm(torch.autograd.Function):
+    """y, batch_mean, batch_var = masked batch norm of x (V,F); see include/mpnn_amd.h.  The statistics
+    outputs carry no gradient (they feed the running estimates)."""
+
+    @staticmethod
+    def forward(ctx, x, mask, weight, bias, stats_mean, stats_var, eps, flags):
+        lib = _lib.load()
+        x = x.contiguous()
+        V, F = int(x.shape[0]), int(x.shape[1])
+        mask = mask.contiguous() if mask is not None else None
+        y = _empty((V, F), x)
+        if flags & BN_USE_STATS:
+            mean, var = stats_mean.contiguous().clone(), stats_var.contiguous().clone()
+        else:
+            mean, var = _empty((F,), x), _empty((F,), x)
+        count = _empty((1,), x)
+        ws_bytes = lib.mpnn_masked_bn_workspace_bytes(F)
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+        w = weight.contiguous() if weight is not None else None
+        b = bias.contiguous() if bias is not None else None
+        _lib.check(lib.mpnn_masked_bn_fwd_f32(_lib.fptr(x), _lib.fptr(mask), _lib.fptr(w), _lib.fptr(b), _lib.fptr(y),
+                                              _lib.fptr(mean), _lib.fptr(var), _lib.fptr(count), V, F, float(eps),
+                                              int(flags), _lib.ptr(ws), ws_bytes, _lib.stream()),
+                   "mpnn_masked_bn_fwd_f32")
+        ctx.save_for_backward(x, mask, w, mean, var, count)
+        ctx.eps, ctx.flags = float(eps), int(flags)
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dmean, _dvar):
+        lib = _lib.load()
+        x, mask, w, mean, var, count = ctx.saved_tensors
+        V, F = int(x.shape[0]), int(x.shape[1])
+        dy = dy.contiguous()
+        if ctx.flags & BN_USE_STATS:                   # eval mode: a fixed per-column scale
+            scale = 1.0 / (torch.sqrt(var + ctx.eps) if ctx.flags & BN_EPS_INSIDE else torch.sqrt(var) + ctx.eps)
+            g = dy * (mask.unsqueeze(-1) if mask is not None else 1.0)
+            xhat = (x - mean) * scale
+            dx = g * scale * (w if w is not None else 1.0)
+            return (dx, None, (g * xhat).sum(0) if w is not None else None, g.sum(0) if w is not None else None,
+                    None, None, None, None)
+        dx = _empty((V, F), x)
+        dweight = _empty((F,), x) if w is not None else None
+        dbias = _empty((F,), x) if w is not None else None
+        ws_bytes = lib.mpnn_masked_bn_workspace_bytes(F)
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+        _lib.check(lib.mpnn_masked_bn_bwd_f32(_lib.fptr(dy), _lib.fptr(x), _lib.fptr(mask), _lib.fptr(w), _lib.fptr(mean),
+                                              _lib.fptr(var), _lib.fptr(dx), _lib.fptr(dweight), _lib.fptr(dbias), V, F,
+                                              ctx.eps, ctx.flags, _lib.fptr(count), _lib.ptr(ws), ws_bytes,
+                                              _lib.stream()), "mpnn_masked_bn_bwd_f32")
+        return dx, None, dweight, dbias, None, None, None, None
+
+
+def masked_batch_norm(x, mask, weight=None, bias=None, stats=None, eps=1e-5, flags=BN_MASKED_MEAN):
+    """x (V,F), mask (V,) -> (y, batch_mean, batch_var); `stats` = (mean, var) with BN_USE_STATS."""
+    sm, sv = stats if stats is not None else (None, None)
+    return MaskedBatchNorm.apply(x, mask, weight, bias, sm, sv, eps, flags)
+
+
 class GRUUpdateFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, m, h, mask, W_ih, W_hh, b_ih, b_hh, grad_mode):

@@ -241,3 +241,56 @@ def test_tower_chain(dev, R, L, n):
     assert max_err(out.cpu(), y) < 2e-5 * scale
     assert max_err(hx.cpu(), gx) < 2e-5 * max(1.0, float(gx.abs().max()))
     assert max_err(hW.cpu(), gW) < 2e-5 * max(1.0, float(gW.abs().max()))
+
+
+# ----------------------------------------------------------------------------- masked batch norm
+def test_masked_bn_against_reference_fixtures(dev):
+    from mpnn_amd import ops
+    f = Fixture("mask_bn1d_train")
+    x, mask = f.inputs["x"].reshape(-1, 8).to(dev), f.inputs["mask"].reshape(-1).to(dev)
+    y, mean, var = ops.masked_batch_norm(x, mask, f.params["weight"].to(dev), f.params["bias"].to(dev), None, 1e-5,
+                                         ops.BN_MASKED_MEAN)
+    assert max_err(y.cpu().view(f.out[""].shape), f.out[""]) < TOL
+    # running statistics after one training step from (0, 1) with momentum 0.1
+    assert max_err(0.1 * mean.cpu(), torch.from_numpy(f.raw["running_mean_after"])) < TOL
+    assert max_err(0.9 + 0.1 * var.cpu(), torch.from_numpy(f.raw["running_var_after"])) < TOL
+    f = Fixture("mask_bn1d_eval")
+    y, _, _ = ops.masked_batch_norm(x, mask, f.params["weight"].to(dev), f.params["bias"].to(dev),
+                                    (f.params["running_mean"].to(dev), f.params["running_var"].to(dev)), 1e-5,
+                                    ops.BN_MASKED_MEAN | ops.BN_USE_STATS)
+    assert max_err(y.cpu().view(f.out[""].shape), f.out[""]) < TOL
+    f = Fixture("mask_bn_noaffine")
+    y, _, _ = ops.masked_batch_norm(x, mask, None, None, None, 1e-6, ops.BN_EPS_INSIDE)
+    assert max_err(y.cpu().view(f.out[""].shape), f.out[""]) < TOL
+
+
+@pytest.mark.parametrize("V,F", [(37, 8), (1000, 22), (5000, 64), (777, 128), (300, 260)])
+@pytest.mark.parametrize("variant", ["bn1d", "noaffine"])
+def test_masked_bn_forward_backward(dev, V, F, variant):
+    """Forward and all gradients against the oracle's differentiable restatement (float64)."""
+    from mpnn_amd import ops
+    g = torch.Generator().manual_seed(V + F)
+    x = torch.randn(V, F, generator=g) * 2 + 0.5
+    mask = (torch.rand(V, generator=g) < 0.7).float()
+    x = x * (mask.unsqueeze(1) if variant == "noaffine" else 1.0) + (0.0 if variant == "noaffine" else 0.0)
+    w, b = torch.rand(F, generator=g) + 0.5, torch.rand(F, generator=g) - 0.5
+    cot = torch.randn(V, F, generator=g)
+    xd = x.double().requires_grad_(True)
+    if variant == "bn1d":
+        wd, bd = w.double().requires_grad_(True), b.double().requires_grad_(True)
+        ref, _, _ = O.mask_bn1d(xd, mask.double().view(-1, 1), wd, bd, None, None, True)
+        gref = torch.autograd.grad((ref * cot.double()).sum(), [xd, wd, bd])
+    else:
+        ref = O.mask_bn(xd, mask.double().view(-1, 1))
+        gref = torch.autograd.grad((ref * cot.double()).sum(), [xd])
+    xg = x.to(dev).requires_grad_(True)
+    if variant == "bn1d":
+        wg, bg = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+        out, _, _ = ops.masked_batch_norm(xg, mask.to(dev), wg, bg, None, 1e-5, ops.BN_MASKED_MEAN)
+        ggpu = torch.autograd.grad((out * cot.to(dev)).sum(), [xg, wg, bg])
+    else:
+        out, _, _ = ops.masked_batch_norm(xg, mask.to(dev), None, None, None, 1e-6, ops.BN_EPS_INSIDE)
+        ggpu = torch.autograd.grad((out * cot.to(dev)).sum(), [xg])
+    assert max_err(out.cpu(), ref) < 2e-5
+    for a, bb in zip(ggpu, gref):
+        assert max_err(a.cpu(), bb) < 2e-5 * max(1.0, float(bb.abs().max()))
