@@ -16,8 +16,6 @@
 //     k contiguous: a B fragment of one piece = one ds_read_b128), 16-byte chunks XOR-swizzled by the
 //     column so the 16-lane read groups are conflict-free;
 //   * activations are split in registers right before use (8 floats -> 3 x bf16x8 per K=16 step).
-#include <stdlib.h>
-
 #include "split_math.h"
 
 namespace mpnn {
@@ -36,8 +34,8 @@ __device__ __forceinline__ int col_swizzle(int col) {
     return H == 64 ? ((col >> 1) & 7) : (col & 15);
 }
 
-template <int H, int NCS, int NW, bool HAS_MASK, int MINW = 1>   // MINW = waves per SIMD the register budget must allow
-__global__ void __launch_bounds__(64 * NW, MINW) gru_update_split_kernel(
+template <int H, int NCS, int NW, bool HAS_MASK>
+__global__ void __launch_bounds__(64 * NW) gru_update_split_kernel(
     const float* __restrict__ m, const float* __restrict__ h, const float* __restrict__ mask,
     const float* __restrict__ W_ih, const float* __restrict__ W_hh, const float* __restrict__ b_ih,
     const float* __restrict__ b_hh, float* __restrict__ out, float* __restrict__ saved, int64_t V, int slices) {
@@ -50,11 +48,8 @@ __global__ void __launch_bounds__(64 * NW, MINW) gru_update_split_kernel(
     constexpr int IMG = NCOL * ROWB;           // bytes of one (matrix, piece) image
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 matrices][3 pieces][NCOL][H] bf16
 
-    // column slices of the same atom range sit on the same XCD (blocks b and b+8 share one): the second
-    // slice's reads of m / h are L2 hits (placement is for speed only)
-    const int xcd = blockIdx.x % kNumXcd, jb = blockIdx.x / kNumXcd;
-    const int slice = jb % slices;
-    const int pblock = (jb / slices) * kNumXcd + xcd, pblocks = gridDim.x / slices;
+    const int slice = blockIdx.x % slices;
+    const int pblock = blockIdx.x / slices, pblocks = gridDim.x / slices;
     const int c0 = slice * CS;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
@@ -187,7 +182,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) gru_update_split_kernel(
     }
 }
 
-template <int H, int NCS, int NW, int MINW, int BLOCKS_PER_CU>
+template <int H, int NCS, int NW>
 static int launch_split(const float* m, const float* h, const float* mask, const float* W_ih, const float* W_hh,
                         const float* b_ih, const float* b_hh, float* out, float* saved, int64_t V, hipStream_t s) {
     constexpr int CS = 32 * NCS;
@@ -195,34 +190,30 @@ static int launch_split(const float* m, const float* h, const float* mask, const
     const size_t lds = (size_t)2 * 3 * (3 * CS) * (2 * H);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gru_update_split_kernel<H, NCS, NW, true, MINW>,
+        (void)hipFuncSetAttribute((const void*)gru_update_split_kernel<H, NCS, NW, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)gru_update_split_kernel<H, NCS, NW, false, MINW>,
+        (void)hipFuncSetAttribute((const void*)gru_update_split_kernel<H, NCS, NW, false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     const int64_t tiles = (V + 31) / 32;
-    // pblocks (atom-range groups) must be a multiple of 8 for the XCD pairing; BLOCKS_PER_CU blocks fit one CU
-    int64_t pblocks = (256 * BLOCKS_PER_CU) / slices;
-    if (pblocks * NW > tiles) pblocks = ((tiles + NW - 1) / NW + kNumXcd - 1) / kNumXcd * kNumXcd;
-    if (pblocks < kNumXcd) pblocks = kNumXcd;
+    int64_t pblocks = (256 + slices - 1) / slices;        // one block per CU (144 KB of LDS)
+    if (pblocks * NW > tiles) pblocks = (tiles + NW - 1) / NW;
+    if (pblocks < 1) pblocks = 1;
     const dim3 grid((unsigned)(pblocks * slices)), block(64 * NW);
     if (mask)
-        hipLaunchKernelGGL((gru_update_split_kernel<H, NCS, NW, true, MINW>), grid, block, lds, s, m, h, mask, W_ih, W_hh,
-                           b_ih, b_hh, out, saved, V, slices);
+        hipLaunchKernelGGL((gru_update_split_kernel<H, NCS, NW, true>), grid, block, lds, s, m, h, mask, W_ih, W_hh, b_ih,
+                           b_hh, out, saved, V, slices);
     else
-        hipLaunchKernelGGL((gru_update_split_kernel<H, NCS, NW, false, MINW>), grid, block, lds, s, m, h, mask, W_ih,
-                           W_hh, b_ih, b_hh, out, saved, V, slices);
+        hipLaunchKernelGGL((gru_update_split_kernel<H, NCS, NW, false>), grid, block, lds, s, m, h, mask, W_ih, W_hh,
+                           b_ih, b_hh, out, saved, V, slices);
     return launch_status("mpnn_gru_update_f32(bf16x6)");
 }
 
 // returns 1 when the width has no split-precision path
 int launch_gru_split(const float* m, const float* h, const float* mask, const float* W_ih, const float* W_hh,
                      const float* b_ih, const float* b_hh, float* out, float* saved, int64_t V, int H, hipStream_t s) {
-    // MPNN_GRU_FWD_SLICED=1: two 6-wave blocks per CU, each a 32-column slice, 3 waves/SIMD (A/B)
-    static const bool sliced = getenv("MPNN_GRU_FWD_SLICED") != nullptr;
-    if (H == 64 && sliced) return launch_split<64, 1, 6, 3, 2>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, s);
-    if (H == 64) return launch_split<64, 2, 8, 1, 1>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, s);
+    if (H == 64) return launch_split<64, 2, 8>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, s);
     // H == 128 (launch_split<128, 1, 4>) measured slower than the fp32 resident kernel (1 wave/SIMD): not dispatched yet
     return 1;
 }
