@@ -8,10 +8,7 @@
 //                  - dA[k]  = sum_{e of type k} dmsg[e] (x) (gate[e]*h[src e])
 //                  - dW_ih  = m^T dgi, dW_hh = h^T dgh, db = column sums of dgi / dgh
 // plus the elementwise gate-gradient kernel of the GRU.
-#include <stdlib.h>
-#include <string.h>
-
-#include "split_math.h"
+#include "common.h"
 
 namespace mpnn {
 
@@ -400,105 +397,6 @@ __global__ void __launch_bounds__(512) edge_dA_direct64_kernel(const float* __re
     }
 }
 
-// ------------------------------------------------------------------------------------ dA, register-direct, bf16x6
-// Same access pattern as edge_dA_direct64_kernel (coalesced dword operand loads, one wave owns the 64x64
-// output) with the products on the bf16 pipe through 3-way operand splitting (split_math.h): a K=16 step
-// takes 8 consecutive edge rows per lane half, i.e. the same 64 dword loads per 32-edge tile, then
-// 4 x split8 and 4 x 6 MFMAs of 32 cycles instead of 32 fp32 MFMAs of 64.
-__global__ void __launch_bounds__(512) edge_dA_direct64_split_kernel(const float* __restrict__ dmsg,
-                                                                     const float* __restrict__ h,
-                                                                     const int32_t* __restrict__ src,
-                                                                     const int32_t* __restrict__ order,
-                                                                     const int32_t* __restrict__ type_ptr,
-                                                                     const float* __restrict__ gate, float* dA, int K,
-                                                                     const int32_t* __restrict__ dst,
-                                                                     const float* __restrict__ w) {
-    constexpr int F = 64;
-    __shared__ float red[F * F];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int i = lane & 31, hi = lane >> 5;
-    const int gw = blockIdx.x * 8 + wv, nw = gridDim.x * 8;
-
-    for (int k = 0; k < K; ++k) {
-        const int tb = type_ptr[k], te = type_ptr[k + 1];
-        if (te == tb) continue;
-        for (int idx = tid; idx < F * F; idx += 512) red[idx] = 0.f;
-        __syncthreads();
-
-        f32x16 acc[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int z = 0; z < 16; ++z) acc[q][z] = 0.f;
-        const int tiles = (te - tb + 31) / 32;
-        bool any = false;
-        for (int t = gw; t < tiles; t += nw) {
-            any = true;
-            const int pos = tb + 32 * t + i;
-            const bool ok = pos < te;
-            const int e_l = ok ? order[pos] : order[tb + 32 * t];
-            const int s_l = src[e_l];
-            const int d_l = dst ? dst[e_l] : e_l;
-            const float w_l = (dst && w) ? w[e_l] : 1.0f;
-            const int rows = min(32, te - tb - 32 * t);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                f32x4 a0[2], a1[2], b0[2], b1[2];          // [half of the 8 rows]: columns i and 32+i of A and B
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int r_lo = 16 * ks + j, r_hi = 16 * ks + 8 + j;       // rows of lane halves 0 / 1
-                    const int d_r = hi ? __builtin_amdgcn_readlane(d_l, r_hi) : __builtin_amdgcn_readlane(d_l, r_lo);
-                    const int s_r = hi ? __builtin_amdgcn_readlane(s_l, r_hi) : __builtin_amdgcn_readlane(s_l, r_lo);
-                    const int e_r = hi ? __builtin_amdgcn_readlane(e_l, r_hi) : __builtin_amdgcn_readlane(e_l, r_lo);
-                    const float w_r = hi ? __builtin_amdgcn_readlane(w_l, r_hi) : __builtin_amdgcn_readlane(w_l, r_lo);
-                    const bool live = (hi ? r_hi : r_lo) < rows;
-                    const float* pa = dmsg + (int64_t)d_r * F + i;
-                    const float* pb = h + (int64_t)s_r * F + i;
-                    float va0 = pa[0] * w_r, va1 = pa[32] * w_r;
-                    float vb0 = pb[0], vb1 = pb[32];
-                    if (gate) {
-                        const float* pg = gate + (int64_t)e_r * F + i;
-                        vb0 *= pg[0];
-                        vb1 *= pg[32];
-                    }
-                    if (!live) { va0 = 0.f; va1 = 0.f; }
-                    a0[j >> 2][j & 3] = va0;
-                    a1[j >> 2][j & 3] = va1;
-                    b0[j >> 2][j & 3] = vb0;
-                    b1[j >> 2][j & 3] = vb1;
-                }
-                bf16x8 a0h, a0m, a0l, a1h, a1m, a1l, b0h, b0m, b0l, b1h, b1m, b1l;
-                split8(a0[0], a0[1], a0h, a0m, a0l);
-                split8(a1[0], a1[1], a1h, a1m, a1l);
-                split8(b0[0], b0[1], b0h, b0m, b0l);
-                split8(b1[0], b1[1], b1h, b1m, b1l);
-                mma6(acc[0], a0h, a0m, a0l, b0h, b0m, b0l);
-                mma6(acc[1], a0h, a0m, a0l, b1h, b1m, b1l);
-                mma6(acc[2], a1h, a1m, a1l, b0h, b0m, b0l);
-                mma6(acc[3], a1h, a1m, a1l, b1h, b1m, b1l);
-            }
-        }
-        if (any) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int col = 32 * (q & 1) + i;
-#pragma unroll
-                for (int z = 0; z < 16; ++z) {
-                    const int row = 32 * (q >> 1) + acc_row(z, lane);
-                    atomicAdd(&red[row * F + col], acc[q][z]);
-                }
-            }
-        }
-        __syncthreads();
-        float* out = dA + (int64_t)k * F * F;
-        for (int idx = tid; idx < F * F; idx += 512) {
-            const float v = red[idx];
-            if (v != 0.f) atomicAdd(out + idx, v);
-        }
-        __syncthreads();
-    }
-}
-
 // ------------------------------------------------------------------------------------ GRU gate gradients
 // From dout and the saved forward gates (r, z, n, gh_n) to the pre-activation gradients
 //   ws[row] = [ dgi_r dgi_z dgi_n | dgh_r dgh_z dgh_n ]   (6H floats)   and   dh_direct = dout*mask*z.
@@ -544,22 +442,6 @@ int launch_gru_bwd_fused64(const float* dout, const float* m, const float* h, co
 
 using namespace mpnn;
 
-static void launch_dA_direct64(const float* dmsg, const float* h, const int32_t* src, const int32_t* order,
-                               const int32_t* type_ptr, const float* gate, float* dA, int K, const int32_t* dst,
-                               const float* w, int64_t E, hipStream_t s) {
-    // MPNN_DA_MATH=fp32 keeps the products on v_mfma_f32_32x32x2_f32 (A/B and reference variant)
-    static const bool fp32_only = getenv("MPNN_DA_MATH") && !strcmp(getenv("MPNN_DA_MATH"), "fp32");
-    int64_t gx = 512;                               // 2 blocks of 8 waves per CU
-    const int64_t need = ceil_div(ceil_div(E, 32) + K, 8);
-    if (gx > need) gx = need;
-    if (fp32_only)
-        hipLaunchKernelGGL(edge_dA_direct64_kernel, dim3((unsigned)gx), dim3(512), 0, s, dmsg, h, src, order, type_ptr,
-                           gate, dA, K, dst, w);
-    else
-        hipLaunchKernelGGL(edge_dA_direct64_split_kernel, dim3((unsigned)gx), dim3(512), 0, s, dmsg, h, src, order,
-                           type_ptr, gate, dA, K, dst, w);
-}
-
 extern "C" int mpnn_edge_message_bwd_f32(const float* h, const float* A, const int32_t* src, const int32_t* order,
                                          const int32_t* type_ptr, const float* gate, const float* dmsg, float* dx,
                                          float* dA, int64_t V, int64_t E, int K, int nf, int mf, void* stream) {
@@ -580,7 +462,11 @@ extern "C" int mpnn_edge_message_bwd_f32(const float* h, const float* A, const i
         if (rc) return rc;
     }
     if (dA && mf == 64 && nf == 64 && K <= 64) {
-        launch_dA_direct64(dmsg, h, src, order, type_ptr, gate, dA, K, nullptr, nullptr, E, s);
+        int64_t gx = 512;                               // 2 blocks of 8 waves per CU
+        const int64_t need = ceil_div(ceil_div(E, 32) + K, 8);
+        if (gx > need) gx = need;
+        hipLaunchKernelGGL(edge_dA_direct64_kernel, dim3((unsigned)gx), dim3(512), 0, s, dmsg, h, src, order, type_ptr,
+                           gate, dA, K, (const int32_t*)nullptr, (const float*)nullptr);
         rc = launch_status("mpnn_edge_message_bwd_f32(dA direct)");
     } else if (dA) {
         const int pairs = (int)(ceil_div(mf, 64) * ceil_div(nf, 64));
@@ -651,6 +537,10 @@ extern "C" int mpnn_edge_message_agg_bwd_da_f32(const float* dagg, const float* 
     if (E == 0) return MPNN_OK;
     MPNN_REQUIRE(dagg && h && src && dst && order && type_ptr && dA && K > 0,
                  "mpnn_edge_message_agg_bwd_da_f32: NULL buffer");
-    launch_dA_direct64(dagg, h, src, order, type_ptr, gate, dA, K, dst, w, E, (hipStream_t)stream);
+    int64_t gx = 512;
+    const int64_t need = ceil_div(ceil_div(E, 32) + K, 8);
+    if (gx > need) gx = need;
+    hipLaunchKernelGGL(edge_dA_direct64_kernel, dim3((unsigned)gx), dim3(512), 0, (hipStream_t)stream, dagg, h, src,
+                       order, type_ptr, gate, dA, K, dst, w);
     return launch_status("mpnn_edge_message_agg_bwd_da_f32");
 }
