@@ -397,6 +397,102 @@ __global__ void __launch_bounds__(512) edge_dA_direct64_kernel(const float* __re
     }
 }
 
+// ------------------------------------------------------------------------------------ tn, register-direct, wide
+// C[type] (32*MA x 32*NBT) += sum_rows A[arow, :]^T (x) B[brow, :] for outputs too wide for one wave.
+// The block's 8 waves walk the SAME 32-row tiles (their operand loads hit the same L1 lines) and split the
+// output: wave w owns a-block (w % MA) and the NBW b-blocks {bg + G*j}, bg = w / MA, G = 8 / MA, so the
+// block covers all MA x (G*NBW) tiles and no two waves add to the same element (no LDS reduction).
+// Operands are coalesced dword loads straight from global, as in edge_dA_direct64_kernel.
+//   TYPED : rows are edges of the type-sorted list; arow = dst[e] (or e), brow = src[e], optional w / gate;
+//           C is flushed per type.        untyped: arow = brow = row; optional column sums of B (bias grads).
+template <int MA, int NBW, bool TYPED>
+__global__ void __launch_bounds__(512) tn_direct_kernel(const float* __restrict__ Xa, int lda,
+                                                        const float* __restrict__ Yb, int ldb,
+                                                        const int32_t* __restrict__ order,
+                                                        const int32_t* __restrict__ type_ptr, int K,
+                                                        const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                                                        const float* __restrict__ w, const float* __restrict__ gate,
+                                                        float* C, float* colsum, int64_t R) {
+    constexpr int G = 8 / MA;
+    constexpr int NBT = G * NBW;
+    constexpr int M = 32 * MA, N = 32 * NBT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, hi = lane >> 5;
+    const int ai = wv % MA, bg = wv / MA;
+
+    f32x16 acc[NBW];
+    float cs[NBW];
+    const int ntypes = TYPED ? K : 1;
+    for (int k = 0; k < ntypes; ++k) {
+        int64_t tb = 0, te = R;
+        if (TYPED) {
+            tb = type_ptr[k];
+            te = type_ptr[k + 1];
+            if (te == tb) continue;
+        }
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            cs[j] = 0.f;
+#pragma unroll
+            for (int z = 0; z < 16; ++z) acc[j][z] = 0.f;
+        }
+        const int64_t tiles = (te - tb + 31) / 32;
+        for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+            const int64_t pos = tb + 32 * t + i;
+            const bool ok = pos < te;
+            const int64_t p0 = ok ? pos : tb + 32 * t;
+            int a_l, b_l, e_l = 0;
+            float w_l = 1.0f;
+            if (TYPED) {
+                e_l = order[p0];
+                a_l = dst ? dst[e_l] : e_l;
+                b_l = src[e_l];
+                if (dst && w) w_l = w[e_l];
+            } else {
+                a_l = b_l = (int)p0;
+            }
+            const int rows = (int)min((int64_t)32, te - tb - 32 * t);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int a_r = hi ? __builtin_amdgcn_readlane(a_l, 16 + s) : __builtin_amdgcn_readlane(a_l, s);
+                const int b_r = hi ? __builtin_amdgcn_readlane(b_l, 16 + s) : __builtin_amdgcn_readlane(b_l, s);
+                const bool live = (hi ? 16 + s : s) < rows;
+                float av = Xa[(int64_t)a_r * lda + 32 * ai + i];
+                if (TYPED && dst && w) av *= hi ? __builtin_amdgcn_readlane(w_l, 16 + s) : __builtin_amdgcn_readlane(w_l, s);
+                if (!live) av = 0.f;
+                const float* pb = Yb + (int64_t)b_r * ldb + 32 * bg + i;
+                const float* pg = nullptr;
+                if (TYPED && gate) {
+                    const int e_r = hi ? __builtin_amdgcn_readlane(e_l, 16 + s) : __builtin_amdgcn_readlane(e_l, s);
+                    pg = gate + (int64_t)e_r * N + 32 * bg + i;
+                }
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) {
+                    float bv = pb[32 * G * j];
+                    if (TYPED && gate) bv *= pg[32 * G * j];
+                    if (!TYPED && live) cs[j] += bv;
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+                }
+            }
+        }
+        float* Ct = C + (int64_t)k * M * N;
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            const int col = 32 * (bg + G * j) + i;
+#pragma unroll
+            for (int z = 0; z < 16; ++z) {
+                const float v = acc[j][z];
+                if (v != 0.f) atomicAdd(Ct + (int64_t)(32 * ai + acc_row(z, lane)) * N + col, v);
+            }
+            if (!TYPED && colsum && ai == 0) {
+                const float tot = cs[j] + __shfl_xor(cs[j], 32);
+                if (hi == 0) atomicAdd(colsum + col, tot);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ GRU gate gradients
 // From dout and the saved forward gates (r, z, n, gh_n) to the pre-activation gradients
 //   ws[row] = [ dgi_r dgi_z dgi_n | dgh_r dgh_z dgh_n ]   (6H floats)   and   dh_direct = dout*mask*z.
@@ -468,6 +564,13 @@ extern "C" int mpnn_edge_message_bwd_f32(const float* h, const float* A, const i
         hipLaunchKernelGGL(edge_dA_direct64_kernel, dim3((unsigned)gx), dim3(512), 0, s, dmsg, h, src, order, type_ptr,
                            gate, dA, K, (const int32_t*)nullptr, (const float*)nullptr);
         rc = launch_status("mpnn_edge_message_bwd_f32(dA direct)");
+    } else if (dA && mf == 128 && nf == 128 && K <= 64) {
+        int64_t gx = 512;
+        const int64_t need = ceil_div(E, 32) + K;
+        if (gx > need) gx = need;
+        hipLaunchKernelGGL((tn_direct_kernel<4, 2, true>), dim3((unsigned)gx), dim3(512), 0, s, dmsg, mf, h, nf, order,
+                           type_ptr, K, src, (const int32_t*)nullptr, (const float*)nullptr, gate, dA, (float*)nullptr, E);
+        rc = launch_status("mpnn_edge_message_bwd_f32(dA direct 128)");
     } else if (dA) {
         const int pairs = (int)(ceil_div(mf, 64) * ceil_div(nf, 64));
         int64_t gx = ceil_div(E, kBT) + K;
@@ -515,6 +618,18 @@ extern "C" int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const 
     rc = launch_rows_gemm<true, false>(ws + 3 * H, 6 * H, nullptr, nullptr, 0, W_hh, 0, 3 * H, dh, dh, H, V, 3 * H, H, s,
                                        "mpnn_gru_update_bwd_f32(dh)");
     if (rc) return rc;
+    if (H == 128) {
+        // dW (128 x 384) and db on the register-direct wide kernel: 8 waves = 4 a-blocks x 2 groups of 6 b-blocks
+        int64_t gxd = 512;
+        if (gxd > ceil_div(V, 32)) gxd = ceil_div(V, 32);
+        hipLaunchKernelGGL((tn_direct_kernel<4, 6, false>), dim3((unsigned)gxd), dim3(512), 0, s, m, H, ws, 6 * H,
+                           (const int32_t*)nullptr, (const int32_t*)nullptr, 1, (const int32_t*)nullptr,
+                           (const int32_t*)nullptr, (const float*)nullptr, (const float*)nullptr, dW_ih, db_ih, V);
+        hipLaunchKernelGGL((tn_direct_kernel<4, 6, false>), dim3((unsigned)gxd), dim3(512), 0, s, h, H, ws + 3 * H, 6 * H,
+                           (const int32_t*)nullptr, (const int32_t*)nullptr, 1, (const int32_t*)nullptr,
+                           (const int32_t*)nullptr, (const float*)nullptr, (const float*)nullptr, dW_hh, db_hh, V);
+        return launch_status("mpnn_gru_update_bwd_f32(dW direct 128)");
+    }
     const int pairs = (int)(ceil_div(H, 64) * ceil_div(3 * H, 64));
     int64_t gx = ceil_div(V, kBT);
     if (gx > 512) gx = 512;
@@ -532,8 +647,8 @@ extern "C" int mpnn_edge_message_agg_bwd_da_f32(const float* dagg, const float* 
                                                 const int32_t* type_ptr, const float* gate, float* dA, int64_t V,
                                                 int64_t E, int K, int nf, int mf, void* stream) {
     MPNN_REQUIRE(E >= 0 && V >= 0 && K >= 0, "mpnn_edge_message_agg_bwd_da_f32: negative size");
-    MPNN_REQUIRE(nf == 64 && mf == 64 && K <= 64,
-                 "mpnn_edge_message_agg_bwd_da_f32: only nf = mf = 64, K <= 64 (got %d, %d, %d)", nf, mf, K);
+    MPNN_REQUIRE(((nf == 64 && mf == 64) || (nf == 128 && mf == 128)) && K <= 64,
+                 "mpnn_edge_message_agg_bwd_da_f32: only nf = mf in {64, 128}, K <= 64 (got %d, %d, %d)", nf, mf, K);
     if (E == 0) return MPNN_OK;
     MPNN_REQUIRE(dagg && h && src && dst && order && type_ptr && dA && K > 0,
                  "mpnn_edge_message_agg_bwd_da_f32: NULL buffer");
