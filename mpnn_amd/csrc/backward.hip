@@ -652,6 +652,14 @@ extern "C" int mpnn_edge_message_agg_bwd_da_f32(const float* dagg, const float* 
     if (E == 0) return MPNN_OK;
     MPNN_REQUIRE(dagg && h && src && dst && order && type_ptr && dA && K > 0,
                  "mpnn_edge_message_agg_bwd_da_f32: NULL buffer");
+    if (nf == 128) {
+        int64_t gx = 512;
+        const int64_t need = ceil_div(E, 32) + K;
+        if (gx > need) gx = need;
+        hipLaunchKernelGGL((tn_direct_kernel<4, 2, true>), dim3((unsigned)gx), dim3(512), 0, (hipStream_t)stream, dagg, mf,
+                           h, nf, order, type_ptr, K, src, dst, w, gate, dA, (float*)nullptr, E);
+        return launch_status("mpnn_edge_message_agg_bwd_da_f32(128)");
+    }
     int64_t gx = 512;
     const int64_t need = ceil_div(ceil_div(E, 32) + K, 8);
     if (gx > need) gx = need;

@@ -168,3 +168,41 @@ def test_lipo_model_backward(dev):
     out = model({k: v.to(dev) for k, v in f.inputs.items()})
     (out * f.cot.to(dev)).sum().backward()
     _check_param_grads(model, f, 2e-4)      # six chained batch norms in the backward chain
+
+
+@pytest.mark.parametrize("H,K,V", [(64, 4, 2500), (128, 4, 900), (64, 1, 300), (32, 3, 400), (22, 5, 333)])
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("need_dh", [False, True])
+def test_message_aggregate_node(dev, H, K, V, weighted, need_dh):
+    """ops.message_aggregate (message + adjacency-weighted sum as ONE autograd node): forward and the
+    gradients of A (always) and h (optional: selects the fused dA-from-dagg path when absent) against
+    a float64 reference -- this is the path BasicModel takes at every width."""
+    from mpnn_amd import ops
+    from mpnn_amd.graph import MolGraph
+    rng = np.random.default_rng(H + K + V + weighted)
+    deg = rng.integers(0, 6, V)
+    row_ptr = np.zeros(V + 1, np.int32)
+    np.cumsum(deg, out=row_ptr[1:])
+    E = int(row_ptr[-1])
+    col = rng.integers(0, V, E).astype(np.int32)
+    et = rng.integers(0, K, E).astype(np.int32)
+    h = torch.from_numpy(rng.standard_normal((V, H)).astype(np.float32))
+    A = torch.from_numpy((rng.standard_normal((K, H, H)) / np.sqrt(H)).astype(np.float32))
+    w = torch.from_numpy((rng.random(E) + 0.5).astype(np.float32)) if weighted else None
+    cot = torch.from_numpy(rng.standard_normal((V, H)).astype(np.float32))
+    dst = np.repeat(np.arange(V), deg)
+    hd, Ad = h.double().requires_grad_(need_dh), A.double().requires_grad_(True)
+    msg = torch.einsum("emn,en->em", Ad[et.astype(np.int64)], hd[col.astype(np.int64)])
+    if weighted:
+        msg = msg * w.double().unsqueeze(1)
+    ref = torch.zeros(V, H, dtype=torch.float64).index_add(0, torch.from_numpy(dst), msg)
+    gref = torch.autograd.grad((ref * cot.double()).sum(), [Ad] + ([hd] if need_dh else []))
+    t = lambda a: torch.from_numpy(a).to(dev)
+    g = MolGraph(t(row_ptr), t(col), None, t(et), torch.zeros(K, 1, device=dev),
+                 torch.tensor([0, V], dtype=torch.int32, device=dev))
+    hg, Ag = h.to(dev).requires_grad_(need_dh), A.to(dev).requires_grad_(True)
+    out = ops.message_aggregate(hg, Ag, g, w.to(dev) if weighted else None)
+    ggpu = torch.autograd.grad((out * cot.to(dev)).sum(), [Ag] + ([hg] if need_dh else []))
+    assert _rel(out.detach().cpu(), ref.detach()) < 1e-5
+    for a, b, name in zip(ggpu, gref, ("dA", "dh")):
+        assert _rel(a.cpu(), b) < 2e-5, (name, _rel(a.cpu(), b))
