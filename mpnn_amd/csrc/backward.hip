@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(512) edge_dA_direct64_kernel(const float* __re
                 const float* pb = h + (int64_t)s_r * F + i;
                 float a0 = pa[0], a1 = pa[32];
                 if (dst && w) {
-                    const float w_lo = __builtin_amdgcn_readlane(w_l, s), w_hi = __builtin_amdgcn_readlane(w_l, 16 + s);
+                    const float w_lo = readlane_f(w_l, s), w_hi = readlane_f(w_l, 16 + s);
                     const float w_r = hi ? w_hi : w_lo;
                     a0 *= w_r;
                     a1 *= w_r;
@@ -459,7 +459,7 @@ __global__ void __launch_bounds__(512) tn_direct_kernel(const float* __restrict_
                 const int b_r = hi ? __builtin_amdgcn_readlane(b_l, 16 + s) : __builtin_amdgcn_readlane(b_l, s);
                 const bool live = (hi ? 16 + s : s) < rows;
                 float av = Xa[(int64_t)a_r * lda + 32 * ai + i];
-                if (TYPED && dst && w) av *= hi ? __builtin_amdgcn_readlane(w_l, 16 + s) : __builtin_amdgcn_readlane(w_l, s);
+                if (TYPED && dst && w) av *= hi ? readlane_f(w_l, 16 + s) : readlane_f(w_l, s);
                 if (!live) av = 0.f;
                 const float* pb = Yb + (int64_t)b_r * ldb + 32 * bg + i;
                 const float* pg = nullptr;

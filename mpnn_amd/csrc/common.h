@@ -39,4 +39,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // holds element (row, col) = ((reg&3) + 8*(reg>>2) + 4*(lane>>5), lane&31).
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
+// v_readlane of a float: the builtin is typed int, so the value must travel as bits (a plain call would
+// value-convert, i.e. truncate)
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
 }  // namespace mpnn
