@@ -263,6 +263,19 @@ def lipo_model_forward(params, batch, steps=6, training=True, return_buffers=Fal
     return (out, buf) if return_buffers else out
 
 
+def att_model_forward(params, afm, bfm, adj, mask, steps, return_state=False):
+    """models/att_model.py:55-59: one AttEdgeNetwork PER STEP (modules mf0..mf{T-1}), AdjMsgAgg, GRU,
+    parameter-free MaskBatchNorm; message always from the original afm; readout on cat[state, afm]
+    (GraphLevelOutput here; the reference's default Set2Vec is outside the hot path)."""
+    ufp, ofp = sub(params, "uf."), sub(params, "of.")
+    h = afm
+    for i in range(steps):
+        pair = att_edge_network_pair(sub(params, "mf%d." % i), afm, bfm)
+        h = mask_bn(gru_update(ufp, agg_adj(pair, adj), h, mask), mask)
+    out = graph_level_output(ofp, torch.cat([h, afm], dim=-1), mask)
+    return (out, h) if return_state else out
+
+
 # ----------------------------------------------------------------------------- index oracle
 def dense_to_csr(adj):
     """Bit-exact index oracle: rows = b*N+i, columns = b*N+j, in adj.nonzero() order."""

@@ -1,0 +1,112 @@
+"""Model-level parity at the SHAPES of BASELINE.json's configs (hidden 64 / 128 / 128-attention / 256,
+their step counts, one-hot bond types), on batches small enough for the dense CPU oracle: forward,
+final node state, and gradients of every parameter through message + aggregate + update.
+
+The oracle itself is pinned by the reference-generated fixtures (tests/test_oracle_golden.py); these tests
+extend the comparison to widths the fixtures do not carry (they would be tens of MB)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import max_err
+from oracle import dense_ref as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _small_batch(H, mols, seed, dist="drug", max_atoms=None):
+    from mpnn_amd import synth
+    mb = synth.make_molecules(200, H, seed=seed, dist=dist)
+    ids = np.argsort(mb.n_atoms, kind="stable")[:mols] if max_atoms is None else \
+        np.nonzero(mb.n_atoms <= max_atoms)[0][:mols]
+    sub = synth.select(mb, ids)
+    return {k: torch.from_numpy(v) for k, v in synth.to_dense(sub).items()}
+
+
+def _rel(a, b):
+    return max_err(a, b) / max(1.0, float(torch.as_tensor(b).detach().abs().max()))
+
+
+def _shared_leaves(model):
+    """CPU copies of a module's parameters as autograd leaves, one per distinct tensor, keyed like state_dict."""
+    leaves, out = {}, {}
+    for k, v in model.state_dict(keep_vars=True).items():
+        if id(v) not in leaves:
+            leaves[id(v)] = v.detach().cpu().clone().requires_grad_(v.requires_grad and v.is_floating_point())
+        out[k] = leaves[id(v)]
+    return out
+
+
+@pytest.mark.parametrize("name,H,T,mols", [("c2", 64, 3, 6), ("c4", 128, 3, 4), ("c5", 256, 3, 2)])
+def test_basic_model_at_config_width(dev, name, H, T, mols):
+    from mpnn_amd.models.basic_model import BasicModel
+    from mpnn_amd.models.graph_model_wrapper import GraphWrapper
+    torch.manual_seed(317)
+    batch = _small_batch(H, mols, seed=317 + H, dist="skewed" if name == "c5" else "drug", max_atoms=30 if name == "c5" else None)
+    N = batch["adj"].shape[-1]
+    model = GraphWrapper(BasicModel(H, 4, H, N, 8, message_opts={}, agg_opts={}, update_opts={}, readout_opts={},
+                                    message_steps=T))
+    # biases away from zero so edge_map(0) != 0 takes part
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if "bias" in k:
+                p.uniform_(-0.1, 0.1)
+    params = _shared_leaves(model)
+    cot = torch.rand(mols, 8) - 0.5
+    ref, ref_state = O.basic_model_forward(O.sub(params, "graph_model."), batch["afm"], batch["bfm"], batch["adj"],
+                                           batch["mask"], T, True)
+    (ref * cot).sum().backward()
+    model = model.to(dev)
+    gb = {k: v.to(dev) for k, v in batch.items()}
+    out = model(gb)
+    state, _ = model.graph_model.message_passing(gb["afm"], gb["bfm"], gb["adj"], gb["mask"])
+    (out * cot.to(dev)).sum().backward()
+    assert _rel(state.detach().cpu(), ref_state) < 1e-5
+    assert _rel(out.detach().cpu(), ref) < 2e-5
+    checked = 0
+    for k, p in model.named_parameters():
+        g_ref = params[k].grad
+        if g_ref is None or p.grad is None:
+            continue
+        assert _rel(p.grad.cpu(), g_ref) < 2e-4, (k, _rel(p.grad.cpu(), g_ref))
+        checked += 1
+    assert checked >= 8
+
+
+def test_attention_model_at_c3_shape(dev):
+    """configs[2]: att_model (AttEdgeNetwork per step + AdjMsgAgg + GRU + MaskBatchNorm), hidden 128, 5 steps."""
+    from mpnn_amd.models.att_model import BasicModel as AttModel
+    H, T, mols = 128, 5, 4
+    torch.manual_seed(317)
+    batch = _small_batch(H, mols, seed=99)
+    N = batch["adj"].shape[-1]
+    model = AttModel(H, 4, H, N, 8, message_opts={}, agg_opts={}, update_opts={}, readout_opts={}, message_steps=T)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if "bias" in k:
+                p.uniform_(-0.1, 0.1)
+    params = _shared_leaves(model)
+    cot = torch.rand(mols, 8) - 0.5
+    ref, ref_state = O.att_model_forward(params, batch["afm"], batch["bfm"], batch["adj"], batch["mask"], T, True)
+    (ref * cot).sum().backward()
+    model = model.to(dev)
+    gb = {k: v.to(dev) for k, v in batch.items()}
+    out = model(gb["afm"], gb["bfm"], gb["adj"], gb["mask"])
+    state, _ = model.message_passing(gb["afm"], gb["bfm"], gb["adj"], gb["mask"])
+    (out * cot.to(dev)).sum().backward()
+    assert _rel(state.detach().cpu(), ref_state) < 2e-5
+    assert _rel(out.detach().cpu(), ref) < 5e-5
+    checked = 0
+    for k, p in model.named_parameters():
+        g_ref = params[k].grad
+        if g_ref is None or p.grad is None:
+            continue
+        assert _rel(p.grad.cpu(), g_ref) < 5e-4, (k, _rel(p.grad.cpu(), g_ref))
+        checked += 1
+    assert checked >= 20
