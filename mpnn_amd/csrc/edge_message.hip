@@ -153,8 +153,8 @@ __global__ void __launch_bounds__(256) edge_message_kernel(const float* __restri
 // BWD = false: msg[e] = A_k . (gate[e] * h[src(e)])       rows gathered by source atom, image = A_k
 // BWD = true : dx[e]  = A_k^T . dmsg[e]                   rows indexed by edge id,     image = A_k^T
 //              (`h` is dmsg, `mf` the OUTPUT width nf_x, A_k is (NF, mf) read transposed)
-template <int NF, int NB, bool BWD>
-__global__ void __launch_bounds__(512) edge_message_resident_kernel(
+template <int NF, int NB, bool BWD, bool GATED>
+__global__ void __launch_bounds__(256, GATED ? 4 : 5) edge_message_resident_kernel(
     const float* __restrict__ h, const float* __restrict__ A, const int32_t* __restrict__ src,
     const int32_t* __restrict__ order, const int32_t* __restrict__ type_ptr, const float* __restrict__ gate,
     float* __restrict__ msg, int K, int mf) {
@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(512) edge_message_resident_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int r = lane & 31, hi = lane >> 5;
-    const int gw = blockIdx.x * 8 + wv, nw = gridDim.x * 8;
+    const int gw = blockIdx.x * 4 + wv, nw = gridDim.x * 4;
 
     for (int k = 0; k < K; ++k) {
         const int tb = type_ptr[k], te = type_ptr[k + 1];
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(512) edge_message_resident_kernel(
         __syncthreads();                                // everyone is done with the previous matrix
         const float* Ak = A + (int64_t)k * mf * NF;
         if (!BWD) {
-            for (int idx = tid; idx < 32 * NB * (NF / 4); idx += 512) {
+            for (int idx = tid; idx < 32 * NB * (NF / 4); idx += 256) {
                 const int n = idx / (NF / 4), q = idx % (NF / 4);
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (n < mf) v = *reinterpret_cast<const f32x4*>(Ak + (int64_t)n * NF + 4 * q);
@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(512) edge_message_resident_kernel(
             }
         } else {
             // A_k is (NF rows a) x (mf cols b); image As[b][a] = A_k[a][b]  (once per type per block)
-            for (int idx = tid; idx < NF * 32 * NB; idx += 512) {
+            for (int idx = tid; idx < NF * 32 * NB; idx += 256) {
                 const int a = idx / (32 * NB), b = idx % (32 * NB);
                 As[b * LD + a] = (b < mf) ? Ak[(int64_t)a * mf + b] : 0.f;
             }
@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(512) edge_message_resident_kernel(
             const float* p = h + (int64_t)s_row * NF + hi * (NF / 2);
 #pragma unroll
             for (int q = 0; q < NF4; ++q) f[q] = *reinterpret_cast<const f32x4*>(p + 4 * q);
-            if (gate) {
+            if (GATED) {
                 const float* g = gate + (int64_t)e_row * NF + hi * (NF / 2);
 #pragma unroll
                 for (int q = 0; q < NF4; ++q) f[q] *= *reinterpret_cast<const f32x4*>(g + 4 * q);
@@ -210,14 +210,15 @@ __global__ void __launch_bounds__(512) edge_message_resident_kernel(
         auto src_of = [&](int e) { return BWD ? e : src[e]; };
         int e_cur = edge_of(t);
         int s_cur = src_of(e_cur);
-        f32x4 f_cur[NF4], f_nxt[NF4];
-        load_rows(s_cur, e_cur, f_cur);
+        f32x4 f_cur[NF4];
         int e_nxt = e_cur, s_nxt = s_cur;
         if (t + nw < tiles) { e_nxt = edge_of(t + nw); s_nxt = src_of(e_nxt); }
 
+        // No register prefetch of the next tile's rows: at <= 80 VGPRs six waves share a SIMD and hide each other's
+        // gather latency; only the two-deep index chain (order -> src) is fetched ahead.
         for (; t < tiles; t += nw) {
-            const bool has1 = t + nw < tiles, has2 = t + 2 * nw < tiles;
-            if (has1) load_rows(s_nxt, e_nxt, f_nxt);            // next tile's rows: in flight under the MFMAs
+            const bool has2 = t + 2 * nw < tiles;
+            load_rows(s_cur, e_cur, f_cur);
             int e_nn = e_nxt;
             if (has2) e_nn = edge_of(t + 2 * nw);
 
@@ -227,16 +228,21 @@ __global__ void __launch_bounds__(512) edge_message_resident_kernel(
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
             const float* xb = As + r * LD + hi * (NF / 2);
+            // B fragments double-buffered by hand; the scheduling barriers keep the compiler from hoisting all
+            // NF4*NB LDS reads above the MFMAs (which costs ~100 registers and an occupancy step)
 #pragma unroll
             for (int q = 0; q < NF4; ++q) {
+                f32x4 bq[NB];
+#pragma unroll
+                for (int n = 0; n < NB; ++n) bq[n] = *reinterpret_cast<const f32x4*>(xb + 32 * n * LD + 4 * q);
 #pragma unroll
                 for (int n = 0; n < NB; ++n) {
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(xb + 32 * n * LD + 4 * q);
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f_cur[q].x, b.x, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f_cur[q].y, b.y, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f_cur[q].z, b.z, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f_cur[q].w, b.w, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f_cur[q].x, bq[n].x, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f_cur[q].y, bq[n].y, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f_cur[q].z, bq[n].z, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f_cur[q].w, bq[n].w, acc[n], 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
             int s_nn = s_nxt;
             if (has2) s_nn = src_of(e_nn);                       // index of the tile after next
@@ -253,13 +259,12 @@ __global__ void __launch_bounds__(512) edge_message_resident_kernel(
                         if (col < mf) __builtin_nontemporal_store(acc[n][i], msg + (int64_t)e_row * mf + col);   // write-once stream
                     }
                 }
+                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
             e_cur = e_nxt;
             s_cur = s_nxt;
             e_nxt = e_nn;
             s_nxt = s_nn;
-#pragma unroll
-            for (int q = 0; q < NF4; ++q) f_cur[q] = f_nxt[q];
         }
     }
 }
@@ -269,18 +274,16 @@ static int launch_message_resident(const float* h, const float* A, const int32_t
                                    const int32_t* type_ptr, const float* gate, float* msg, int64_t E, int K, int mf,
                                    hipStream_t s) {
     const size_t lds = (size_t)32 * NB * (NF + 4) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done && lds > 48 * 1024) {
-        (void)hipFuncSetAttribute((const void*)edge_message_resident_kernel<NF, NB, BWD>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
-    int64_t blocks = 512;                                   // 2 blocks of 8 waves per CU
-    const int64_t need = ceil_div(ceil_div(E, 32) + K, 8);
+    int64_t blocks = gate ? 1024 : 1280;                    // 4-wave blocks: 5 per CU ungated (<= 96 VGPRs), 4 gated
+    const int64_t need = ceil_div(ceil_div(E, 32) + K, 4);
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((edge_message_resident_kernel<NF, NB, BWD>), dim3((unsigned)blocks), dim3(512), lds, s, h, A, src,
-                       order, type_ptr, gate, msg, K, mf);
+    if (gate)
+        hipLaunchKernelGGL((edge_message_resident_kernel<NF, NB, BWD, true>), dim3((unsigned)blocks), dim3(256), lds, s, h,
+                           A, src, order, type_ptr, gate, msg, K, mf);
+    else
+        hipLaunchKernelGGL((edge_message_resident_kernel<NF, NB, BWD, false>), dim3((unsigned)blocks), dim3(256), lds, s,
+                           h, A, src, order, type_ptr, gate, msg, K, mf);
     return launch_status("mpnn_edge_message_f32(resident)");
 }
 
