@@ -8,6 +8,9 @@
 //                  - dA[k]  = sum_{e of type k} dmsg[e] (x) (gate[e]*h[src e])
 //                  - dW_ih  = m^T dgi, dW_hh = h^T dgh, db = column sums of dgi / dgh
 // plus the elementwise gate-gradient kernel of the GRU.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 
 namespace mpnn {
@@ -529,6 +532,9 @@ __global__ void __launch_bounds__(256) gru_gate_grad_kernel(const float* __restr
 // resident-matrix dx path (edge_message.hip); returns 1 when the shape is not covered
 int launch_message_dx_resident(const float* dmsg, const float* A, const int32_t* order, const int32_t* type_ptr,
                                float* dx, int64_t E, int K, int nf, int mf, hipStream_t s);
+// H = 128: dm / dh on the bf16x6 column-sliced kernel (gru_bwd128.hip)
+int launch_gru_bwd_dx128(const float* ws, const float* W_ih, const float* W_hh, float* dm, float* dh, int64_t V,
+                         hipStream_t s);
 // fused H = 64 path (gru_bwd.hip)
 int launch_gru_bwd_fused64(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
                            const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
@@ -610,14 +616,20 @@ extern "C" int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const 
     hipLaunchKernelGGL(gru_gate_grad_kernel, dim3((unsigned)g), dim3(256), 0, s, dout, h, mask, saved, ws, dh, V, H);
     int rc = launch_status("mpnn_gru_update_bwd_f32(gates)");
     if (rc) return rc;
-    // dm = dgi . W_ih^T : B given as [n = input feature][k = gate column], ld 3H
-    rc = launch_rows_gemm<true, false>(ws, 6 * H, nullptr, nullptr, 0, W_ih, 0, 3 * H, nullptr, dm, H, V, 3 * H, H, s,
-                                       "mpnn_gru_update_bwd_f32(dm)");
-    if (rc) return rc;
-    // dh = dgh . W_hh^T + dout*mask*z   (the direct term already sits in dh)
-    rc = launch_rows_gemm<true, false>(ws + 3 * H, 6 * H, nullptr, nullptr, 0, W_hh, 0, 3 * H, dh, dh, H, V, 3 * H, H, s,
-                                       "mpnn_gru_update_bwd_f32(dh)");
-    if (rc) return rc;
+    static const bool fp32_only = getenv("MPNN_GRU_MATH") && !strcmp(getenv("MPNN_GRU_MATH"), "fp32");
+    if (H == 128 && !fp32_only) {
+        rc = launch_gru_bwd_dx128(ws, W_ih, W_hh, dm, dh, V, s);
+        if (rc) return rc;
+    } else {
+        // dm = dgi . W_ih^T : B given as [n = input feature][k = gate column], ld 3H
+        rc = launch_rows_gemm<true, false>(ws, 6 * H, nullptr, nullptr, 0, W_ih, 0, 3 * H, nullptr, dm, H, V, 3 * H, H,
+                                           s, "mpnn_gru_update_bwd_f32(dm)");
+        if (rc) return rc;
+        // dh = dgh . W_hh^T + dout*mask*z   (the direct term already sits in dh)
+        rc = launch_rows_gemm<true, false>(ws + 3 * H, 6 * H, nullptr, nullptr, 0, W_hh, 0, 3 * H, dh, dh, H, V, 3 * H,
+                                           H, s, "mpnn_gru_update_bwd_f32(dh)");
+        if (rc) return rc;
+    }
     if (H == 128) {
         // dW (128 x 384) and db on the register-direct wide kernel: 8 waves = 4 a-blocks x 2 groups of 6 b-blocks
         int64_t gxd = 512;

@@ -1,0 +1,136 @@
+// Backward of the masked GRU update at hidden width 128: the two GEMM families on the bf16 matrix pipe with
+// 3-way operand splitting (split_math.h), reading the pre-activation gradients the gate-gradient kernel wrote
+// (backward.hip: ws[row] = [dar daz dan | dar daz dnh], 6H floats).
+//
+//   gru_bwd_dx128_kernel   dm = dgi W_ih^T,  dh = dgh W_hh^T + (dout*mask*z already in dh)
+//
+// The fused single-kernel arrangement of gru_bwd.hip does not carry over: at H = 128 the split images of one
+// weight matrix are 295 KB, so the weights are sliced by OUTPUT column (32 columns of dm and of dh per block =
+// 32 rows of each matrix, 144 KB of LDS) exactly like the forward kernel (gru_split.hip, H = 128), four blocks
+// per row tile placed on one XCD, and the contraction rows (the gate gradients) stream through a register ring.
+#include "split_math.h"
+
+namespace mpnn {
+
+__global__ void __launch_bounds__(512) gru_bwd_dx128_kernel(const float* __restrict__ ws, const float* __restrict__ W_ih,
+                                                            const float* __restrict__ W_hh, float* __restrict__ dm,
+                                                            float* __restrict__ dh, int64_t V) {
+    constexpr int H = 128, LDW = 6 * H, KC = 3 * H;
+    constexpr int ROWB = 2 * KC;               // one image row = one weight row (3H gate columns) in bf16
+    constexpr int IMG = 32 * ROWB;             // one (matrix, piece) image: 32 output columns
+    constexpr int NW = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 matrices][3 pieces][32][384] bf16
+
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int slice = jb & 3;
+    const int pblock = (jb >> 2) * 8 + xcd, pblocks = gridDim.x >> 2;
+    const int c0 = slice * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    // image[mat][piece][n][k] = W_mat[c0 + n][k]: the weight rows as they lie in memory, 16-byte chunks
+    // XOR-swizzled by the row (rows are 192 dwords apart = the same bank)
+    for (int idx = tid; idx < 2 * 32 * (KC / 4); idx += 64 * NW) {
+        const int mat = idx / (32 * (KC / 4));
+        const int rem = idx % (32 * (KC / 4));
+        const int n = rem / (KC / 4), q = rem % (KC / 4);
+        const float* W = mat == 0 ? W_ih : W_hh;
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(W + (int64_t)(c0 + n) * KC + 4 * q);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = 4 * q + u;
+            __bf16 ph, pm, pl;
+            split3(w4[u], ph, pm, pl);
+            const int off = n * ROWB + (((k >> 3) ^ (n & 15)) << 4) + ((k & 7) << 1);
+            *reinterpret_cast<__bf16*>(smem + (mat * 3 + 0) * IMG + off) = ph;
+            *reinterpret_cast<__bf16*>(smem + (mat * 3 + 1) * IMG + off) = pm;
+            *reinterpret_cast<__bf16*>(smem + (mat * 3 + 2) * IMG + off) = pl;
+        }
+    }
+    __syncthreads();
+
+    const int r = lane & 31, hi = lane >> 5;
+    const int64_t tiles = (V + 31) / 32;
+    const int64_t stride = (int64_t)pblocks * NW;
+    int64_t t = (int64_t)pblock * NW + wv;
+    if (t >= tiles) return;
+
+    // chunk c (0..15) of a tile: gradient segment g = c >> 2 (dar, daz, dan, dnh), 16 floats at 16*(c&3) of the
+    // lane half's 64 floats of that segment.  K index inside the weight row: gate block (g, or 2 for dnh).
+    f32x4 ring[4][4];
+    auto load_chunk = [&](int64_t tile, int c, f32x4 (&f)[4]) {
+        int64_t row = tile * 32 + r;
+        if (row >= V) row = V - 1;
+        const int g = c >> 2;
+        const float* p = ws + row * LDW + (g == 3 ? 5 * H : g * H) + hi * (H / 2) + 16 * (c & 3);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f[q] = *reinterpret_cast<const f32x4*>(p + 4 * q);
+    };
+    auto bfrag = [&](int mat, int piece, int chunk) {
+        return *reinterpret_cast<const bf16x8*>(smem + (mat * 3 + piece) * IMG + r * ROWB + ((chunk ^ (r & 15)) << 4));
+    };
+
+    load_chunk(t, 0, ring[0]);
+    load_chunk(t, 1, ring[1]);
+    load_chunk(t, 2, ring[2]);
+    for (; t < tiles; t += stride) {
+        const int64_t tn = t + stride < tiles ? t + stride : t;
+        f32x16 d_m, d_h;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { d_m[i] = 0.f; d_h[i] = 0.f; }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            if (c + 3 < 16) load_chunk(t, c + 3, ring[(c + 3) & 3]);
+            else load_chunk(tn, c + 3 - 16, ring[(c + 3) & 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int g = c >> 2;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 ah, am, al;
+                split8(ring[c & 3][2 * s2], ring[c & 3][2 * s2 + 1], ah, am, al);
+                const int chunk = 16 * (g == 3 ? 2 : g) + 8 * hi + 2 * (c & 3) + s2;
+                if (g != 3) mma6(d_m, ah, am, al, bfrag(0, 0, chunk), bfrag(0, 1, chunk), bfrag(0, 2, chunk));
+                if (g != 2) mma6(d_h, ah, am, al, bfrag(1, 0, chunk), bfrag(1, 1, chunk), bfrag(1, 2, chunk));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        const int col = c0 + r;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            float prev[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int64_t row = t * 32 + 8 * g4 + 4 * hi + u;
+                if (row >= V) row = V - 1;
+                prev[u] = dh[row * H + col];                      // dout*mask*z from the gate-gradient kernel
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = 4 * g4 + u;
+                const int64_t row = t * 32 + 8 * g4 + 4 * hi + u;
+                if (row < V) {
+                    dm[row * H + col] = d_m[i];
+                    dh[row * H + col] = d_h[i] + prev[u];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+int launch_gru_bwd_dx128(const float* ws, const float* W_ih, const float* W_hh, float* dm, float* dh, int64_t V,
+                         hipStream_t s) {
+    const size_t lds = (size_t)2 * 3 * 32 * (2 * 3 * 128);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gru_bwd_dx128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int64_t tiles = (V + 31) / 32;
+    int64_t pblocks = 64;                                   // x 4 slices = one block per CU
+    if (pblocks * 8 > tiles) pblocks = (tiles + 7) / 8;
+    pblocks = (pblocks + 7) / 8 * 8;
+    hipLaunchKernelGGL(gru_bwd_dx128_kernel, dim3((unsigned)(pblocks * 4)), dim3(512), lds, s, ws, W_ih, W_hh, dm, dh, V);
+    return launch_status("mpnn_gru_update_bwd_f32(dx, H=128)");
+}
+
+}  // namespace mpnn
