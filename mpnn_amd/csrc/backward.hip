@@ -535,6 +535,8 @@ int launch_message_dx_resident(const float* dmsg, const float* A, const int32_t*
 // H = 128: dm / dh on the bf16x6 column-sliced kernel (gru_bwd128.hip)
 int launch_gru_bwd_dx128(const float* ws, const float* W_ih, const float* W_hh, float* dm, float* dh, int64_t V,
                          hipStream_t s);
+int launch_gru_bwd_dw128(const float* m, const float* h, const float* ws, float* dW_ih, float* dW_hh, float* db_ih,
+                         float* db_hh, int64_t V, hipStream_t s);
 // fused H = 64 path (gru_bwd.hip)
 int launch_gru_bwd_fused64(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
                            const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
@@ -630,6 +632,7 @@ extern "C" int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const 
                                            H, s, "mpnn_gru_update_bwd_f32(dh)");
         if (rc) return rc;
     }
+    if (H == 128 && !fp32_only) return launch_gru_bwd_dw128(m, h, ws, dW_ih, dW_hh, db_ih, db_hh, V, s);
     if (H == 128) {
         // dW (128 x 384) and db on the register-direct wide kernel: 8 waves = 4 a-blocks x 2 groups of 6 b-blocks
         int64_t gxd = 512;

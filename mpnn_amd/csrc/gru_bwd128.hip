@@ -133,4 +133,132 @@ int launch_gru_bwd_dx128(const float* ws, const float* W_ih, const float* W_hh, 
     return launch_status("mpnn_gru_update_bwd_f32(dx, H=128)");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+//   gru_bwd_dw128_kernel   dW_ih = m^T dgi, db_ih = colsum(dgi)   (blockIdx.y = 0)
+//                          dW_hh = h^T dgh, db_hh = colsum(dgh)   (blockIdx.y = 1)
+// The contraction runs over ATOMS, so an MFMA fragment is 8 consecutive atoms of one column.  A thread owns one
+// of the 512 columns [X (128) | G (384)] of the step's 16 atoms: its 2 x 8 coalesced dword loads ARE two
+// fragments; it splits them once and parks the three bf16 pieces in LDS ([piece][octet][column] 16-byte slots,
+// conflict-free both ways), double-buffered, one barrier per 16-atom step.  The 8 waves then share the step:
+// wave = (a-pair, b-triple) owns 2 x 3 of the 4 x 12 output tiles, 36 MFMAs per step, accumulators live in
+// registers for the whole kernel and are flushed with one atomic pass.
+__global__ void __launch_bounds__(512) gru_bwd_dw128_kernel(const float* __restrict__ m, const float* __restrict__ h,
+                                                            const float* __restrict__ ws, float* dW_ih, float* dW_hh,
+                                                            float* db_ih, float* db_hh, int64_t V) {
+    constexpr int H = 128, LDW = 6 * H, NC = 4 * H;        // 512 staged columns
+    constexpr int SLOT = NC * 16;                          // bytes of one (piece, octet) plane
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][3 pieces][2 octets][512][8] bf16
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, hi = lane >> 5;
+    const int mat = blockIdx.y;
+    const float* X = mat == 0 ? m : h;
+    // this thread's column of the staged tile and where it lives in global memory
+    const float* colp = tid < H ? X + tid : ws + mat * 3 * H + (tid - H);
+    const int64_t ldc = tid < H ? H : LDW;
+    const int ag = wv & 1, bg = wv >> 1;
+
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+    float colsum = 0.f;
+
+    const int64_t steps = (V + 15) / 16;
+    float raw[16];
+    auto load_raw = [&](int64_t st) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            int64_t row = st * 16 + u;
+            const bool ok = row < V;
+            if (!ok) row = V - 1;
+            const float v = colp[row * ldc];
+            raw[u] = ok ? v : 0.f;
+        }
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const f32x4 x0 = {raw[8 * o], raw[8 * o + 1], raw[8 * o + 2], raw[8 * o + 3]};
+            const f32x4 x1 = {raw[8 * o + 4], raw[8 * o + 5], raw[8 * o + 6], raw[8 * o + 7]};
+            bf16x8 ph, pm, pl;
+            split8(x0, x1, ph, pm, pl);
+            char* base = smem + (size_t)buf * 6 * SLOT + o * SLOT + tid * 16;
+            *reinterpret_cast<bf16x8*>(base) = ph;
+            *reinterpret_cast<bf16x8*>(base + 2 * SLOT) = pm;
+            *reinterpret_cast<bf16x8*>(base + 4 * SLOT) = pl;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) colsum += raw[u];
+    };
+    auto frag = [&](int buf, int piece, int col) {
+        return *reinterpret_cast<const bf16x8*>(smem + (size_t)buf * 6 * SLOT + (piece * 2 + hi) * SLOT + col * 16);
+    };
+
+    int64_t st = blockIdx.x;
+    int cur = 0;
+    if (st < steps) {
+        load_raw(st);
+        park(0);
+    }
+    for (; st < steps; st += gridDim.x) {
+        __syncthreads();                                   // buffer `cur` is complete, `cur^1` is free
+        const bool more = st + gridDim.x < steps;
+        if (more) load_raw(st + gridDim.x);
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 bh[3], bm[3], bl[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int col = H + 32 * (3 * bg + b) + i;
+            bh[b] = frag(cur, 0, col);
+            bm[b] = frag(cur, 1, col);
+            bl[b] = frag(cur, 2, col);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int col = 32 * (2 * ag + a) + i;
+            const bf16x8 ah = frag(cur, 0, col), am = frag(cur, 1, col), al = frag(cur, 2, col);
+#pragma unroll
+            for (int b = 0; b < 3; ++b) mma6(acc[a][b], ah, am, al, bh[b], bm[b], bl[b]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) park(cur ^ 1);
+        cur ^= 1;
+    }
+
+    float* dW = mat == 0 ? dW_ih : dW_hh;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int col = 32 * (3 * bg + b) + i;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = 32 * (2 * ag + a) + acc_row(q, lane);
+                atomicAdd(dW + (int64_t)row * 3 * H + col, acc[a][b][q]);
+            }
+        }
+    if (tid >= H && blockIdx.x < steps) atomicAdd((mat == 0 ? db_ih : db_hh) + (tid - H), colsum);
+}
+
+int launch_gru_bwd_dw128(const float* m, const float* h, const float* ws, float* dW_ih, float* dW_hh, float* db_ih,
+                         float* db_hh, int64_t V, hipStream_t s) {
+    const size_t lds = (size_t)2 * 3 * 2 * 512 * 16;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gru_bwd_dw128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int64_t steps = (V + 15) / 16;
+    int64_t gx = 128;                                       // x 2 matrices = one block per CU (96 KB of LDS)
+    if (gx > steps) gx = steps;
+    hipLaunchKernelGGL(gru_bwd_dw128_kernel, dim3((unsigned)gx, 2), dim3(512), lds, s, m, h, ws, dW_ih, dW_hh, db_ih,
+                       db_hh, V);
+    return launch_status("mpnn_gru_update_bwd_f32(dW, H=128)");
+}
+
 }  // namespace mpnn
