@@ -12,6 +12,9 @@
 //   Bs[n][k]  A_k[n][k]      (A_k is stored (mf, nf) row-major == already "n-major, k-contiguous")
 // Lane (r = lane&31, hi = lane>>5) of the MFMA supplies k = hi*KC/2 + s for step s, so a lane
 // reads 4 consecutive k (one b128) per 4 MFMAs.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 
 namespace mpnn {
@@ -292,9 +295,21 @@ static size_t message_lds_bytes(int nb) {
 }
 
 // dx[e] = A_type(e)^T dmsg[e] on the resident-matrix kernel; returns 1 when the shape has no fast path
+// nf = mf = 128 on the bf16x6 pipe (edge_message128.hip)
+int launch_message_split128(const float* h, const float* A, const int32_t* src, const int32_t* order,
+                            const int32_t* type_ptr, const float* gate, float* msg, int64_t E, int K, hipStream_t s);
+int launch_message_dx_split128(const float* dmsg, const float* A, const int32_t* order, const int32_t* type_ptr,
+                               float* dx, int64_t E, int K, hipStream_t s);
+
+static bool fp32_only() {
+    static const bool v = getenv("MPNN_GRU_MATH") && !strcmp(getenv("MPNN_GRU_MATH"), "fp32");
+    return v;
+}
+
 int launch_message_dx_resident(const float* dmsg, const float* A, const int32_t* order, const int32_t* type_ptr,
                                float* dx, int64_t E, int K, int nf, int mf, hipStream_t s) {
     if (K > 64) return 1;
+    if (mf == 128 && nf == 128 && !fp32_only()) return launch_message_dx_split128(dmsg, A, order, type_ptr, dx, E, K, s);
     if (mf == 64 && nf == 64)
         return launch_message_resident<64, 2, true>(dmsg, A, nullptr, order, type_ptr, nullptr, dx, E, K, nf, s);
     if (mf == 32 && nf == 32)
@@ -327,6 +342,7 @@ extern "C" int mpnn_edge_message_f32(const float* h, const float* A, const int32
         if (nf == 64 && nb == 2) return launch_message_resident<64, 2, false>(h, A, src, order, type_ptr, gate, msg, E, K, mf, st);
         if (nf == 64 && nb == 1) return launch_message_resident<64, 1, false>(h, A, src, order, type_ptr, gate, msg, E, K, mf, st);
         if (nf == 32 && nb == 1) return launch_message_resident<32, 1, false>(h, A, src, order, type_ptr, gate, msg, E, K, mf, st);
+        if (nf == 128 && mf == 128 && !fp32_only()) return launch_message_split128(h, A, src, order, type_ptr, gate, msg, E, K, st);
     }
     const int64_t tiles = ceil_div(E, kTileEdges) + K;   // upper bound; surplus blocks exit at once
     const dim3 grid((unsigned)tiles), block(256);
