@@ -537,6 +537,14 @@ int launch_gru_bwd_dx128(const float* ws, const float* W_ih, const float* W_hh, 
                          hipStream_t s);
 int launch_gru_bwd_dw128(const float* m, const float* h, const float* ws, float* dW_ih, float* dW_hh, float* db_ih,
                          float* db_hh, int64_t V, hipStream_t s);
+// nf = mf = 128 weight gradient on the bf16x6 pipe (edge_da128.hip)
+int launch_edge_da_split128(const float* Y, const float* h, const int32_t* src, const int32_t* dst, const float* w,
+                            const int32_t* order, const int32_t* type_ptr, const float* gate, float* dA, int64_t E,
+                            int K, hipStream_t s);
+static bool math_fp32_only() {
+    static const bool v = getenv("MPNN_GRU_MATH") && !strcmp(getenv("MPNN_GRU_MATH"), "fp32");
+    return v;
+}
 // fused H = 64 path (gru_bwd.hip)
 int launch_gru_bwd_fused64(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
                            const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
@@ -572,6 +580,8 @@ extern "C" int mpnn_edge_message_bwd_f32(const float* h, const float* A, const i
         hipLaunchKernelGGL(edge_dA_direct64_kernel, dim3((unsigned)gx), dim3(512), 0, s, dmsg, h, src, order, type_ptr,
                            gate, dA, K, (const int32_t*)nullptr, (const float*)nullptr);
         rc = launch_status("mpnn_edge_message_bwd_f32(dA direct)");
+    } else if (dA && mf == 128 && nf == 128 && K <= 64 && !math_fp32_only()) {
+        rc = launch_edge_da_split128(dmsg, h, src, nullptr, nullptr, order, type_ptr, gate, dA, E, K, s);
     } else if (dA && mf == 128 && nf == 128 && K <= 64) {
         int64_t gx = 512;
         const int64_t need = ceil_div(E, 32) + K;
@@ -667,6 +677,8 @@ extern "C" int mpnn_edge_message_agg_bwd_da_f32(const float* dagg, const float* 
     if (E == 0) return MPNN_OK;
     MPNN_REQUIRE(dagg && h && src && dst && order && type_ptr && dA && K > 0,
                  "mpnn_edge_message_agg_bwd_da_f32: NULL buffer");
+    if (nf == 128 && !math_fp32_only())
+        return launch_edge_da_split128(dagg, h, src, dst, w, order, type_ptr, gate, dA, E, K, (hipStream_t)stream);
     if (nf == 128) {
         int64_t gx = 512;
         const int64_t need = ceil_div(E, 32) + K;

@@ -1,0 +1,168 @@
+// Weight gradient of the typed edge message at nf = mf = 128 on the bf16 matrix pipe (3-way operand splitting):
+//   dA[k][a][b] += sum_{e in type k}  y[e][a] * x[e][b],   y[e] = w[e] * Y[arow(e)],  x[e] = gate[e] * h[src(e)]
+// arow(e) = dst[e] (Y = d(aggregate), the fused message+aggregate backward) or e (Y = dmsg).
+//
+// The contraction runs over EDGES, so an MFMA fragment is 8 consecutive edges of one column.  As in
+// gru_bwd_dw128_kernel a thread owns one of the 256 columns [y (128) | x (128)] of half of the step's 32 edges:
+// its 16 gathered dword loads (coalesced across the wave: same row, consecutive columns) are two fragments, split
+// once and parked in LDS as bf16 pieces ([piece][octet][column] 16-byte slots), double-buffered, one barrier per
+// 32-edge step.  Wave (a, b-pair) owns 2 of the 4 x 4 output tiles; accumulators are flushed once per type.
+#include "split_math.h"
+
+namespace mpnn {
+
+template <bool HAS_DST, bool HAS_W, bool GATED>
+__global__ void __launch_bounds__(512) edge_da_split128_kernel(
+    const float* __restrict__ Y, const float* __restrict__ h, const int32_t* __restrict__ src,
+    const int32_t* __restrict__ dst, const float* __restrict__ w, const int32_t* __restrict__ order,
+    const int32_t* __restrict__ type_ptr, const float* __restrict__ gate, float* dA, int K) {
+    constexpr int F = 128;
+    constexpr int SLOT = 256 * 16;                         // bytes of one (piece, octet) plane
+    constexpr int BUF = 12 * SLOT;                         // 3 pieces x 4 octets
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, hi = lane >> 5;
+    const int col = tid & 255;                             // staged column: < 128 = y, else x
+    const int og = wv >> 2;                                // which 16 of the step's 32 edges this thread stages
+    const bool is_y = (wv & 2) == 0;                       // wave-uniform
+    const int fcol = col & 127;
+    const int ta = wv & 3, tb2 = wv >> 2;                  // output tiles (ta, 2*tb2) and (ta, 2*tb2 + 1)
+
+    f32x16 acc[2];
+    float raw0[16], raw1[16], aux0[16], aux1[16];
+    for (int k = 0; k < K; ++k) {
+        const int tb = type_ptr[k], te = type_ptr[k + 1];
+        if (te == tb) continue;
+        const int steps = (te - tb + 31) / 32;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[b][q] = 0.f;
+
+        // The step's edge ids are wave-uniform, so order / dst / src / w come through the scalar cache.  Everything
+        // in the fetch is branch-free (flags are template parameters, the y / x role is one wave-uniform branch
+        // around the whole body): a per-element branch makes the compiler wait for each load before the next one.
+        // Masking and the w / gate factors are applied when the step is parked, so nothing waits at issue time.
+        // Data is fetched TWO steps ahead (raw0 / raw1 alternate).
+        auto load_raw = [&](int st, float (&raw)[16], float (&aux)[16]) {
+            const int p0 = tb + 32 * st + 16 * og;
+            int e[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) e[u] = order[p0 + u < te ? p0 + u : tb];
+            if (is_y) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int row = HAS_DST ? dst[e[u]] : e[u];
+                    raw[u] = Y[(int64_t)row * F + fcol];
+                    aux[u] = HAS_W ? w[e[u]] : 1.0f;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    raw[u] = h[(int64_t)src[e[u]] * F + fcol];
+                    aux[u] = GATED ? gate[(int64_t)e[u] * F + fcol] : 1.0f;
+                }
+            }
+        };
+        auto park = [&](int buf, int st, const float (&raw)[16], const float (&aux)[16]) {
+            const int p0 = tb + 32 * st + 16 * og;
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                f32x4 x0, x1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int u0 = 8 * o + j, u1 = 8 * o + 4 + j;
+                    float v0 = raw[u0], v1 = raw[u1];
+                    if (HAS_W || GATED) { v0 *= aux[u0]; v1 *= aux[u1]; }
+                    x0[j] = p0 + u0 < te ? v0 : 0.f;
+                    x1[j] = p0 + u1 < te ? v1 : 0.f;
+                }
+                bf16x8 ph, pm, pl;
+                split8(x0, x1, ph, pm, pl);
+                char* base = smem + buf * BUF + (2 * og + o) * SLOT + col * 16;
+                *reinterpret_cast<bf16x8*>(base) = ph;
+                *reinterpret_cast<bf16x8*>(base + 4 * SLOT) = pm;
+                *reinterpret_cast<bf16x8*>(base + 8 * SLOT) = pl;
+            }
+        };
+        auto frag = [&](int buf, int piece, int octet, int c) {
+            return *reinterpret_cast<const bf16x8*>(smem + buf * BUF + (piece * 4 + octet) * SLOT + c * 16);
+        };
+
+        int st = blockIdx.x;
+        const int g = gridDim.x;
+        int cur = 0;
+        __syncthreads();                                    // the previous type's last buffer is no longer read
+        if (st < steps) {
+            load_raw(st, raw0, aux0);
+            park(0, st, raw0, aux0);
+            if (st + g < steps) load_raw(st + g, raw0, aux0);
+        }
+        // one step: fetch step st+2g into `rin`, multiply step st out of LDS, park step st+g (already in `rout`)
+        auto step = [&](int st_now, float (&rout)[16], float (&aout)[16], float (&rin)[16], float (&ain)[16]) {
+            __syncthreads();
+            if (st_now + 2 * g < steps) load_raw(st_now + 2 * g, rin, ain);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int oc = 2 * ks + hi;
+                const int ca = 32 * ta + i;
+                const bf16x8 ah = frag(cur, 0, oc, ca), am = frag(cur, 1, oc, ca), al = frag(cur, 2, oc, ca);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int cb = 128 + 32 * (2 * tb2 + b) + i;
+                    mma6(acc[b], ah, am, al, frag(cur, 0, oc, cb), frag(cur, 1, oc, cb), frag(cur, 2, oc, cb));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (st_now + g < steps) park(cur ^ 1, st_now + g, rout, aout);
+            cur ^= 1;
+        };
+        for (; st < steps; st += 2 * g) {
+            step(st, raw0, aux0, raw1, aux1);
+            if (st + g < steps) step(st + g, raw1, aux1, raw0, aux0);
+        }
+        if ((int)blockIdx.x < steps) {
+            float* out = dA + (int64_t)k * F * F;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int c = 32 * (2 * tb2 + b) + i;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float v = acc[b][q];
+                    if (v != 0.f) atomicAdd(out + (int64_t)(32 * ta + acc_row(q, lane)) * F + c, v);
+                }
+            }
+        }
+    }
+}
+
+int launch_edge_da_split128(const float* Y, const float* h, const int32_t* src, const int32_t* dst, const float* w,
+                            const int32_t* order, const int32_t* type_ptr, const float* gate, float* dA, int64_t E,
+                            int K, hipStream_t s) {
+    const size_t lds = (size_t)2 * 12 * 256 * 16;
+    int64_t gx = 256;                                       // one block per CU (96 KB of LDS)
+    const int64_t need = ceil_div(E, 32) + K;
+    if (gx > need) gx = need;
+#define MPNN_DA128(D, W, G)                                                                                         \
+    do {                                                                                                            \
+        static bool attr_done = false;                                                                              \
+        if (!attr_done) {                                                                                           \
+            (void)hipFuncSetAttribute((const void*)edge_da_split128_kernel<D, W, G>,                                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
+            attr_done = true;                                                                                       \
+        }                                                                                                           \
+        hipLaunchKernelGGL((edge_da_split128_kernel<D, W, G>), dim3((unsigned)gx), dim3(512), lds, s, Y, h, src, dst, \
+                           w, order, type_ptr, gate, dA, K);                                                        \
+    } while (0)
+    const bool hw = dst && w;
+    if (!dst) { if (gate) MPNN_DA128(false, false, true); else MPNN_DA128(false, false, false); }
+    else if (!hw) { if (gate) MPNN_DA128(true, false, true); else MPNN_DA128(true, false, false); }
+    else { if (gate) MPNN_DA128(true, true, true); else MPNN_DA128(true, true, false); }
+#undef MPNN_DA128
+    return launch_status("mpnn_edge_message_bwd_f32(dA, bf16x6 128)");
+}
+
+}  // namespace mpnn
