@@ -55,15 +55,15 @@ __global__ void __launch_bounds__(512) edge_message_split128_kernel(
         };
         auto src_of = [&](int e) { return BWD ? e : src[e]; };
         // chunk j (0..3): 16 floats at 16*j of the lane half's 64 floats of the row
-        auto load_chunk = [&](int s_row, int e_row, int j, f32x4 (&f)[4]) {
+        auto load_chunk = [&](int s_row, int j, f32x4 (&f)[4]) {
             const float* p = h + (int64_t)s_row * F + hi * (F / 2) + 16 * j;
 #pragma unroll
             for (int q = 0; q < 4; ++q) f[q] = *reinterpret_cast<const f32x4*>(p + 4 * q);
-            if (GATED) {
-                const float* g = gate + (int64_t)e_row * F + hi * (F / 2) + 16 * j;
+        };
+        auto load_gate = [&](int e_row, int j, f32x4 (&f)[4]) {
+            const float* g = gate + (int64_t)e_row * F + hi * (F / 2) + 16 * j;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) f[q] *= *reinterpret_cast<const f32x4*>(g + 4 * q);
-            }
+            for (int q = 0; q < 4; ++q) f[q] = *reinterpret_cast<const f32x4*>(g + 4 * q);
         };
         auto bfrag = [&](int piece, int n, int chunk) {
             return *reinterpret_cast<const bf16x8*>(smem + piece * IMG + n * ROWB + ((chunk ^ (n & 15)) << 4));
@@ -73,9 +73,18 @@ __global__ void __launch_bounds__(512) edge_message_split128_kernel(
         int s_cur = src_of(e_cur);
         int e_nxt = e_cur, s_nxt = s_cur;
         if (t + nw < tiles) { e_nxt = edge_of(t + nw); s_nxt = src_of(e_nxt); }
-        f32x4 ring[RD][4];
+        // Gated rows: the gate chunk travels in its own one-deep buffer and is multiplied in AFTER the MFMAs of the
+        // running chunk are issued (a multiply at fetch time would wait for both loads before any MFMA goes out).
+        f32x4 ring[RD][4], gbuf[4];
 #pragma unroll
-        for (int j = 0; j < RD - 1; ++j) load_chunk(s_cur, e_cur, j, ring[j]);
+        for (int j = 0; j < RD - 1; ++j) {
+            load_chunk(s_cur, j, ring[j]);
+            if (GATED) {
+                load_gate(e_cur, j, gbuf);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ring[j][q] *= gbuf[q];
+            }
+        }
 
         for (; t < tiles; t += nw) {
             const bool has2 = t + 2 * nw < tiles;
@@ -89,8 +98,13 @@ __global__ void __launch_bounds__(512) edge_message_split128_kernel(
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int cn = c + RD - 1;                                 // chunk to fetch now
-                if (cn < 4) load_chunk(s_cur, e_cur, cn, ring[cn % RD]);
-                else load_chunk(s_nxt, e_nxt, cn - 4, ring[cn % RD]);      // next tile (or a harmless re-read)
+                if (cn < 4) {
+                    load_chunk(s_cur, cn, ring[cn % RD]);
+                    if (GATED) load_gate(e_cur, cn, gbuf);
+                } else {                                                   // next tile (or a harmless re-read)
+                    load_chunk(s_nxt, cn - 4, ring[cn % RD]);
+                    if (GATED) load_gate(e_nxt, cn - 4, gbuf);
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
@@ -101,6 +115,11 @@ __global__ void __launch_bounds__(512) edge_message_split128_kernel(
                     for (int n = 0; n < 4; ++n)
                         mma6(acc[n], ah, am, al, bfrag(0, 32 * n + r, chunk), bfrag(1, 32 * n + r, chunk),
                              bfrag(2, 32 * n + r, chunk));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (GATED) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ring[cn % RD][q] *= gbuf[q];
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }

@@ -170,17 +170,22 @@ __global__ void __launch_bounds__(512) gru_bwd_dw128_kernel(const float* __restr
 
     const int64_t steps = (V + 15) / 16;
     float raw[16];
+    // fetch is branch- and select-free (rows clamped); masking of the ragged last step happens in park(), so
+    // nothing waits on the loads until the MFMAs of the current step are issued
     auto load_raw = [&](int64_t st) {
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             int64_t row = st * 16 + u;
-            const bool ok = row < V;
-            if (!ok) row = V - 1;
-            const float v = colp[row * ldc];
-            raw[u] = ok ? v : 0.f;
+            if (row >= V) row = V - 1;
+            raw[u] = colp[row * ldc];
         }
     };
-    auto park = [&](int buf) {
+    auto park = [&](int buf, int64_t st) {
+        if (st * 16 + 16 > V) {                            // ragged last step only (block-uniform)
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (st * 16 + u >= V) raw[u] = 0.f;
+        }
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
             const f32x4 x0 = {raw[8 * o], raw[8 * o + 1], raw[8 * o + 2], raw[8 * o + 3]};
@@ -203,7 +208,7 @@ __global__ void __launch_bounds__(512) gru_bwd_dw128_kernel(const float* __restr
     int cur = 0;
     if (st < steps) {
         load_raw(st);
-        park(0);
+        park(0, st);
     }
     for (; st < steps; st += gridDim.x) {
         __syncthreads();                                   // buffer `cur` is complete, `cur^1` is free
@@ -226,7 +231,7 @@ __global__ void __launch_bounds__(512) gru_bwd_dw128_kernel(const float* __restr
             for (int b = 0; b < 3; ++b) mma6(acc[a][b], ah, am, al, bh[b], bm[b], bl[b]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (more) park(cur ^ 1);
+        if (more) park(cur ^ 1, st + gridDim.x);
         cur ^= 1;
     }
 
