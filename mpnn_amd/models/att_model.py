@@ -1,10 +1,9 @@
 """Attention model: one AttEdgeNetwork per step, AdjMsgAgg, GRU, parameter-free masked norm.
-Reference: models/att_model.py:6-59.  The reference's default readout is Set2Vec (not on the
-hot path and not importable without rdkit); GraphLevelOutput is the default here."""
+Reference: models/att_model.py:6-59 (default readout Set2Vec, as there)."""
 import torch
 from torch import nn
 
-from mpnn_amd.mpnn_functions import AdjMsgAgg, AttEdgeNetwork, GraphLevelOutput, GRUUpdate
+from mpnn_amd.mpnn_functions import AdjMsgAgg, AttEdgeNetwork, GRUUpdate, Set2Vec
 from ._batch import graph_of
 from .mask_batch_norm import MaskBatchNorm
 
@@ -14,7 +13,7 @@ class BasicModel(nn.Module):
                  message_func=AttEdgeNetwork, message_opts={},
                  message_agg_func=AdjMsgAgg, agg_opts={},
                  update_func=GRUUpdate, update_opts={}, message_steps=3,
-                 readout_func=GraphLevelOutput, readout_opts={}):
+                 readout_func=Set2Vec, readout_opts={}):
         super().__init__()
         message_opts.update(node_features=node_features, edge_features=edge_features,
                             message_features=message_features)

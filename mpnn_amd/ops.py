@@ -385,6 +385,24 @@ class _MoleculeSum(torch.autograd.Function):
         return segsum_bwd_raw(dout.contiguous(), g.graph_ptr, None, g.num_nodes), None
 
 
+class _MoleculeBroadcast(torch.autograd.Function):
+    """(G,F) -> (V,F): every atom receives its molecule's row; backward is the per-molecule sum."""
+
+    @staticmethod
+    def forward(ctx, x, graph):
+        ctx.graph = graph
+        return segsum_bwd_raw(x.contiguous(), graph.graph_ptr, None, graph.num_nodes)
+
+    @staticmethod
+    def backward(ctx, dout):
+        g = ctx.graph
+        return segsum_raw(dout.contiguous(), g.graph_ptr, None, g.num_graphs), None
+
+
+def molecule_broadcast(x, graph):
+    return _MoleculeBroadcast.apply(x, graph)
+
+
 class _ExpandRows(torch.autograd.Function):
     """x (V,F) -> (E,F): every edge receives the row of its DESTINATION atom.  Forward is the
     aggregator's backward kernel (row broadcast), backward is the aggregator itself -- unlike

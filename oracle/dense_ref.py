@@ -224,6 +224,36 @@ def graph_level_output(params, x, mask=None):
     return g.sum(dim=1)
 
 
+def set2vec(params, x, mask=None, steps=100, inner_prod="default"):
+    """Set2Vec.forward (mpnn_functions/readout/set2vec.py:93-151) with LSTMCellHidden.forward (:67-75).
+    PARITY UNPINNED for this function: the reference module cannot be imported here (it imports
+    pre_process.utils -> rdkit, and uses Py2 dict.iteritems), so this restatement follows the source text only.
+    x (B,N,nf2); params: q_attn.weight, e_attn.weight, lstmcell.{w,b}_h{i,f,g,o}.  Returns (B, 2*nf2)."""
+    B, nf = x.shape[0], x.shape[-1]
+    mprev = torch.cat([x.new_zeros(B, nf), x.new_zeros(B, nf)], dim=1)          # :111-113
+    cprev = x.new_zeros(B, nf)
+    pen = (1 - mask) * _BIG_NEGATIVE if mask is not None else None              # :121-123
+    m = mprev
+    for _ in range(steps):
+        def gate(g, fn):
+            return fn(mprev.matmul(params["lstmcell.w_h" + g]) + params["lstmcell.b_h" + g])
+        i, f, g, o = gate("i", torch.sigmoid), gate("f", torch.sigmoid), gate("g", torch.tanh), gate("o", torch.sigmoid)
+        c = f * cprev + i * g
+        m = o * torch.tanh(c)
+        query = F.linear(m, params["q_attn.weight"]).unsqueeze(1)               # :130
+        if inner_prod == "default":
+            energies = F.linear(torch.tanh(query + x).view(-1, nf), params["e_attn.weight"])   # :133
+        else:
+            energies = x.matmul(query.view(-1, nf, 1)).view(B, -1)              # :136
+        if pen is not None:
+            energies = energies + pen.view(-1, 1)
+        att = torch.softmax(energies, dim=0).view(B, -1, 1)                     # :139 (dim 0 of the flat batch)
+        read = att.mul(x).sum(dim=1)
+        m = torch.cat([m, read], dim=1)
+        mprev, cprev = m, c
+    return m
+
+
 # ----------------------------------------------------------------------------- models
 def basic_model_forward(params, afm, bfm, adj, mask, steps=3, return_state=False):
     """The intended basic_model.BasicModel.forward (models/basic_model.py:50-58):

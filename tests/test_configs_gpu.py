@@ -86,7 +86,9 @@ def test_attention_model_at_c3_shape(dev):
     torch.manual_seed(317)
     batch = _small_batch(H, mols, seed=99)
     N = batch["adj"].shape[-1]
-    model = AttModel(H, 4, H, N, 8, message_opts={}, agg_opts={}, update_opts={}, readout_opts={}, message_steps=T)
+    from mpnn_amd.mpnn_functions import GraphLevelOutput
+    model = AttModel(H, 4, H, N, 8, message_opts={}, agg_opts={}, update_opts={}, readout_opts={}, message_steps=T,
+                     readout_func=GraphLevelOutput)
     with torch.no_grad():
         for k, p in model.named_parameters():
             if "bias" in k:

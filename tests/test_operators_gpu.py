@@ -1,10 +1,12 @@
 """Operator- and model-level parity on the GPU against vectors produced by the REAL reference
 (tests/golden/*.npz) -- the modules are driven exactly as the reference's would be."""
+import numpy as np
 import pytest
 import torch
 from torch import nn
 
 from conftest import Fixture, max_err
+from oracle import dense_ref as O
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -193,3 +195,49 @@ def test_sparse_native_batch_equals_dense_batch(dev):
         b = model(sparse)
     assert a.shape == b.shape == (40, 5)
     assert max_err(a.cpu(), b.cpu()) < TOL
+
+
+@pytest.mark.parametrize("inner,masked,steps", [("default", True, 7), ("default", False, 3), ("dot", False, 4),
+                                                ("default", True, 100)])
+def test_set2vec_readout(dev, inner, masked, steps):
+    """Set2Vec (set2vec.py:78-151): dense layout and compact layout against the oracle's restatement, forward and
+    gradients.  (The restatement is unpinned: the reference module needs rdkit to import.)"""
+    from mpnn_amd.mpnn_functions import Set2Vec
+    from mpnn_amd.graph import MolGraph
+    from mpnn_amd import synth
+    torch.manual_seed(5)
+    nfeat = 6
+    mb = synth.select(synth.make_molecules(40, 2 * nfeat, seed=11), np.arange(9))
+    dense = {k: torch.from_numpy(v) for k, v in synth.to_dense(mb).items()}
+    x = dense["afm"].clone()                                   # (B,N,2*nfeat), padded rows zero
+    mask = dense["mask"] if masked else None
+    mod = Set2Vec(nfeat, 3, time_steps=steps, inner_prod=inner)
+    with torch.no_grad():
+        for k, p in mod.named_parameters():
+            if k.startswith("lstmcell.b_"):
+                p.uniform_(-0.2, 0.2)
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in mod.state_dict().items()}
+    xr = x.clone().requires_grad_(True)
+    ref = O.set2vec(params, xr, mask, steps, inner)
+    cot = torch.rand_like(ref) - 0.5
+    (ref * cot).sum().backward()
+
+    mod = mod.to(dev)
+    xg = x.to(dev).requires_grad_(True)
+    out = mod(xg, mask.to(dev) if masked else None)
+    (out * cot.to(dev)).sum().backward()
+    assert max_err(out.detach().cpu(), ref) < 2e-5
+    assert max_err(xg.grad.cpu(), xr.grad) < 2e-5
+    for k, p in mod.named_parameters():
+        assert max_err(p.grad.cpu(), params[k].grad) < 5e-5, k
+
+    if inner == "default" and masked:                          # compact layout: only real atoms, graph_ptr sums
+        g = MolGraph.from_molbatch(mb, dev)
+        for p in mod.parameters():
+            p.grad = None
+        xc = torch.from_numpy(mb.atom_feat).to(dev).requires_grad_(True)
+        outc = mod(xc, torch.ones(xc.shape[0], 1, device=dev), graph=g)
+        (outc * cot.to(dev)).sum().backward()
+        assert max_err(outc.detach().cpu(), ref) < 2e-5
+        for k, p in mod.named_parameters():
+            assert max_err(p.grad.cpu(), params[k].grad) < 5e-5, k

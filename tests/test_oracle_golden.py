@@ -161,3 +161,39 @@ def test_index_oracle():
     rp, ci, w = O.dense_to_csr(adj)
     assert torch.equal(rp, torch.from_numpy(f.raw["row_ptr"]))
     assert torch.equal(ci, torch.from_numpy(f.raw["col_idx"]))
+
+
+def test_set2vec_restatement_properties():
+    """Set2Vec cannot be pinned by reference vectors (the module imports rdkit); check the properties its source
+    text implies instead: the read is invariant to the order of atoms inside a molecule, padded atoms (mask 0)
+    carry exactly zero attention, and the attention of a step sums to 1 over the WHOLE batch (softmax dim 0)."""
+    import torch
+    from oracle import dense_ref as O
+    torch.manual_seed(3)
+    B, N, nf = 3, 6, 8
+    params = {"q_attn.weight": torch.randn(nf, nf) * 0.3, "e_attn.weight": torch.randn(1, nf) * 0.3}
+    for g in "ifgo":
+        params["lstmcell.w_h" + g] = torch.randn(2 * nf, nf) * 0.2
+        params["lstmcell.b_h" + g] = torch.randn(1, nf) * 0.1
+    mask = torch.ones(B, N, 1)
+    mask[0, 4:] = 0
+    mask[2, 3:] = 0
+    x = torch.randn(B, N, nf) * mask
+    out = O.set2vec(params, x, mask, steps=5)
+    assert out.shape == (B, 2 * nf)
+    perm = torch.tensor([2, 0, 3, 1, 4, 5])                   # permute real atoms of molecule 0 only
+    x2 = x.clone()
+    x2[0] = x[0, perm]
+    assert (O.set2vec(params, x2, mask, steps=5) - out).abs().max() < 1e-6
+    x3 = x.clone()
+    x3[0, 4:] = 7.0                                            # garbage in padded slots must not matter
+    assert (O.set2vec(params, x3, mask, steps=5) - out).abs().max() < 1e-6
+    # one step by hand: m0 = 0 -> query; attention over all B*N atoms
+    one = O.set2vec(params, x, mask, steps=1)
+    i = torch.sigmoid(params["lstmcell.b_hi"]); g = torch.tanh(params["lstmcell.b_hg"]); o = torch.sigmoid(params["lstmcell.b_ho"])
+    m = (o * torch.tanh(i * g)).expand(B, nf)
+    q = m @ params["q_attn.weight"].t()
+    e = torch.tanh(q.unsqueeze(1) + x).reshape(-1, nf) @ params["e_attn.weight"].t() + ((1 - mask) * -1e8).view(-1, 1)
+    att = torch.softmax(e, dim=0).view(B, N, 1)
+    assert abs(float(att.sum()) - 1.0) < 1e-6
+    assert (one - torch.cat([m, (att * x).sum(1)], dim=1)).abs().max() < 1e-6
