@@ -500,6 +500,9 @@ __global__ void __launch_bounds__(512) tn_direct_kernel(const float* __restrict_
 // From dout and the saved forward gates (r, z, n, gh_n) to the pre-activation gradients
 //   ws[row] = [ dgi_r dgi_z dgi_n | dgh_r dgh_z dgh_n ]   (6H floats)   and   dh_direct = dout*mask*z.
 // mask is 0/1 (as the reference's create_mask makes it): d sigma / d tanh use the masked gate values.
+// COMPACT: ws[row] = [ dar daz dan dnh ] (4H floats; dgi = first 3 blocks, dgh = blocks 0, 1, 3) for the H = 128
+// kernels of gru_bwd128.hip, which index the blocks themselves.
+template <bool COMPACT>
 __global__ void __launch_bounds__(256) gru_gate_grad_kernel(const float* __restrict__ dout, const float* __restrict__ h,
                                                             const float* __restrict__ mask,
                                                             const float* __restrict__ saved, float* __restrict__ ws,
@@ -518,13 +521,21 @@ __global__ void __launch_bounds__(256) gru_gate_grad_kernel(const float* __restr
         const float dan = dn * mk * (1.0f - n * n);     // n = tanh(.)*mask
         const float dar = dan * nh * mk * r * (1.0f - r);
         const float daz = dz * mk * z * (1.0f - z);
-        float* w = ws + row * 6 * H + col;
-        w[0] = dar;
-        w[H] = daz;
-        w[2 * H] = dan;
-        w[3 * H] = dar;
-        w[4 * H] = daz;
-        w[5 * H] = dan * r;
+        if (COMPACT) {
+            float* w = ws + row * 4 * H + col;
+            w[0] = dar;
+            w[H] = daz;
+            w[2 * H] = dan;
+            w[3 * H] = dan * r;
+        } else {
+            float* w = ws + row * 6 * H + col;
+            w[0] = dar;
+            w[H] = daz;
+            w[2 * H] = dan;
+            w[3 * H] = dar;
+            w[4 * H] = daz;
+            w[5 * H] = dan * r;
+        }
         dh[idx] = g * z;
     }
 }
@@ -625,24 +636,29 @@ extern "C" int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const 
     float* ws = (float*)workspace;
     int64_t g = ceil_div(V * H, 256);
     if (g > 256 * 16) g = 256 * 16;
-    hipLaunchKernelGGL(gru_gate_grad_kernel, dim3((unsigned)g), dim3(256), 0, s, dout, h, mask, saved, ws, dh, V, H);
-    int rc = launch_status("mpnn_gru_update_bwd_f32(gates)");
-    if (rc) return rc;
     static const bool fp32_only = getenv("MPNN_GRU_MATH") && !strcmp(getenv("MPNN_GRU_MATH"), "fp32");
+    int rc;
     if (H == 128 && !fp32_only) {
+        hipLaunchKernelGGL(gru_gate_grad_kernel<true>, dim3((unsigned)g), dim3(256), 0, s, dout, h, mask, saved, ws, dh, V,
+                           H);
+        rc = launch_status("mpnn_gru_update_bwd_f32(gates)");
+        if (rc) return rc;
         rc = launch_gru_bwd_dx128(ws, W_ih, W_hh, dm, dh, V, s);
         if (rc) return rc;
-    } else {
-        // dm = dgi . W_ih^T : B given as [n = input feature][k = gate column], ld 3H
-        rc = launch_rows_gemm<true, false>(ws, 6 * H, nullptr, nullptr, 0, W_ih, 0, 3 * H, nullptr, dm, H, V, 3 * H, H,
-                                           s, "mpnn_gru_update_bwd_f32(dm)");
-        if (rc) return rc;
-        // dh = dgh . W_hh^T + dout*mask*z   (the direct term already sits in dh)
-        rc = launch_rows_gemm<true, false>(ws + 3 * H, 6 * H, nullptr, nullptr, 0, W_hh, 0, 3 * H, dh, dh, H, V, 3 * H,
-                                           H, s, "mpnn_gru_update_bwd_f32(dh)");
-        if (rc) return rc;
+        return launch_gru_bwd_dw128(m, h, ws, dW_ih, dW_hh, db_ih, db_hh, V, s);
     }
-    if (H == 128 && !fp32_only) return launch_gru_bwd_dw128(m, h, ws, dW_ih, dW_hh, db_ih, db_hh, V, s);
+    hipLaunchKernelGGL(gru_gate_grad_kernel<false>, dim3((unsigned)g), dim3(256), 0, s, dout, h, mask, saved, ws, dh, V,
+                       H);
+    rc = launch_status("mpnn_gru_update_bwd_f32(gates)");
+    if (rc) return rc;
+    // dm = dgi . W_ih^T : B given as [n = input feature][k = gate column], ld 3H
+    rc = launch_rows_gemm<true, false>(ws, 6 * H, nullptr, nullptr, 0, W_ih, 0, 3 * H, nullptr, dm, H, V, 3 * H, H, s,
+                                       "mpnn_gru_update_bwd_f32(dm)");
+    if (rc) return rc;
+    // dh = dgh . W_hh^T + dout*mask*z   (the direct term already sits in dh)
+    rc = launch_rows_gemm<true, false>(ws + 3 * H, 6 * H, nullptr, nullptr, 0, W_hh, 0, 3 * H, dh, dh, H, V, 3 * H, H, s,
+                                       "mpnn_gru_update_bwd_f32(dh)");
+    if (rc) return rc;
     if (H == 128) {
         // dW (128 x 384) and db on the register-direct wide kernel: 8 waves = 4 a-blocks x 2 groups of 6 b-blocks
         int64_t gxd = 512;

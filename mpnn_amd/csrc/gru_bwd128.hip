@@ -1,6 +1,6 @@
 // Backward of the masked GRU update at hidden width 128: the two GEMM families on the bf16 matrix pipe with
 // 3-way operand splitting (split_math.h), reading the pre-activation gradients the gate-gradient kernel wrote
-// (backward.hip: ws[row] = [dar daz dan | dar daz dnh], 6H floats).
+// (backward.hip, compact layout: ws[row] = [dar daz dan dnh], 4H floats).
 //
 //   gru_bwd_dx128_kernel   dm = dgi W_ih^T,  dh = dgh W_hh^T + (dout*mask*z already in dh)
 //
@@ -15,7 +15,7 @@ namespace mpnn {
 __global__ void __launch_bounds__(512) gru_bwd_dx128_kernel(const float* __restrict__ ws, const float* __restrict__ W_ih,
                                                             const float* __restrict__ W_hh, float* __restrict__ dm,
                                                             float* __restrict__ dh, int64_t V) {
-    constexpr int H = 128, LDW = 6 * H, KC = 3 * H;
+    constexpr int H = 128, LDW = 4 * H, KC = 3 * H;
     constexpr int ROWB = 2 * KC;               // one image row = one weight row (3H gate columns) in bf16
     constexpr int IMG = 32 * ROWB;             // one (matrix, piece) image: 32 output columns
     constexpr int NW = 8;
@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(512) gru_bwd_dx128_kernel(const float* __restr
         int64_t row = tile * 32 + r;
         if (row >= V) row = V - 1;
         const int g = c >> 2;
-        const float* p = ws + row * LDW + (g == 3 ? 5 * H : g * H) + hi * (H / 2) + 16 * (c & 3);
+        const float* p = ws + row * LDW + g * H + hi * (H / 2) + 16 * (c & 3);
 #pragma unroll
         for (int q = 0; q < 4; ++q) f[q] = *reinterpret_cast<const f32x4*>(p + 4 * q);
     };
@@ -145,7 +145,7 @@ int launch_gru_bwd_dx128(const float* ws, const float* W_ih, const float* W_hh, 
 __global__ void __launch_bounds__(512) gru_bwd_dw128_kernel(const float* __restrict__ m, const float* __restrict__ h,
                                                             const float* __restrict__ ws, float* dW_ih, float* dW_hh,
                                                             float* db_ih, float* db_hh, int64_t V) {
-    constexpr int H = 128, LDW = 6 * H, NC = 4 * H;        // 512 staged columns
+    constexpr int H = 128, LDW = 4 * H, NC = 4 * H;        // 512 staged columns
     constexpr int SLOT = NC * 16;                          // bytes of one (piece, octet) plane
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][3 pieces][2 octets][512][8] bf16
 
@@ -155,7 +155,8 @@ __global__ void __launch_bounds__(512) gru_bwd_dw128_kernel(const float* __restr
     const int mat = blockIdx.y;
     const float* X = mat == 0 ? m : h;
     // this thread's column of the staged tile and where it lives in global memory
-    const float* colp = tid < H ? X + tid : ws + mat * 3 * H + (tid - H);
+    // G columns: dgi = blocks 0,1,2 of ws; dgh = blocks 0,1,3
+    const float* colp = tid < H ? X + tid : ws + (tid - H) + ((mat == 1 && tid >= 3 * H) ? H : 0);
     const int64_t ldc = tid < H ? H : LDW;
     const int ag = wv & 1, bg = wv >> 1;
 
