@@ -139,3 +139,117 @@ def test_c5_skewed_degree_aggregator(dev):
     pick = torch.randint(0, g.num_edges, (2048,), device=dev, generator=gen)
     direct = torch.einsum("emn,en->em", A[g.edge_type.long()[pick]].double(), hh[g.col_idx.long()[pick]].double())
     assert max_err(msg[pick], direct) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------ hidden 128 (C3 / C4)
+@pytest.fixture(scope="module")
+def c4s(dev):
+    """C3/C4-shaped molecules at hidden 128, 25k molecules (V ~ 750k, E ~ 1.5M): every persistent loop of the
+    H = 128 kernels runs several tiles per wave and ends on a ragged tile."""
+    from mpnn_amd import synth
+    from mpnn_amd.graph import MolGraph
+    mb = synth.make_molecules(25_000, 128, seed=318)
+    return mb, MolGraph.from_molbatch(mb, dev), torch.from_numpy(mb.atom_feat).to(dev)
+
+
+def _gru_ref64(m, h, mask, W_ih, W_hh, b_ih, b_hh):
+    H = h.shape[1]
+    gi = m @ W_ih + b_ih
+    gh = h @ W_hh + b_hh
+    r = torch.sigmoid(gi[:, :H] + gh[:, :H]) * mask
+    z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H]) * mask
+    n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:]) * mask
+    return ((1 - z) * n + z * h) * mask
+
+
+def test_h128_gru_forward_backward_full_size(dev, c4s):
+    """GRU at hidden 128 on ~750k atoms against float64 autograd on the same device (all rows, all gradients)."""
+    from mpnn_amd import ops
+    mb, g, h = c4s
+    V, H = h.shape
+    gen = torch.Generator(device=dev).manual_seed(7)
+    m = torch.randn(V, H, device=dev, generator=gen)
+    mask = (torch.rand(V, 1, device=dev, generator=gen) > 0.1).float()
+    bound = (6.0 / (H + 3 * H)) ** 0.5
+    W_ih = (torch.rand(H, 3 * H, device=dev, generator=gen) * 2 - 1) * bound
+    W_hh = (torch.rand(H, 3 * H, device=dev, generator=gen) * 2 - 1) * bound
+    b_ih = torch.rand(3 * H, device=dev, generator=gen) * 0.2 - 0.1
+    b_hh = torch.rand(3 * H, device=dev, generator=gen) * 0.2 - 0.1
+    dout = torch.randn(V, H, device=dev, generator=gen)
+    leaves = [t.clone().requires_grad_(True) for t in (m, h, W_ih, W_hh, b_ih, b_hh)]
+    out = ops.gru_update(leaves[0], leaves[1], mask, *leaves[2:])
+    out.backward(dout)
+    ref_leaves = [t.double().requires_grad_(True) for t in (m, h, W_ih, W_hh, b_ih, b_hh)]
+    ref = _gru_ref64(ref_leaves[0], ref_leaves[1], mask.double(), *ref_leaves[2:])
+    ref.backward(dout.double())
+    assert max_err(out.detach(), ref.detach()) < 1e-5
+    for got, want, name in zip(leaves, ref_leaves, ("dm", "dh", "dW_ih", "dW_hh", "db_ih", "db_hh")):
+        scale = max(1.0, float(want.grad.abs().max()))
+        tol = 1e-5 if name in ("dm", "dh") else 2e-5            # weight gradients sum 750k terms
+        assert max_err(got.grad, want.grad) / scale < tol, name
+
+
+@pytest.mark.parametrize("gated", [False, True])
+def test_h128_message_and_weight_gradient_full_size(dev, c4s, gated):
+    """Typed edge message at nf = mf = 128 on ~1.5M edges: rows against float64, dx and dA against float64 autograd."""
+    from mpnn_amd import ops
+    mb, g, h = c4s
+    E, F, K = g.num_edges, 128, int(g.type_feat.shape[0])
+    gen = torch.Generator(device=dev).manual_seed(9)
+    A = torch.randn(K, F, F, device=dev, generator=gen) * (1.0 / F ** 0.5)
+    gate = torch.rand(E, F, device=dev, generator=gen) if gated else None
+    dmsg = torch.randn(E, F, device=dev, generator=gen)
+    hl, Al = h.clone().requires_grad_(True), A.clone().requires_grad_(True)
+    gl = gate.clone().requires_grad_(True) if gated else None
+    msg = ops.edge_message(hl, Al, g, gl)
+    msg.backward(dmsg)
+    src, typ = g.col_idx.long(), g.edge_type.long()
+    h64, A64 = h.double().requires_grad_(True), A.double().requires_grad_(True)
+    x = h64[src]
+    if gated:
+        g64 = gate.double().requires_grad_(True)
+        x = x * g64
+    ref = torch.empty(E, F, dtype=torch.float64, device=dev)
+    parts = []
+    for k in range(K):                                          # one dense GEMM per type
+        idx = (typ == k).nonzero().squeeze(1)
+        parts.append((idx, x[idx] @ A64[k].t()))
+    ref = torch.zeros(E, F, dtype=torch.float64, device=dev)
+    for idx, val in parts:
+        ref = ref.index_add(0, idx, val)
+    ref.backward(dmsg.double())
+    assert max_err(msg.detach(), ref.detach()) < 1e-5
+    assert max_err(hl.grad, h64.grad) / max(1.0, float(h64.grad.abs().max())) < 1e-5
+    assert max_err(Al.grad, A64.grad) / max(1.0, float(A64.grad.abs().max())) < 2e-5
+    if gated:
+        assert max_err(gl.grad, g64.grad) / max(1.0, float(g64.grad.abs().max())) < 1e-5
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_h128_fused_message_aggregate_weight_gradient_full_size(dev, c4s, weighted):
+    """dA of message + adjacency-weighted sum as one node (the no-dmsg path used in training) at hidden 128."""
+    from mpnn_amd import ops
+    mb, g, h = c4s
+    E, V, F, K = g.num_edges, g.num_nodes, 128, int(g.type_feat.shape[0])
+    gen = torch.Generator(device=dev).manual_seed(10)
+    A = torch.randn(K, F, F, device=dev, generator=gen) * (1.0 / F ** 0.5)
+    w = (torch.rand(E, device=dev, generator=gen) + 0.5) if weighted else None
+    dagg = torch.randn(V, F, device=dev, generator=gen)
+    Al = A.clone().requires_grad_(True)
+    agg = ops.message_aggregate(h, Al, g, w)
+    agg.backward(dagg)
+    src, dst, typ = g.col_idx.long(), g.edge_dst.long(), g.edge_type.long()
+    y = dagg.double()[dst]
+    if weighted:
+        y = y * w.double().unsqueeze(1)
+    x = h.double()[src]
+    ref = torch.stack([y[typ == k].t() @ x[typ == k] for k in range(K)])
+    assert max_err(Al.grad, ref) / max(1.0, float(ref.abs().max())) < 2e-5
+    fwd = torch.zeros(V, F, dtype=torch.float64, device=dev)
+    for k in range(K):
+        idx = (typ == k).nonzero().squeeze(1)
+        val = x[idx] @ A.double()[k].t()
+        if weighted:
+            val = val * w.double()[idx].unsqueeze(1)
+        fwd = fwd.index_add(0, dst[idx], val)
+    assert max_err(agg.detach(), fwd) < 2e-5
