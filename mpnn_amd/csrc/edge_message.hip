@@ -300,6 +300,10 @@ int launch_message_split128(const float* h, const float* A, const int32_t* src, 
                             const int32_t* type_ptr, const float* gate, float* msg, int64_t E, int K, hipStream_t s);
 int launch_message_dx_split128(const float* dmsg, const float* A, const int32_t* order, const int32_t* type_ptr,
                                float* dx, int64_t E, int K, hipStream_t s);
+int launch_message_split64(const float* h, const float* A, const int32_t* src, const int32_t* order,
+                           const int32_t* type_ptr, const float* gate, float* msg, int64_t E, int K, hipStream_t s);
+int launch_message_dx_split64(const float* dmsg, const float* A, const int32_t* order, const int32_t* type_ptr,
+                              float* dx, int64_t E, int K, hipStream_t s);
 
 static bool fp32_only() {
     static const bool v = getenv("MPNN_GRU_MATH") && !strcmp(getenv("MPNN_GRU_MATH"), "fp32");
@@ -310,6 +314,7 @@ int launch_message_dx_resident(const float* dmsg, const float* A, const int32_t*
                                float* dx, int64_t E, int K, int nf, int mf, hipStream_t s) {
     if (K > 64) return 1;
     if (mf == 128 && nf == 128 && !fp32_only()) return launch_message_dx_split128(dmsg, A, order, type_ptr, dx, E, K, s);
+    if (mf == 64 && nf == 64 && !fp32_only()) return launch_message_dx_split64(dmsg, A, order, type_ptr, dx, E, K, s);
     if (mf == 64 && nf == 64)
         return launch_message_resident<64, 2, true>(dmsg, A, nullptr, order, type_ptr, nullptr, dx, E, K, nf, s);
     if (mf == 32 && nf == 32)
@@ -339,6 +344,7 @@ extern "C" int mpnn_edge_message_f32(const float* h, const float* A, const int32
     const int nb = (mf + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
     if (K <= 64) {      // resident-matrix fast path: the type loop is sequential, keep K small
+        if (nf == 64 && mf == 64 && !fp32_only()) return launch_message_split64(h, A, src, order, type_ptr, gate, msg, E, K, st);
         if (nf == 64 && nb == 2) return launch_message_resident<64, 2, false>(h, A, src, order, type_ptr, gate, msg, E, K, mf, st);
         if (nf == 64 && nb == 1) return launch_message_resident<64, 1, false>(h, A, src, order, type_ptr, gate, msg, E, K, mf, st);
         if (nf == 32 && nb == 1) return launch_message_resident<32, 1, false>(h, A, src, order, type_ptr, gate, msg, E, K, mf, st);

@@ -1,4 +1,4 @@
-// Typed edge message at nf = mf = 128 on the bf16 matrix pipe with 3-way operand splitting (split_math.h).
+// Typed edge message at nf = mf = 128 (and 64) on the bf16 matrix pipe with 3-way operand splitting (split_math.h).
 //
 // Same shape as edge_message_resident_kernel (edge_message.hip): persistent waves, the type's matrix resident in
 // LDS, a lane gathers its own edge's contiguous half-row, no barrier inside a type.  Differences at this width:
@@ -12,25 +12,32 @@
 
 namespace mpnn {
 
-template <bool BWD, bool GATED>
-__global__ void __launch_bounds__(512) edge_message_split128_kernel(
+template <int F, int NW, bool BWD, bool GATED>
+__global__ void __launch_bounds__(64 * NW, (F == 64 && !GATED) ? 4 : 1) edge_message_split_kernel(
     const float* __restrict__ h, const float* __restrict__ A, const int32_t* __restrict__ src,
     const int32_t* __restrict__ order, const int32_t* __restrict__ type_ptr, const float* __restrict__ gate,
     float* __restrict__ msg, int K) {
-    constexpr int F = 128, ROWB = 2 * F, IMG = F * ROWB;
-    constexpr int RD = GATED ? 2 : 4;          // ring depth; chunks are fetched RD-1 ahead
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [3 pieces][128 n][128 k] bf16
+    constexpr int ROWB = 2 * F, IMG = F * ROWB;
+    constexpr int NCH = F / 32;                // 16-float chunks in a lane's half-row
+    constexpr int NB = F / 32;                 // 32-column output blocks
+    constexpr int SW = F == 128 ? 15 : 7;      // swizzle mask: rows are F/2 dwords apart
+    constexpr int RD = (GATED || NCH < 4) ? 2 : 4;   // ring depth; chunks are fetched RD-1 ahead
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [3 pieces][F n][F k] bf16
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int r = lane & 31, hi = lane >> 5;
-    const int gw = blockIdx.x * 8 + wv, nw = gridDim.x * 8;
+    // 16-byte chunks of an image row are XOR-swizzled by the row: H=128 rows start on one bank (16 positions),
+    // H=64 rows alternate between the two halves of the banks (8 positions, keyed on row/2)
+    auto swz = [](int n) { return F == 128 ? (n & 15) : ((n >> 1) & 7); };
+    (void)SW;
+    const int gw = blockIdx.x * NW + wv, nw = gridDim.x * NW;
 
     for (int k = 0; k < K; ++k) {
         const int tb = type_ptr[k], te = type_ptr[k + 1];
         if (te == tb) continue;                         // uniform over the grid
         __syncthreads();                                // everyone is done with the previous matrix
         const float* Ak = A + (int64_t)k * F * F;
-        for (int idx = tid; idx < F * (F / 4); idx += 512) {
+        for (int idx = tid; idx < F * (F / 4); idx += 64 * NW) {
             const int row = idx / (F / 4), c4 = 4 * (idx % (F / 4));
             const f32x4 w4 = *reinterpret_cast<const f32x4*>(Ak + (int64_t)row * F + c4);
 #pragma unroll
@@ -38,7 +45,7 @@ __global__ void __launch_bounds__(512) edge_message_split128_kernel(
                 const int n = BWD ? c4 + u : row, kk = BWD ? row : c4 + u;
                 __bf16 ph, pm, pl;
                 split3(w4[u], ph, pm, pl);
-                const int off = n * ROWB + (((kk >> 3) ^ (n & 15)) << 4) + ((kk & 7) << 1);
+                const int off = n * ROWB + (((kk >> 3) ^ swz(n)) << 4) + ((kk & 7) << 1);
                 *reinterpret_cast<__bf16*>(smem + off) = ph;
                 *reinterpret_cast<__bf16*>(smem + IMG + off) = pm;
                 *reinterpret_cast<__bf16*>(smem + 2 * IMG + off) = pl;
@@ -54,7 +61,7 @@ __global__ void __launch_bounds__(512) edge_message_split128_kernel(
             return order[pos < te ? pos : tb + 32 * tile];
         };
         auto src_of = [&](int e) { return BWD ? e : src[e]; };
-        // chunk j (0..3): 16 floats at 16*j of the lane half's 64 floats of the row
+        // chunk j (0..NCH-1): 16 floats at 16*j of the lane half's F/2 floats of the row
         auto load_chunk = [&](int s_row, int j, f32x4 (&f)[4]) {
             const float* p = h + (int64_t)s_row * F + hi * (F / 2) + 16 * j;
 #pragma unroll
@@ -66,7 +73,7 @@ __global__ void __launch_bounds__(512) edge_message_split128_kernel(
             for (int q = 0; q < 4; ++q) f[q] = *reinterpret_cast<const f32x4*>(g + 4 * q);
         };
         auto bfrag = [&](int piece, int n, int chunk) {
-            return *reinterpret_cast<const bf16x8*>(smem + piece * IMG + n * ROWB + ((chunk ^ (n & 15)) << 4));
+            return *reinterpret_cast<const bf16x8*>(smem + piece * IMG + n * ROWB + ((chunk ^ swz(n)) << 4));
         };
 
         int e_cur = edge_of(t);
@@ -90,29 +97,29 @@ __global__ void __launch_bounds__(512) edge_message_split128_kernel(
             const bool has2 = t + 2 * nw < tiles;
             int e_nn = e_nxt;
             if (has2) e_nn = edge_of(t + 2 * nw);
-            f32x16 acc[4];
+            f32x16 acc[NB];
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
+            for (int n = 0; n < NB; ++n)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < NCH; ++c) {
                 const int cn = c + RD - 1;                                 // chunk to fetch now
-                if (cn < 4) {
+                if (cn < NCH) {
                     load_chunk(s_cur, cn, ring[cn % RD]);
                     if (GATED) load_gate(e_cur, cn, gbuf);
                 } else {                                                   // next tile (or a harmless re-read)
-                    load_chunk(s_nxt, cn - 4, ring[cn % RD]);
-                    if (GATED) load_gate(e_nxt, cn - 4, gbuf);
+                    load_chunk(s_nxt, cn - NCH, ring[cn % RD]);
+                    if (GATED) load_gate(e_nxt, cn - NCH, gbuf);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     bf16x8 ah, am, al;
                     split8(ring[c % RD][2 * s2], ring[c % RD][2 * s2 + 1], ah, am, al);
-                    const int chunk = 8 * hi + 2 * c + s2;
+                    const int chunk = (F / 16) * hi + 2 * c + s2;
 #pragma unroll
-                    for (int n = 0; n < 4; ++n)
+                    for (int n = 0; n < NB; ++n)
                         mma6(acc[n], ah, am, al, bfrag(0, 32 * n + r, chunk), bfrag(1, 32 * n + r, chunk),
                              bfrag(2, 32 * n + r, chunk));
                     __builtin_amdgcn_sched_barrier(0);
@@ -133,7 +140,7 @@ __global__ void __launch_bounds__(512) edge_message_split128_kernel(
                 const int e_row = __shfl(e_cur, row);
                 if (row < rows) {
 #pragma unroll
-                    for (int n = 0; n < 4; ++n)
+                    for (int n = 0; n < NB; ++n)
                         __builtin_nontemporal_store(acc[n][i], msg + (int64_t)e_row * F + 32 * n + r);
                 }
                 if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -146,38 +153,48 @@ __global__ void __launch_bounds__(512) edge_message_split128_kernel(
     }
 }
 
-template <bool BWD>
-static int launch_split128(const float* h, const float* A, const int32_t* src, const int32_t* order,
-                           const int32_t* type_ptr, const float* gate, float* msg, int64_t E, int K, hipStream_t s) {
-    const size_t lds = (size_t)3 * 128 * 256;
+template <int F, bool BWD>
+static int launch_split(const float* h, const float* A, const int32_t* src, const int32_t* order,
+                        const int32_t* type_ptr, const float* gate, float* msg, int64_t E, int K, hipStream_t s) {
+    // F = 128: one 8-wave block per CU (96 KB of LDS).  F = 64: 24 KB images, 4-wave blocks, 4 per CU ungated (<= 128 VGPRs).
+    constexpr int NW = F == 128 ? 8 : 4;
+    const size_t lds = (size_t)3 * F * 2 * F;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)edge_message_split128_kernel<BWD, false>,
+        (void)hipFuncSetAttribute((const void*)edge_message_split_kernel<F, NW, BWD, false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)edge_message_split128_kernel<BWD, true>,
+        (void)hipFuncSetAttribute((const void*)edge_message_split_kernel<F, NW, BWD, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    int64_t blocks = 256;                                   // one 8-wave block per CU (96 KB of LDS)
-    const int64_t need = ceil_div(ceil_div(E, 32) + K, 8);
+    int64_t blocks = F == 128 ? 256 : (gate ? 512 : 1024);
+    const int64_t need = ceil_div(ceil_div(E, 32) + K, NW);
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
     if (gate)
-        hipLaunchKernelGGL((edge_message_split128_kernel<BWD, true>), dim3((unsigned)blocks), dim3(512), lds, s, h, A, src,
-                           order, type_ptr, gate, msg, K);
+        hipLaunchKernelGGL((edge_message_split_kernel<F, NW, BWD, true>), dim3((unsigned)blocks), dim3(64 * NW), lds, s, h,
+                           A, src, order, type_ptr, gate, msg, K);
     else
-        hipLaunchKernelGGL((edge_message_split128_kernel<BWD, false>), dim3((unsigned)blocks), dim3(512), lds, s, h, A,
-                           src, order, type_ptr, gate, msg, K);
-    return launch_status(BWD ? "mpnn_edge_message_bwd_f32(dx, bf16x6 128)" : "mpnn_edge_message_f32(bf16x6 128)");
+        hipLaunchKernelGGL((edge_message_split_kernel<F, NW, BWD, false>), dim3((unsigned)blocks), dim3(64 * NW), lds, s,
+                           h, A, src, order, type_ptr, gate, msg, K);
+    return launch_status(BWD ? "mpnn_edge_message_bwd_f32(dx, bf16x6)" : "mpnn_edge_message_f32(bf16x6)");
 }
 
 int launch_message_split128(const float* h, const float* A, const int32_t* src, const int32_t* order,
                             const int32_t* type_ptr, const float* gate, float* msg, int64_t E, int K, hipStream_t s) {
-    return launch_split128<false>(h, A, src, order, type_ptr, gate, msg, E, K, s);
+    return launch_split<128, false>(h, A, src, order, type_ptr, gate, msg, E, K, s);
 }
 int launch_message_dx_split128(const float* dmsg, const float* A, const int32_t* order, const int32_t* type_ptr,
                                float* dx, int64_t E, int K, hipStream_t s) {
-    return launch_split128<true>(dmsg, A, nullptr, order, type_ptr, nullptr, dx, E, K, s);
+    return launch_split<128, true>(dmsg, A, nullptr, order, type_ptr, nullptr, dx, E, K, s);
+}
+int launch_message_split64(const float* h, const float* A, const int32_t* src, const int32_t* order,
+                           const int32_t* type_ptr, const float* gate, float* msg, int64_t E, int K, hipStream_t s) {
+    return launch_split<64, false>(h, A, src, order, type_ptr, gate, msg, E, K, s);
+}
+int launch_message_dx_split64(const float* dmsg, const float* A, const int32_t* order, const int32_t* type_ptr,
+                              float* dx, int64_t E, int K, hipStream_t s) {
+    return launch_split<64, true>(dmsg, A, nullptr, order, type_ptr, nullptr, dx, E, K, s);
 }
 
 }  // namespace mpnn
