@@ -552,6 +552,13 @@ int launch_gru_bwd_dw128(const float* m, const float* h, const float* ws, float*
 int launch_edge_da_split128(const float* Y, const float* h, const int32_t* src, const int32_t* dst, const float* w,
                             const int32_t* order, const int32_t* type_ptr, const float* gate, float* dA, int64_t E,
                             int K, hipStream_t s);
+int launch_edge_da_split64(const float* Y, const float* h, const int32_t* src, const int32_t* dst, const float* w,
+                           const int32_t* order, const int32_t* type_ptr, const float* gate, float* dA, int64_t E,
+                           int K, hipStream_t s);
+static bool da64_split() {
+    static const bool v = getenv("MPNN_DA64_SPLIT") != nullptr;
+    return v;
+}
 static bool math_fp32_only() {
     static const bool v = getenv("MPNN_GRU_MATH") && !strcmp(getenv("MPNN_GRU_MATH"), "fp32");
     return v;
@@ -584,7 +591,9 @@ extern "C" int mpnn_edge_message_bwd_f32(const float* h, const float* A, const i
                                            nf, s, "mpnn_edge_message_bwd_f32(dx)");
         if (rc) return rc;
     }
-    if (dA && mf == 64 && nf == 64 && K <= 64) {
+    if (dA && mf == 64 && nf == 64 && K <= 64 && da64_split() && !math_fp32_only()) {
+        rc = launch_edge_da_split64(dmsg, h, src, nullptr, nullptr, order, type_ptr, gate, dA, E, K, s);
+    } else if (dA && mf == 64 && nf == 64 && K <= 64) {
         int64_t gx = 512;                               // 2 blocks of 8 waves per CU
         const int64_t need = ceil_div(ceil_div(E, 32) + K, 8);
         if (gx > need) gx = need;
@@ -703,6 +712,8 @@ extern "C" int mpnn_edge_message_agg_bwd_da_f32(const float* dagg, const float* 
                            h, nf, order, type_ptr, K, src, dst, w, gate, dA, (float*)nullptr, E);
         return launch_status("mpnn_edge_message_agg_bwd_da_f32(128)");
     }
+    if (da64_split() && !math_fp32_only())
+        return launch_edge_da_split64(dagg, h, src, dst, w, order, type_ptr, gate, dA, E, K, (hipStream_t)stream);
     int64_t gx = 512;
     const int64_t need = ceil_div(ceil_div(E, 32) + K, 8);
     if (gx > need) gx = need;

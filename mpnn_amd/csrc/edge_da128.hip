@@ -11,33 +11,35 @@
 
 namespace mpnn {
 
-template <bool HAS_DST, bool HAS_W, bool GATED>
-__global__ void __launch_bounds__(512) edge_da_split128_kernel(
+template <int F, bool HAS_DST, bool HAS_W, bool GATED>
+__global__ void __launch_bounds__(4 * F) edge_da_split_kernel(
     const float* __restrict__ Y, const float* __restrict__ h, const int32_t* __restrict__ src,
     const int32_t* __restrict__ dst, const float* __restrict__ w, const int32_t* __restrict__ order,
     const int32_t* __restrict__ type_ptr, const float* __restrict__ gate, float* dA, int K) {
-    constexpr int F = 128;
-    constexpr int SLOT = 256 * 16;                         // bytes of one (piece, octet) plane
+    constexpr int NC = 2 * F;                              // staged columns [y | x]
+    constexpr int SLOT = NC * 16;                          // bytes of one (piece, octet) plane
+    constexpr int NA = F / 32;                             // 32-wide output blocks per side
+    constexpr int NT = NA * NA / (4 * F / 64);             // output tiles per wave (2 at F = 128, 1 at F = 64)
     constexpr int BUF = 12 * SLOT;                         // 3 pieces x 4 octets
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, hi = lane >> 5;
-    const int col = tid & 255;                             // staged column: < 128 = y, else x
-    const int og = wv >> 2;                                // which 16 of the step's 32 edges this thread stages
-    const bool is_y = (wv & 2) == 0;                       // wave-uniform
-    const int fcol = col & 127;
-    const int ta = wv & 3, tb2 = wv >> 2;                  // output tiles (ta, 2*tb2) and (ta, 2*tb2 + 1)
+    const int col = tid % NC;                              // staged column: < F = y, else x
+    const int og = wv / (NC / 64);                         // which 16 of the step's 32 edges this thread stages
+    const bool is_y = (wv * 64) % NC < F;                  // wave-uniform
+    const int fcol = col % F;
+    const int ta = wv % NA, tb2 = wv / NA;                 // output tiles (ta, NT*tb2 + b)
 
-    f32x16 acc[2];
+    f32x16 acc[NT];
     float raw0[16], raw1[16], aux0[16], aux1[16];
     for (int k = 0; k < K; ++k) {
         const int tb = type_ptr[k], te = type_ptr[k + 1];
         if (te == tb) continue;
         const int steps = (te - tb + 31) / 32;
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NT; ++b)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[b][q] = 0.f;
 
@@ -111,8 +113,8 @@ __global__ void __launch_bounds__(512) edge_da_split128_kernel(
                 const int ca = 32 * ta + i;
                 const bf16x8 ah = frag(cur, 0, oc, ca), am = frag(cur, 1, oc, ca), al = frag(cur, 2, oc, ca);
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const int cb = 128 + 32 * (2 * tb2 + b) + i;
+                for (int b = 0; b < NT; ++b) {
+                    const int cb = F + 32 * (NT * tb2 + b) + i;
                     mma6(acc[b], ah, am, al, frag(cur, 0, oc, cb), frag(cur, 1, oc, cb), frag(cur, 2, oc, cb));
                 }
             }
@@ -127,8 +129,8 @@ __global__ void __launch_bounds__(512) edge_da_split128_kernel(
         if ((int)blockIdx.x < steps) {
             float* out = dA + (int64_t)k * F * F;
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int c = 32 * (2 * tb2 + b) + i;
+            for (int b = 0; b < NT; ++b) {
+                const int c = 32 * (NT * tb2 + b) + i;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const float v = acc[b][q];
@@ -139,30 +141,42 @@ __global__ void __launch_bounds__(512) edge_da_split128_kernel(
     }
 }
 
-int launch_edge_da_split128(const float* Y, const float* h, const int32_t* src, const int32_t* dst, const float* w,
-                            const int32_t* order, const int32_t* type_ptr, const float* gate, float* dA, int64_t E,
-                            int K, hipStream_t s) {
-    const size_t lds = (size_t)2 * 12 * 256 * 16;
-    int64_t gx = 256;                                       // one block per CU (96 KB of LDS)
+template <int F>
+static int launch_edge_da_split(const float* Y, const float* h, const int32_t* src, const int32_t* dst, const float* w,
+                                const int32_t* order, const int32_t* type_ptr, const float* gate, float* dA, int64_t E,
+                                int K, hipStream_t s) {
+    const size_t lds = (size_t)2 * 12 * (2 * F) * 16;       // 96 KB at F = 128 (1 block / CU), 48 KB at F = 64 (3)
+    int64_t gx = F == 128 ? 256 : 768;
     const int64_t need = ceil_div(E, 32) + K;
     if (gx > need) gx = need;
-#define MPNN_DA128(D, W, G)                                                                                         \
+#define MPNN_DA(D, W, G)                                                                                            \
     do {                                                                                                            \
         static bool attr_done = false;                                                                              \
         if (!attr_done) {                                                                                           \
-            (void)hipFuncSetAttribute((const void*)edge_da_split128_kernel<D, W, G>,                                \
+            (void)hipFuncSetAttribute((const void*)edge_da_split_kernel<F, D, W, G>,                                \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
             attr_done = true;                                                                                       \
         }                                                                                                           \
-        hipLaunchKernelGGL((edge_da_split128_kernel<D, W, G>), dim3((unsigned)gx), dim3(512), lds, s, Y, h, src, dst, \
+        hipLaunchKernelGGL((edge_da_split_kernel<F, D, W, G>), dim3((unsigned)gx), dim3(4 * F), lds, s, Y, h, src, dst, \
                            w, order, type_ptr, gate, dA, K);                                                        \
     } while (0)
     const bool hw = dst && w;
-    if (!dst) { if (gate) MPNN_DA128(false, false, true); else MPNN_DA128(false, false, false); }
-    else if (!hw) { if (gate) MPNN_DA128(true, false, true); else MPNN_DA128(true, false, false); }
-    else { if (gate) MPNN_DA128(true, true, true); else MPNN_DA128(true, true, false); }
-#undef MPNN_DA128
-    return launch_status("mpnn_edge_message_bwd_f32(dA, bf16x6 128)");
+    if (!dst) { if (gate) MPNN_DA(false, false, true); else MPNN_DA(false, false, false); }
+    else if (!hw) { if (gate) MPNN_DA(true, false, true); else MPNN_DA(true, false, false); }
+    else { if (gate) MPNN_DA(true, true, true); else MPNN_DA(true, true, false); }
+#undef MPNN_DA
+    return launch_status("mpnn_edge_message_bwd_f32(dA, bf16x6)");
+}
+
+int launch_edge_da_split128(const float* Y, const float* h, const int32_t* src, const int32_t* dst, const float* w,
+                            const int32_t* order, const int32_t* type_ptr, const float* gate, float* dA, int64_t E,
+                            int K, hipStream_t s) {
+    return launch_edge_da_split<128>(Y, h, src, dst, w, order, type_ptr, gate, dA, E, K, s);
+}
+int launch_edge_da_split64(const float* Y, const float* h, const int32_t* src, const int32_t* dst, const float* w,
+                           const int32_t* order, const int32_t* type_ptr, const float* gate, float* dA, int64_t E,
+                           int K, hipStream_t s) {
+    return launch_edge_da_split<64>(Y, h, src, dst, w, order, type_ptr, gate, dA, E, K, s);
 }
 
 }  // namespace mpnn
