@@ -87,7 +87,7 @@ int mpnn_edge_message_bwd_f32(const float* h, const float* A, const int32_t* src
  * Backward of message FOLLOWED BY adjacency-weighted aggregation, weight-gradient part, without a
  * materialised dmsg: dA[k] += sum_{e in type k} (w[e] * dagg[dst[e]]) (x) (gate[e] * h[src[e]]).
  * replaces: the autograd of edge_network.py:40,52 composed with adjacent_message_agg.py:18.
- * nf = mf in {64, 128} only (returns MPNN_EINVAL otherwise: callers fall back to segsum_bwd + edge_message_bwd).
+ * nf = mf in {64, 128, 256} only (returns MPNN_EINVAL otherwise: callers fall back to segsum_bwd + edge_message_bwd).
  */
 int mpnn_edge_message_agg_bwd_da_f32(const float* dagg, const float* h, const int32_t* src,
                                      const int32_t* dst, const float* w /* may be NULL */,

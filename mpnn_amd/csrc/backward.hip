@@ -552,6 +552,9 @@ int launch_gru_bwd_dw128(const float* m, const float* h, const float* ws, float*
 int launch_edge_da_split128(const float* Y, const float* h, const int32_t* src, const int32_t* dst, const float* w,
                             const int32_t* order, const int32_t* type_ptr, const float* gate, float* dA, int64_t E,
                             int K, hipStream_t s);
+int launch_edge_da_split256(const float* Y, const float* h, const int32_t* src, const int32_t* dst, const float* w,
+                            const int32_t* order, const int32_t* type_ptr, const float* gate, float* dA, int64_t E,
+                            int K, hipStream_t s);
 int launch_edge_da_split64(const float* Y, const float* h, const int32_t* src, const int32_t* dst, const float* w,
                            const int32_t* order, const int32_t* type_ptr, const float* gate, float* dA, int64_t E,
                            int K, hipStream_t s);
@@ -563,6 +566,8 @@ static bool math_fp32_only() {
     static const bool v = getenv("MPNN_GRU_MATH") && !strcmp(getenv("MPNN_GRU_MATH"), "fp32");
     return v;
 }
+int launch_gru_bwd_dw256(const float* m, const float* h, const float* ws, float* dW_ih, float* dW_hh, float* db_ih,
+                         float* db_hh, int64_t V, hipStream_t s);
 // fused H = 64 path (gru_bwd.hip)
 int launch_gru_bwd_fused64(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
                            const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
@@ -602,6 +607,8 @@ extern "C" int mpnn_edge_message_bwd_f32(const float* h, const float* A, const i
         rc = launch_status("mpnn_edge_message_bwd_f32(dA direct)");
     } else if (dA && mf == 128 && nf == 128 && K <= 64 && !math_fp32_only()) {
         rc = launch_edge_da_split128(dmsg, h, src, nullptr, nullptr, order, type_ptr, gate, dA, E, K, s);
+    } else if (dA && mf == 256 && nf == 256 && K <= 64 && !math_fp32_only()) {
+        rc = launch_edge_da_split256(dmsg, h, src, nullptr, nullptr, order, type_ptr, gate, dA, E, K, s);
     } else if (dA && mf == 128 && nf == 128 && K <= 64) {
         int64_t gx = 512;
         const int64_t need = ceil_div(E, 32) + K;
@@ -668,6 +675,7 @@ extern "C" int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const 
     rc = launch_rows_gemm<true, false>(ws + 3 * H, 6 * H, nullptr, nullptr, 0, W_hh, 0, 3 * H, dh, dh, H, V, 3 * H, H, s,
                                        "mpnn_gru_update_bwd_f32(dh)");
     if (rc) return rc;
+    if (H == 256 && !fp32_only) return launch_gru_bwd_dw256(m, h, ws, dW_ih, dW_hh, db_ih, db_hh, V, s);
     if (H == 128) {
         // dW (128 x 384) and db on the register-direct wide kernel: 8 waves = 4 a-blocks x 2 groups of 6 b-blocks
         int64_t gxd = 512;
@@ -697,11 +705,15 @@ extern "C" int mpnn_edge_message_agg_bwd_da_f32(const float* dagg, const float* 
                                                 const int32_t* type_ptr, const float* gate, float* dA, int64_t V,
                                                 int64_t E, int K, int nf, int mf, void* stream) {
     MPNN_REQUIRE(E >= 0 && V >= 0 && K >= 0, "mpnn_edge_message_agg_bwd_da_f32: negative size");
-    MPNN_REQUIRE(((nf == 64 && mf == 64) || (nf == 128 && mf == 128)) && K <= 64,
-                 "mpnn_edge_message_agg_bwd_da_f32: only nf = mf in {64, 128}, K <= 64 (got %d, %d, %d)", nf, mf, K);
+    MPNN_REQUIRE(nf == mf && (nf == 64 || nf == 128 || nf == 256) && K <= 64,
+                 "mpnn_edge_message_agg_bwd_da_f32: only nf = mf in {64, 128, 256}, K <= 64 (got %d, %d, %d)", nf, mf, K);
     if (E == 0) return MPNN_OK;
     MPNN_REQUIRE(dagg && h && src && dst && order && type_ptr && dA && K > 0,
                  "mpnn_edge_message_agg_bwd_da_f32: NULL buffer");
+    if (nf == 256) {
+        MPNN_REQUIRE(!math_fp32_only(), "mpnn_edge_message_agg_bwd_da_f32: width 256 has no fp32-only path");
+        return launch_edge_da_split256(dagg, h, src, dst, w, order, type_ptr, gate, dA, E, K, (hipStream_t)stream);
+    }
     if (nf == 128 && !math_fp32_only())
         return launch_edge_da_split128(dagg, h, src, dst, w, order, type_ptr, gate, dA, E, K, (hipStream_t)stream);
     if (nf == 128) {

@@ -12,15 +12,18 @@
 namespace mpnn {
 
 template <int F, bool HAS_DST, bool HAS_W, bool GATED>
-__global__ void __launch_bounds__(4 * F) edge_da_split_kernel(
+__global__ void __launch_bounds__(F >= 128 ? 512 : 256) edge_da_split_kernel(
     const float* __restrict__ Y, const float* __restrict__ h, const int32_t* __restrict__ src,
     const int32_t* __restrict__ dst, const float* __restrict__ w, const int32_t* __restrict__ order,
     const int32_t* __restrict__ type_ptr, const float* __restrict__ gate, float* dA, int K) {
     constexpr int NC = 2 * F;                              // staged columns [y | x]
     constexpr int SLOT = NC * 16;                          // bytes of one (piece, octet) plane
+    constexpr int NWV = F >= 128 ? 8 : 4;                  // waves per block
+    constexpr int EPS = F == 256 ? 16 : 32;                // edges per step (F = 256: 512 columns x 16 edges)
+    constexpr int NO = EPS / 8;                            // octets (MFMA fragments along the contraction) per step
     constexpr int NA = F / 32;                             // 32-wide output blocks per side
-    constexpr int NT = NA * NA / (4 * F / 64);             // output tiles per wave (2 at F = 128, 1 at F = 64)
-    constexpr int BUF = 12 * SLOT;                         // 3 pieces x 4 octets
+    constexpr int NT = NA * NA / NWV;                      // output tiles per wave (8 / 2 / 1 at F = 256 / 128 / 64)
+    constexpr int BUF = 3 * NO * SLOT;                     // 3 pieces x NO octets
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -37,7 +40,7 @@ __global__ void __launch_bounds__(4 * F) edge_da_split_kernel(
     for (int k = 0; k < K; ++k) {
         const int tb = type_ptr[k], te = type_ptr[k + 1];
         if (te == tb) continue;
-        const int steps = (te - tb + 31) / 32;
+        const int steps = (te - tb + EPS - 1) / EPS;
 #pragma unroll
         for (int b = 0; b < NT; ++b)
 #pragma unroll
@@ -49,7 +52,7 @@ __global__ void __launch_bounds__(4 * F) edge_da_split_kernel(
         // Masking and the w / gate factors are applied when the step is parked, so nothing waits at issue time.
         // Data is fetched TWO steps ahead (raw0 / raw1 alternate).
         auto load_raw = [&](int st, float (&raw)[16], float (&aux)[16]) {
-            const int p0 = tb + 32 * st + 16 * og;
+            const int p0 = tb + EPS * st + 16 * og;
             int e[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) e[u] = order[p0 + u < te ? p0 + u : tb];
@@ -69,7 +72,7 @@ __global__ void __launch_bounds__(4 * F) edge_da_split_kernel(
             }
         };
         auto park = [&](int buf, int st, const float (&raw)[16], const float (&aux)[16]) {
-            const int p0 = tb + 32 * st + 16 * og;
+            const int p0 = tb + EPS * st + 16 * og;
 #pragma unroll
             for (int o = 0; o < 2; ++o) {
                 f32x4 x0, x1;
@@ -85,12 +88,12 @@ __global__ void __launch_bounds__(4 * F) edge_da_split_kernel(
                 split8(x0, x1, ph, pm, pl);
                 char* base = smem + buf * BUF + (2 * og + o) * SLOT + col * 16;
                 *reinterpret_cast<bf16x8*>(base) = ph;
-                *reinterpret_cast<bf16x8*>(base + 4 * SLOT) = pm;
-                *reinterpret_cast<bf16x8*>(base + 8 * SLOT) = pl;
+                *reinterpret_cast<bf16x8*>(base + NO * SLOT) = pm;
+                *reinterpret_cast<bf16x8*>(base + 2 * NO * SLOT) = pl;
             }
         };
         auto frag = [&](int buf, int piece, int octet, int c) {
-            return *reinterpret_cast<const bf16x8*>(smem + buf * BUF + (piece * 4 + octet) * SLOT + c * 16);
+            return *reinterpret_cast<const bf16x8*>(smem + buf * BUF + (piece * NO + octet) * SLOT + c * 16);
         };
 
         int st = blockIdx.x;
@@ -108,7 +111,7 @@ __global__ void __launch_bounds__(4 * F) edge_da_split_kernel(
             if (st_now + 2 * g < steps) load_raw(st_now + 2 * g, rin, ain);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < EPS / 16; ++ks) {
                 const int oc = 2 * ks + hi;
                 const int ca = 32 * ta + i;
                 const bf16x8 ah = frag(cur, 0, oc, ca), am = frag(cur, 1, oc, ca), al = frag(cur, 2, oc, ca);
@@ -145,9 +148,9 @@ template <int F>
 static int launch_edge_da_split(const float* Y, const float* h, const int32_t* src, const int32_t* dst, const float* w,
                                 const int32_t* order, const int32_t* type_ptr, const float* gate, float* dA, int64_t E,
                                 int K, hipStream_t s) {
-    const size_t lds = (size_t)2 * 12 * (2 * F) * 16;       // 96 KB at F = 128 (1 block / CU), 48 KB at F = 64 (3)
-    int64_t gx = F == 128 ? 256 : 768;
-    const int64_t need = ceil_div(E, 32) + K;
+    const size_t lds = (size_t)2 * 3 * (F == 256 ? 2 : 4) * (2 * F) * 16;   // 96 KB at F >= 128 (1 block / CU), 48 KB at F = 64 (3)
+    int64_t gx = F >= 128 ? 256 : 768;
+    const int64_t need = ceil_div(E, F == 256 ? 16 : 32) + K;
     if (gx > need) gx = need;
 #define MPNN_DA(D, W, G)                                                                                            \
     do {                                                                                                            \
@@ -157,7 +160,7 @@ static int launch_edge_da_split(const float* Y, const float* h, const int32_t* s
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
             attr_done = true;                                                                                       \
         }                                                                                                           \
-        hipLaunchKernelGGL((edge_da_split_kernel<F, D, W, G>), dim3((unsigned)gx), dim3(4 * F), lds, s, Y, h, src, dst, \
+        hipLaunchKernelGGL((edge_da_split_kernel<F, D, W, G>), dim3((unsigned)gx), dim3(F >= 128 ? 512 : 256), lds, s, Y, h, src, dst, \
                            w, order, type_ptr, gate, dA, K);                                                        \
     } while (0)
     const bool hw = dst && w;
@@ -172,6 +175,11 @@ int launch_edge_da_split128(const float* Y, const float* h, const int32_t* src, 
                             const int32_t* order, const int32_t* type_ptr, const float* gate, float* dA, int64_t E,
                             int K, hipStream_t s) {
     return launch_edge_da_split<128>(Y, h, src, dst, w, order, type_ptr, gate, dA, E, K, s);
+}
+int launch_edge_da_split256(const float* Y, const float* h, const int32_t* src, const int32_t* dst, const float* w,
+                            const int32_t* order, const int32_t* type_ptr, const float* gate, float* dA, int64_t E,
+                            int K, hipStream_t s) {
+    return launch_edge_da_split<256>(Y, h, src, dst, w, order, type_ptr, gate, dA, E, K, s);
 }
 int launch_edge_da_split64(const float* Y, const float* h, const int32_t* src, const int32_t* dst, const float* w,
                            const int32_t* order, const int32_t* type_ptr, const float* gate, float* dA, int64_t E,

@@ -267,4 +267,130 @@ int launch_gru_bwd_dw128(const float* m, const float* h, const float* ws, float*
     return launch_status("mpnn_gru_update_bwd_f32(dW, H=128)");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same parked-fragment weight-gradient kernel at H = 256.  The step still stages 512 columns, now
+// [X (256) | one gate block of G (256)], so a block owns one (matrix, gate) pair: blockIdx.y = 3*matrix + gate,
+// output = the 256 x 256 block dW_matrix[:, gate*H : (gate+1)*H] as 8 x 8 tiles, wave = (a-pair, b-quad).
+// Reads the 6H workspace layout of the generic path (ws[row] = [dgi | dgh]).
+__global__ void __launch_bounds__(512) gru_bwd_dw256_kernel(const float* __restrict__ m, const float* __restrict__ h,
+                                                            const float* __restrict__ ws, float* dW_ih, float* dW_hh,
+                                                            float* db_ih, float* db_hh, int64_t V) {
+    constexpr int H = 256, LDW = 6 * H, NC = 2 * H;
+    constexpr int SLOT = NC * 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][3 pieces][2 octets][512][8] bf16
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, hi = lane >> 5;
+    const int mat = blockIdx.y / 3, gate = blockIdx.y % 3;
+    const float* X = mat == 0 ? m : h;
+    const float* colp = tid < H ? X + tid : ws + mat * 3 * H + gate * H + (tid - H);
+    const int64_t ldc = tid < H ? H : LDW;
+    const int ag = wv & 3, bg = wv >> 2;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+    float colsum = 0.f;
+
+    const int64_t steps = (V + 15) / 16;
+    float raw[16];
+    auto load_raw = [&](int64_t st) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            int64_t row = st * 16 + u;
+            if (row >= V) row = V - 1;
+            raw[u] = colp[row * ldc];
+        }
+    };
+    auto park = [&](int buf, int64_t st) {
+        if (st * 16 + 16 > V) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (st * 16 + u >= V) raw[u] = 0.f;
+        }
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const f32x4 x0 = {raw[8 * o], raw[8 * o + 1], raw[8 * o + 2], raw[8 * o + 3]};
+            const f32x4 x1 = {raw[8 * o + 4], raw[8 * o + 5], raw[8 * o + 6], raw[8 * o + 7]};
+            bf16x8 ph, pm, pl;
+            split8(x0, x1, ph, pm, pl);
+            char* base = smem + (size_t)buf * 6 * SLOT + o * SLOT + tid * 16;
+            *reinterpret_cast<bf16x8*>(base) = ph;
+            *reinterpret_cast<bf16x8*>(base + 2 * SLOT) = pm;
+            *reinterpret_cast<bf16x8*>(base + 4 * SLOT) = pl;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) colsum += raw[u];
+    };
+    auto frag = [&](int buf, int piece, int col) {
+        return *reinterpret_cast<const bf16x8*>(smem + (size_t)buf * 6 * SLOT + (piece * 2 + hi) * SLOT + col * 16);
+    };
+
+    int64_t st = blockIdx.x;
+    int cur = 0;
+    if (st < steps) {
+        load_raw(st);
+        park(0, st);
+    }
+    for (; st < steps; st += gridDim.x) {
+        __syncthreads();
+        const bool more = st + gridDim.x < steps;
+        if (more) load_raw(st + gridDim.x);
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 bh[4], bm[4], bl[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int col = H + 32 * (4 * bg + b) + i;
+            bh[b] = frag(cur, 0, col);
+            bm[b] = frag(cur, 1, col);
+            bl[b] = frag(cur, 2, col);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int col = 32 * (2 * ag + a) + i;
+            const bf16x8 ah = frag(cur, 0, col), am = frag(cur, 1, col), al = frag(cur, 2, col);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) mma6(acc[a][b], ah, am, al, bh[b], bm[b], bl[b]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) park(cur ^ 1, st + gridDim.x);
+        cur ^= 1;
+    }
+
+    float* dW = (mat == 0 ? dW_ih : dW_hh) + gate * H;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int col = 32 * (4 * bg + b) + i;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = 32 * (2 * ag + a) + acc_row(q, lane);
+                atomicAdd(dW + (int64_t)row * 3 * H + col, acc[a][b][q]);
+            }
+        }
+    if (tid >= H && blockIdx.x < steps) atomicAdd((mat == 0 ? db_ih : db_hh) + gate * H + (tid - H), colsum);
+}
+
+int launch_gru_bwd_dw256(const float* m, const float* h, const float* ws, float* dW_ih, float* dW_hh, float* db_ih,
+                         float* db_hh, int64_t V, hipStream_t s) {
+    const size_t lds = (size_t)2 * 3 * 2 * 512 * 16;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gru_bwd_dw256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int64_t steps = (V + 15) / 16;
+    int64_t gx = 43;                                        // x 6 (matrix, gate) jobs ~ one block per CU
+    if (gx > steps) gx = steps;
+    hipLaunchKernelGGL(gru_bwd_dw256_kernel, dim3((unsigned)gx, 6), dim3(512), lds, s, m, h, ws, dW_ih, dW_hh, db_ih,
+                       db_hh, V);
+    return launch_status("mpnn_gru_update_bwd_f32(dW, H=256)");
+}
+
 }  // namespace mpnn

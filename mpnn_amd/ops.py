@@ -241,7 +241,7 @@ class MessageAggregate(torch.autograd.Function):
         dout = dout.contiguous()
         need_dx = ctx.needs_input_grad[0] or (gate is not None and ctx.needs_input_grad[2])
         K, mf, nf = (int(s) for s in A.shape)
-        if not need_dx and mf == nf and mf in (64, 128) and K <= 64:
+        if not need_dx and mf == nf and mf in (64, 128, 256) and K <= 64:
             if not ctx.needs_input_grad[1]:
                 return None, None, None, None, None
             lib = _lib.load()

@@ -170,7 +170,7 @@ def test_lipo_model_backward(dev):
     _check_param_grads(model, f, 2e-4)      # six chained batch norms in the backward chain
 
 
-@pytest.mark.parametrize("H,K,V", [(64, 4, 2500), (128, 4, 900), (64, 1, 300), (32, 3, 400), (22, 5, 333)])
+@pytest.mark.parametrize("H,K,V", [(64, 4, 2500), (128, 4, 900), (256, 3, 500), (64, 1, 300), (32, 3, 400), (22, 5, 333)])
 @pytest.mark.parametrize("weighted", [False, True])
 @pytest.mark.parametrize("need_dh", [False, True])
 def test_message_aggregate_node(dev, H, K, V, weighted, need_dh):
