@@ -38,6 +38,7 @@ WORKLOADS = {
     "tiny": (2_000, 64, 3, "drug", "2k mols (plumbing check)"),
 }
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
+MFMA_F32_PEAK_TF = 157.3    # dense fp32 MFMA peak (MI355X_MICROARCH.md); the 1e-5 bar rules out plain bf16/xf32
 
 
 def parse():
@@ -135,6 +136,25 @@ def cpu_baseline(mb, hidden, steps, mode, budget_s):
     return {"value": edges / dt, "unit": "edges/s", "cores": cores, "kind": "port",
             "sample": "%d batches of 16 molecules of the same synthetic set, dense padded torch-CPU path, "
                       "%s, %.1f s" % (nb, "forward+backward" if mode == "train" else "forward", dt)}
+
+
+def stream_calibration(dev, nbytes):
+    """What a plain 2-reads-1-write stream of the aggregator's byte count reaches on THIS box (torch `add`), so the
+    aggregator's fraction of the 8 TB/s spec number can be read against the practical ceiling."""
+    n = int(nbytes // 12)
+    a = torch.empty(n, device=dev).normal_()
+    b = torch.empty(n, device=dev).normal_()
+    c = torch.empty(n, device=dev)
+    for _ in range(3):
+        torch.add(a, b, out=c)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        torch.add(a, b, out=c)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    return {"op": "torch.add, 2 reads : 1 write, same bytes", "GB/s": 12.0 * n / (ms * 1e-3) / 1e9, "ms": ms}
 
 
 def main():
@@ -261,6 +281,21 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": seg_ms, "algorithmic_bytes_per_launch": alg_bytes},
             "kernels_ms": {k: timer.mean_ms(k) for k in ("edge_message", "segsum", "gru_update")},
         }
+        # the two dense contractions of the path against the fp32 matrix-core peak (fp32 MFMA 157.3 TF).
+        # They run as bf16x6 (three-way split operands, six bf16 MFMAs per fp32 product), so "achieved" is in
+        # fp32-EQUIVALENT flops: useful multiply-adds of the fp32 problem, not bf16 issue slots.
+        msg_ms, gru_ms = timer.mean_ms("edge_message"), timer.mean_ms("gru_update")
+        out["roofline_contractions"] = [
+            {"kernel": "typed edge message (mpnn_edge_message_f32)", "bound": "mfma", "unit": "TFLOP/s",
+             "peak": MFMA_F32_PEAK_TF, "achieved": 2.0 * F * F * E / (msg_ms * 1e-3) / 1e12,
+             "frac": 2.0 * F * F * E / (msg_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "avg_launch_ms": msg_ms,
+             "hbm_GBs_algorithmic": (4.0 * F * V + 4.0 * F * E + 8.0 * E) / (msg_ms * 1e-3) / 1e9},
+            {"kernel": "masked GRU update (mpnn_gru_update_f32)", "bound": "mfma", "unit": "TFLOP/s",
+             "peak": MFMA_F32_PEAK_TF, "achieved": 12.0 * F * F * V / (gru_ms * 1e-3) / 1e12,
+             "frac": 12.0 * F * F * V / (gru_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "avg_launch_ms": gru_ms},
+        ]
+        if world == 1:
+            out["roofline"]["stream_calibration"] = stream_calibration(dev, alg_bytes)
         if dt_fwd is not None:
             out["forward"] = {"value": total_edges * T * args.steps / dt_fwd, "unit": "edges/s",
                               "ms_per_step": dt_fwd / args.steps * 1e3,

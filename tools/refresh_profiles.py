@@ -43,9 +43,20 @@ with open(ROOT + "/profiles/r01_c2_train_kernel_stats.md", "w") as f:
     f.write("\nAggregator: algorithmic bytes %.3f GB per launch, PMC traffic %.3f GB -> traffic/algorithmic = %.3f.\n"
             % (b["roofline"]["algorithmic_bytes_per_launch"] / 1e9, agg["hbm_bytes"] / 1e9,
                agg["hbm_bytes"] / b["roofline"]["algorithmic_bytes_per_launch"]))
-    f.write("Calibration on the same box (tools/bench_segsum.py): torch `add` (2R:1W, same bytes) 6006 GB/s, torch `copy_` 5285 GB/s.\n")
-    f.write("\nOther workloads (`profiles/r01_bench_c{3,4,5}.json`, measured a few commits earlier; hidden 128/256 use the "
-            "staged fp32 kernels, not yet tuned):\n\n| workload | training step ms | forward pass ms | aggregator frac of 8 TB/s |\n|---|---|---|---|\n")
+    cal = b["roofline"].get("stream_calibration")
+    if cal:
+        f.write("Calibration in the same bench run: %s reaches %.0f GB/s (%.3f ms).\n" % (cal["op"], cal["GB/s"], cal["ms"]))
+    try:
+        sq = json.load(open(ROOT + "/profiles/r01_sq_c2.json"))["kernels"]
+        f.write("\nSQ counters (`profiles/r01_sq_c2.json`, one `--pmc` pass; fractions of wave cycles, MFMA pipe busy as a "
+                "fraction of the kernel's duration per SIMD):\n\n| kernel | parked on s_waitcnt/barrier | issue stall | issuing | MFMA busy |\n|---|---|---|---|---|\n")
+        for k, v in sq.items():
+            f.write("| `%s` | %.2f | %.2f | %.2f | %s |\n" % (k[:70], v["wave_parked_frac"], v["issue_stall_frac"], v["issuing_frac"],
+                                                             "%.2f" % v["mfma_busy_frac"] if v["mfma_busy_frac"] is not None else "n/a"))
+    except FileNotFoundError:
+        pass
+    f.write("\nOther workloads (`profiles/r01_bench_c{3,4,5}.json`, same commit; hidden 128 runs on the bf16x6 kernels, hidden 256 "
+            "partly on the generic fp32 kernels):\n\n| workload | training step ms | forward pass ms | aggregator frac of 8 TB/s |\n|---|---|---|---|\n")
     for w in ("c3", "c4", "c5"):
         d = json.load(open(ROOT + "/profiles/r01_bench_%s.json" % w))
         f.write("| %s | %.1f | %.1f | %.3f |\n" % (d["config"]["workload"][:70], d["ms_per_step"], d["forward"]["ms_per_step"], d["roofline"]["frac"]))

@@ -8,10 +8,11 @@
 
 Units (MI355X_MICROARCH.md "rocprofv3 PMC slots"): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles
 summed over waves; WAIT_ANY (parked on s_waitcnt/barrier) + WAIT_INST_ANY (issue stall) + ACTIVE_INST_ANY ~= WAVE_CYCLES.
-SQ_VALU_MFMA_BUSY_CYCLES is in cycles summed over SIMDs; SQ_BUSY_CYCLES in cycles summed over shader engines, so
-the MFMA-pipe utilisation is reported against the kernel's duration-equivalent: MFMA_BUSY / (4 SIMD x BUSY_CU_CYCLES)
-is not available in one pass, hence mfma_busy_frac = MFMA_BUSY / (1024 SIMDs x GRBM_GUI_ACTIVE) when GRBM_GUI_ACTIVE
-was collected, else null.  MOPS counters are in units of 512 flops-equivalents (ops/512)."""
+SQ_VALU_MFMA_BUSY_CYCLES is in cycles summed over the chip's 1024 SIMDs (checked: the fp32 message kernel issues
+187.5k tiles x 64 MFMAs x 64 cycles = 7.68e8, the counter reads 7.67e8); GRBM_GUI_ACTIVE is summed over the 8 XCDs
+(1.34e7 for a 0.78 ms kernel = 8 x 1.67e6 cycles at ~2.15 GHz).  So
+    mfma_busy_frac = MFMA_BUSY / (1024 SIMDs x GUI_ACTIVE / 8)
+= the fraction of the kernel's duration the average SIMD's matrix pipe was busy."""
 import csv
 import glob
 import json
@@ -36,7 +37,7 @@ def main():
                "issue_stall_frac": m.get("SQ_WAIT_INST_ANY", 0.0) / wc,
                "issuing_frac": m.get("SQ_ACTIVE_INST_ANY", 0.0) / wc}
         gui = m.get("GRBM_GUI_ACTIVE")
-        row["mfma_busy_frac"] = (m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * gui)) if gui else None
+        row["mfma_busy_frac"] = (m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (128.0 * gui)) if gui else None
         out[k] = row
         print("%-58s parked %.2f stall %.2f issuing %.2f mfma_busy %s" % (
             k[:58], row["wave_parked_frac"], row["issue_stall_frac"], row["issuing_frac"],
