@@ -65,6 +65,9 @@ int mpnn_csr_fill(const float* adj, const float* bfm, int64_t rows, int cols, in
  * Typed edge message: msg[e, :] = A[type[e]] (mf x nf) . h[src[e], :]
  * replaces: mpnn_functions/message/edge_network.py:40,52 (per-pair form),
  *           :50 (the bmm), mpnn_functions/message/ggnn_msg_pass.py:19-31.
+ * K may be anything from 1 to E: few types (discrete bond features) run as dense contractions on the matrix
+ * cores; above 4096 types (continuous bond features, a matrix per bond) each matrix is streamed once and applied
+ * to its one or two edges.
  * Edges are visited in type-sorted order so one tile multiplies by one matrix:
  *   order[E]     edge ids stably sorted by type
  *   type_ptr[K+1] start of each type's run inside `order`

@@ -568,6 +568,9 @@ static bool math_fp32_only() {
 }
 int launch_gru_bwd_dw256(const float* m, const float* h, const float* ws, float* dW_ih, float* dW_hh, float* db_ih,
                          float* db_hh, int64_t V, hipStream_t s);
+int launch_edge_pertype(int mode, const float* h, const float* A, const int32_t* src, const int32_t* order,
+                        const int32_t* type_ptr, const float* gate, const float* dmsg, float* out, float* dA, int K,
+                        int nf, int mf, hipStream_t s);
 // fused H = 64 path (gru_bwd.hip)
 int launch_gru_bwd_fused64(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
                            const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
@@ -586,9 +589,13 @@ extern "C" int mpnn_edge_message_bwd_f32(const float* h, const float* A, const i
     MPNN_REQUIRE(E < (1ll << 31) && V < (1ll << 31), "mpnn_edge_message_bwd_f32: int32 index overflow");
     if (E == 0) return MPNN_OK;
     MPNN_REQUIRE(h && A && src && order && type_ptr && dmsg && K > 0, "mpnn_edge_message_bwd_f32: NULL buffer");
-    MPNN_REQUIRE(K <= 4096, "mpnn_edge_message_bwd_f32: K=%d edge types unsupported", K);
     hipStream_t s = (hipStream_t)stream;
     int rc = MPNN_OK;
+    if (K > 4096) {   // many matrices, few edges each: streaming matvec kernels (edge_pertype.hip)
+        if (dx) rc = launch_edge_pertype(1, h, A, src, order, type_ptr, gate, dmsg, dx, nullptr, K, nf, mf, s);
+        if (rc == MPNN_OK && dA) rc = launch_edge_pertype(2, h, A, src, order, type_ptr, gate, dmsg, nullptr, dA, K, nf, mf, s);
+        return rc;
+    }
     if (dx) {
         // dx[e, b] = sum_a dmsg[e, a] * A_k[a, b]  : X = dmsg (ld mf), B = A_k as [k=a][n=b]
         rc = launch_message_dx_resident(dmsg, A, order, type_ptr, dx, E, K, nf, mf, s);

@@ -19,6 +19,7 @@
 
 namespace mpnn {
 
+constexpr int kManyTypes = 4096;  // above this many matrices a "type" is a handful of edges: per-type matvec path
 constexpr int kTileEdges = 128;   // 4 waves x 32 rows
 constexpr int kKC = 64;           // k-chunk staged per pass
 constexpr int kLD = kKC + 4;      // padded LDS row stride (floats)
@@ -295,6 +296,10 @@ static size_t message_lds_bytes(int nb) {
 }
 
 // dx[e] = A_type(e)^T dmsg[e] on the resident-matrix kernel; returns 1 when the shape has no fast path
+// many matrices, few edges each (edge_pertype.hip)
+int launch_edge_pertype(int mode, const float* h, const float* A, const int32_t* src, const int32_t* order,
+                        const int32_t* type_ptr, const float* gate, const float* dmsg, float* out, float* dA, int K,
+                        int nf, int mf, hipStream_t s);
 // nf = mf = 128 on the bf16x6 pipe (edge_message128.hip)
 int launch_message_split128(const float* h, const float* A, const int32_t* src, const int32_t* order,
                             const int32_t* type_ptr, const float* gate, float* msg, int64_t E, int K, hipStream_t s);
@@ -335,7 +340,9 @@ extern "C" int mpnn_edge_message_f32(const float* h, const float* A, const int32
     MPNN_REQUIRE(E < (1ll << 31) && V < (1ll << 31), "mpnn_edge_message_f32: int32 index overflow");
     if (E == 0) return MPNN_OK;
     MPNN_REQUIRE(h && A && src && order && type_ptr && msg && K > 0, "mpnn_edge_message_f32: NULL buffer");
-    MPNN_REQUIRE(K <= 4096, "mpnn_edge_message_f32: K=%d edge types; use the per-edge-matrix path above 4096", K);
+    if (K > kManyTypes)   // continuous bond features: one or two edges per matrix, HBM-bound matvec (edge_pertype.hip)
+        return launch_edge_pertype(0, h, A, src, order, type_ptr, gate, nullptr, msg, nullptr, K, nf, mf,
+                                   (hipStream_t)stream);
     if ((nf & 3) == 0) {
         const uintptr_t al = reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(A) |
                              reinterpret_cast<uintptr_t>(gate);

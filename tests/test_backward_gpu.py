@@ -67,7 +67,8 @@ def test_gru_backward_random(dev, V, H):
 
 
 @pytest.mark.parametrize("nf,mf,K,V", [(8, 8, 4, 60), (22, 22, 5, 333), (64, 64, 4, 3000), (128, 128, 4, 700),
-                                       (256, 256, 3, 300), (64, 32, 2, 500)])
+                                       (256, 256, 3, 300), (64, 32, 2, 500), (64, 64, 100, 900),
+                                       (64, 64, 5000, 2500), (24, 40, 4500, 2400), (130, 70, 4200, 2300)])
 @pytest.mark.parametrize("gated", [False, True])
 def test_edge_message_backward(dev, nf, mf, K, V, gated):
     from mpnn_amd import ops

@@ -141,7 +141,9 @@ def _message_setup(rng, V, K, nf, mf, max_deg=5):
 
 
 @pytest.mark.parametrize("nf,mf,K,V", [(8, 8, 4, 50), (22, 22, 5, 333), (64, 64, 4, 2000), (64, 32, 3, 700),
-                                       (100, 72, 2, 300), (128, 128, 4, 900), (256, 256, 3, 400), (64, 64, 1, 129)])
+                                       (100, 72, 2, 300), (128, 128, 4, 900), (256, 256, 3, 400), (64, 64, 1, 129),
+                                       (64, 64, 70, 900), (22, 22, 600, 500),       # 64 < K <= 4096: staged kernel
+                                       (64, 64, 5000, 2600), (24, 40, 4500, 2400), (130, 70, 4200, 2300)])   # per-type matvec
 @pytest.mark.parametrize("gated", [False, True])
 def test_edge_message(dev, nf, mf, K, V, gated):
     from mpnn_amd import ops
