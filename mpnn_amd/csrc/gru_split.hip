@@ -16,6 +16,8 @@
 //     k contiguous: a B fragment of one piece = one ds_read_b128), 16-byte chunks XOR-swizzled by the
 //     column so the 16-lane read groups are conflict-free;
 //   * activations are split in registers right before use (8 floats -> 3 x bf16x8 per K=16 step).
+#include <stdlib.h>
+
 #include "split_math.h"
 
 namespace mpnn {
@@ -369,11 +371,208 @@ static int launch_split128(const float* m, const float* h, const float* mask, co
     return launch_status("mpnn_gru_update_f32(bf16x6, H=128)");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// H >= 128, weights STREAMED.  The column-sliced kernel above re-reads a row tile once per 32-feature slice, and PMC
+// shows those re-reads reach the fabric (16 GB for 3.8 GB of operands at H = 128); at H = 256 its resident slice
+// would not even fit.  Here a block owns a 64-feature slice (192 gate columns of both matrices) and the contraction
+// is cut into 32-wide K chunks: all 512 threads split chunk c+1 of the weights into bf16 pieces and park it in the
+// other half of a double-buffered LDS image (one barrier per chunk) while the eight waves multiply chunk c.
+// A wave owns 32 rows x 32 features (two waves share a row tile), accumulators r, z, gi_n, gh_n stay in registers
+// across the whole contraction, its operand rows arrive as 16-float pieces one chunk ahead.  Row operands are read
+// H/64 times (2 at H = 128, 4 at H = 256); the weights come out of L2.
+template <int H, bool HAS_MASK>
+__global__ void __launch_bounds__(512) gru_update_stream_kernel(
+    const float* __restrict__ m, const float* __restrict__ h, const float* __restrict__ mask,
+    const float* __restrict__ W_ih, const float* __restrict__ W_hh, const float* __restrict__ b_ih,
+    const float* __restrict__ b_hh, float* __restrict__ out, float* __restrict__ saved, int64_t V) {
+    constexpr int NS = H / 64, NCHUNK = H / 32, COLS = 192;
+    constexpr int IMGC = COLS * 64;            // bytes of one (matrix, piece) chunk image: 192 columns x 32 k bf16
+    constexpr int BUF = 6 * IMGC;              // 72 KB
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][2 matrices][3 pieces][192][32] bf16
+
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int slice = jb % NS;                                 // the NS slice blocks of a row group share an XCD
+    const int pblock = (jb / NS) * 8 + xcd, pblocks = gridDim.x / NS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hi = lane >> 5;
+    const int tr = wv >> 1, half = wv & 1;
+
+    const int64_t rounds_total = (V + 127) / 128;              // a round = 128 rows = 4 tiles, two waves per tile
+    if (pblock >= rounds_total) return;                        // block-uniform
+    const int64_t nrounds = (rounds_total - pblock + pblocks - 1) / pblocks;
+
+    const int fcol = 64 * slice + 32 * half + r;               // this lane's output feature
+    const float br = b_ih[fcol] + b_hh[fcol], bz = b_ih[H + fcol] + b_hh[H + fcol];
+    const float bni = b_ih[2 * H + fcol], bnh = b_hh[2 * H + fcol];
+
+
+    // ---- weight staging: unit = (matrix, k-octet of the chunk, column); 1536 units, three per thread ----
+    // per-thread constants of its three units: source pointer at chunk 0 and LDS byte offset
+    const float* wsrc[3];
+    int ldst[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int u = tid + 512 * j;
+        const int mat = u / 768, rem = u % 768;
+        const int o = rem / COLS, cl = rem % COLS;
+        wsrc[j] = (mat ? W_hh : W_ih) + (int64_t)(8 * o) * 3 * H + (cl / 64) * H + 64 * slice + (cl % 64);
+        ldst[j] = mat * 3 * IMGC + cl * 64 + ((o ^ ((cl >> 2) & 3)) << 4);
+    }
+    float raw[3][8];
+    auto stage_load = [&](int c) {
+        const int64_t off = (int64_t)(32 * c) * 3 * H;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float* W = wsrc[j] + off;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) raw[j][i] = W[(int64_t)i * 3 * H];
+        }
+    };
+    auto stage_write = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const f32x4 x0 = {raw[j][0], raw[j][1], raw[j][2], raw[j][3]};
+            const f32x4 x1 = {raw[j][4], raw[j][5], raw[j][6], raw[j][7]};
+            bf16x8 ph, pm, pl;
+            split8(x0, x1, ph, pm, pl);
+            char* base = smem + buf * BUF + ldst[j];
+            *reinterpret_cast<bf16x8*>(base) = ph;
+            *reinterpret_cast<bf16x8*>(base + IMGC) = pm;
+            *reinterpret_cast<bf16x8*>(base + 2 * IMGC) = pl;
+        }
+    };
+    // B fragment: column cl = gate*64 + 32*half + r, k-octet 2*hi + st of the chunk
+    auto bfrag = [&](int buf, int mat, int piece, int gate, int st) {
+        const int cl = gate * 64 + 32 * half + r;
+        const int o = 2 * hi + st;
+        return *reinterpret_cast<const bf16x8*>(smem + buf * BUF + (mat * 3 + piece) * IMGC + cl * 64 +
+                                                ((o ^ ((cl >> 2) & 3)) << 4));
+    };
+    // this lane's 16 floats of chunk c of operand X for row tile `tile`
+    auto load_rows = [&](const float* __restrict__ X, int64_t tile, int c, f32x4 (&f)[4]) {
+        int64_t row = tile * 32 + r;
+        if (row >= V) row = V - 1;
+        const float* p = X + row * H + 32 * c + 16 * hi;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f[q] = *reinterpret_cast<const f32x4*>(p + 4 * q);
+    };
+
+    f32x16 acc_r, acc_z, acc_ni, acc_nh;
+    f32x4 am0[4], ah0[4], am1[4], ah1[4];
+    int cur = 0;
+    int64_t tile = ((int64_t)pblock) * 4 + tr;
+
+    // one K chunk: stage the next chunk of weights, fetch the next chunk of rows, multiply the current one
+    auto chunk = [&](int c, int64_t tile_next, f32x4 (&xm)[4], f32x4 (&xh)[4], f32x4 (&nm)[4], f32x4 (&nh)[4]) {
+        __syncthreads();                                   // buffer `cur` is complete, `cur ^ 1` is free
+        const int cn = (c + 1) % NCHUNK;
+        stage_load(cn);
+        load_rows(m, cn == 0 ? tile_next : tile, cn, nm);
+        load_rows(h, cn == 0 ? tile_next : tile, cn, nh);
+        __builtin_amdgcn_sched_barrier(0);
+        // twelve mma6 groups (operand, K step, gate)
+        bf16x8 a_h, a_m, a_l;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int mat = i / 6, st = (i / 3) % 2, gate = i % 3;
+            if (gate == 0) {
+                if (mat == 0) split8(xm[2 * st], xm[2 * st + 1], a_h, a_m, a_l);
+                else split8(xh[2 * st], xh[2 * st + 1], a_h, a_m, a_l);
+            }
+            f32x16& acc = gate == 0 ? acc_r : gate == 1 ? acc_z : (mat == 0 ? acc_ni : acc_nh);
+            mma6(acc, a_h, a_m, a_l, bfrag(cur, mat, 0, gate, st), bfrag(cur, mat, 1, gate, st), bfrag(cur, mat, 2, gate, st));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stage_write(cur ^ 1);
+        cur ^= 1;
+    };
+
+    stage_load(0);
+    stage_write(0);
+    load_rows(m, tile, 0, am0);
+    load_rows(h, tile, 0, ah0);
+    for (int64_t rd = 0; rd < nrounds; ++rd) {
+        const int64_t tile_next = rd + 1 < nrounds ? tile + (int64_t)pblocks * 4 : tile;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc_r[i] = 0.f; acc_z[i] = 0.f; acc_ni[i] = 0.f; acc_nh[i] = 0.f; }
+#pragma unroll 1
+        for (int c = 0; c < NCHUNK; c += 2) {
+            chunk(c, tile_next, am0, ah0, am1, ah1);
+            chunk(c + 1, tile_next, am1, ah1, am0, ah0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float mk4[4], hv4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int64_t row = tile * 32 + 8 * g + 4 * hi + u;
+                if (row >= V) row = V - 1;
+                mk4[u] = HAS_MASK ? mask[row] : 1.0f;
+                hv4[u] = h[row * H + fcol];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = 4 * g + u;
+                const int64_t row = tile * 32 + 8 * g + 4 * hi + u;
+                const float mk = mk4[u];
+                const float rg = sigmoid_fast(acc_r[i] + br) * mk;
+                const float zg = sigmoid_fast(acc_z[i] + bz) * mk;
+                const float nh = acc_nh[i] + bnh;
+                const float ng = tanh_fast(acc_ni[i] + bni + rg * nh) * mk;
+                const float o = ((1.0f - zg) * ng + zg * hv4[u]) * mk;
+                if (row < V) {
+                    __builtin_nontemporal_store(o, out + row * H + fcol);
+                    if (saved) {
+                        float* sv = saved + row * 4 * H + fcol;
+                        __builtin_nontemporal_store(rg, sv);
+                        __builtin_nontemporal_store(zg, sv + H);
+                        __builtin_nontemporal_store(ng, sv + 2 * H);
+                        __builtin_nontemporal_store(nh, sv + 3 * H);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        tile = tile_next;
+    }
+}
+
+template <int H>
+static int launch_stream(const float* m, const float* h, const float* mask, const float* W_ih, const float* W_hh,
+                         const float* b_ih, const float* b_hh, float* out, float* saved, int64_t V, hipStream_t s) {
+    constexpr int NS = H / 64;
+    const size_t lds = (size_t)2 * 6 * 192 * 64;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gru_update_stream_kernel<H, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gru_update_stream_kernel<H, false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int64_t rounds = (V + 127) / 128;
+    int64_t pblocks = 256 / NS;                             // x NS slices = one block per CU (144 KB of LDS)
+    if (pblocks > rounds) pblocks = rounds;
+    pblocks = (pblocks + 7) / 8 * 8;                        // XCD-aware numbering wants groups of 8 row blocks
+    const dim3 grid((unsigned)(pblocks * NS)), block(512);
+    if (mask)
+        hipLaunchKernelGGL((gru_update_stream_kernel<H, true>), grid, block, lds, s, m, h, mask, W_ih, W_hh, b_ih, b_hh,
+                           out, saved, V);
+    else
+        hipLaunchKernelGGL((gru_update_stream_kernel<H, false>), grid, block, lds, s, m, h, mask, W_ih, W_hh, b_ih, b_hh,
+                           out, saved, V);
+    return launch_status("mpnn_gru_update_f32(bf16x6, streamed weights)");
+}
+
 // returns 1 when the width has no split-precision path
 int launch_gru_split(const float* m, const float* h, const float* mask, const float* W_ih, const float* W_hh,
                      const float* b_ih, const float* b_hh, float* out, float* saved, int64_t V, int H, hipStream_t s) {
     if (H == 64) return launch_split<64, 2, 8>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, s);
+    static const bool stream128 = getenv("MPNN_GRU128_STREAM") != nullptr;
+    if (H == 128 && stream128) return launch_stream<128>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, s);
     if (H == 128) return launch_split128(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, s);
+    if (H == 256) return launch_stream<256>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, s);
     return 1;
 }
 
