@@ -566,6 +566,10 @@ static bool math_fp32_only() {
     static const bool v = getenv("MPNN_GRU_MATH") && !strcmp(getenv("MPNN_GRU_MATH"), "fp32");
     return v;
 }
+int launch_gru_bwd_dx_stream256(const float* ws, const float* W_ih, const float* W_hh, float* dm, float* dh, int64_t V,
+                                hipStream_t s);
+int launch_gru_bwd_dx_stream128(const float* ws, const float* W_ih, const float* W_hh, float* dm, float* dh, int64_t V,
+                                hipStream_t s);
 int launch_gru_bwd_dw256(const float* m, const float* h, const float* ws, float* dW_ih, float* dW_hh, float* db_ih,
                          float* db_hh, int64_t V, hipStream_t s);
 int launch_edge_pertype(int mode, const float* h, const float* A, const int32_t* src, const int32_t* order,
@@ -661,13 +665,17 @@ extern "C" int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const 
     if (g > 256 * 16) g = 256 * 16;
     static const bool fp32_only = getenv("MPNN_GRU_MATH") && !strcmp(getenv("MPNN_GRU_MATH"), "fp32");
     int rc;
-    if (H == 128 && !fp32_only) {
+    if ((H == 128 || H == 256) && !fp32_only) {
         hipLaunchKernelGGL(gru_gate_grad_kernel<true>, dim3((unsigned)g), dim3(256), 0, s, dout, h, mask, saved, ws, dh, V,
                            H);
         rc = launch_status("mpnn_gru_update_bwd_f32(gates)");
         if (rc) return rc;
-        rc = launch_gru_bwd_dx128(ws, W_ih, W_hh, dm, dh, V, s);
+        static const bool stream128 = getenv("MPNN_GRU128_STREAM") != nullptr;
+        if (H == 256) rc = launch_gru_bwd_dx_stream256(ws, W_ih, W_hh, dm, dh, V, s);
+        else if (stream128) rc = launch_gru_bwd_dx_stream128(ws, W_ih, W_hh, dm, dh, V, s);
+        else rc = launch_gru_bwd_dx128(ws, W_ih, W_hh, dm, dh, V, s);
         if (rc) return rc;
+        if (H == 256) return launch_gru_bwd_dw256(m, h, ws, dW_ih, dW_hh, db_ih, db_hh, V, s);
         return launch_gru_bwd_dw128(m, h, ws, dW_ih, dW_hh, db_ih, db_hh, V, s);
     }
     hipLaunchKernelGGL(gru_gate_grad_kernel<false>, dim3((unsigned)g), dim3(256), 0, s, dout, h, mask, saved, ws, dh, V,
@@ -682,7 +690,6 @@ extern "C" int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const 
     rc = launch_rows_gemm<true, false>(ws + 3 * H, 6 * H, nullptr, nullptr, 0, W_hh, 0, 3 * H, dh, dh, H, V, 3 * H, H, s,
                                        "mpnn_gru_update_bwd_f32(dh)");
     if (rc) return rc;
-    if (H == 256 && !fp32_only) return launch_gru_bwd_dw256(m, h, ws, dW_ih, dW_hh, db_ih, db_hh, V, s);
     if (H == 128) {
         // dW (128 x 384) and db on the register-direct wide kernel: 8 waves = 4 a-blocks x 2 groups of 6 b-blocks
         int64_t gxd = 512;

@@ -271,11 +271,11 @@ int launch_gru_bwd_dw128(const float* m, const float* h, const float* ws, float*
 // The same parked-fragment weight-gradient kernel at H = 256.  The step still stages 512 columns, now
 // [X (256) | one gate block of G (256)], so a block owns one (matrix, gate) pair: blockIdx.y = 3*matrix + gate,
 // output = the 256 x 256 block dW_matrix[:, gate*H : (gate+1)*H] as 8 x 8 tiles, wave = (a-pair, b-quad).
-// Reads the 6H workspace layout of the generic path (ws[row] = [dgi | dgh]).
+// Reads the compact workspace (ws[row] = [dar daz dan dnh]): gate block 2 of W_hh pairs with block 3 (dnh).
 __global__ void __launch_bounds__(512) gru_bwd_dw256_kernel(const float* __restrict__ m, const float* __restrict__ h,
                                                             const float* __restrict__ ws, float* dW_ih, float* dW_hh,
                                                             float* db_ih, float* db_hh, int64_t V) {
-    constexpr int H = 256, LDW = 6 * H, NC = 2 * H;
+    constexpr int H = 256, LDW = 4 * H, NC = 2 * H;
     constexpr int SLOT = NC * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][3 pieces][2 octets][512][8] bf16
 
@@ -284,7 +284,7 @@ __global__ void __launch_bounds__(512) gru_bwd_dw256_kernel(const float* __restr
     const int i = lane & 31, hi = lane >> 5;
     const int mat = blockIdx.y / 3, gate = blockIdx.y % 3;
     const float* X = mat == 0 ? m : h;
-    const float* colp = tid < H ? X + tid : ws + mat * 3 * H + gate * H + (tid - H);
+    const float* colp = tid < H ? X + tid : ws + ((mat == 1 && gate == 2) ? 3 : gate) * H + (tid - H);
     const int64_t ldc = tid < H ? H : LDW;
     const int ag = wv & 3, bg = wv >> 2;
 
@@ -391,6 +391,174 @@ int launch_gru_bwd_dw256(const float* m, const float* h, const float* ws, float*
     hipLaunchKernelGGL(gru_bwd_dw256_kernel, dim3((unsigned)gx, 6), dim3(512), lds, s, m, h, ws, dW_ih, dW_hh, db_ih,
                        db_hh, V);
     return launch_status("mpnn_gru_update_bwd_f32(dW, H=256)");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+//   gru_bwd_dx_stream_kernel<H>   dm, dh with the weights STREAMED (same idea as gru_update_stream_kernel): a block
+// owns 64 output features of dm and of dh, the contraction over the 3H gate columns is cut into 64-wide chunks of one
+// gate block, all threads split the next chunk of W_ih / W_hh rows into a double-buffered LDS image while the waves
+// multiply the current one.  For the r and z blocks both products share the operand (dar, daz); the third block
+// pairs dan with W_ih and dnh with W_hh.  Reads the compact workspace ws[row] = [dar daz dan dnh].
+template <int H>
+__global__ void __launch_bounds__(512) gru_bwd_dx_stream_kernel(const float* __restrict__ ws,
+                                                                const float* __restrict__ W_ih,
+                                                                const float* __restrict__ W_hh, float* __restrict__ dm,
+                                                                float* __restrict__ dh, int64_t V) {
+    constexpr int NS = H / 64, CPS = H / 64, NCT = 3 * CPS, LDW = 4 * H;
+    constexpr int IMGC = 64 * 128;             // one (matrix, piece) chunk image: 64 output rows x 64 k bf16
+    constexpr int BUF = 6 * IMGC;              // 48 KB
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int slice = jb % NS;
+    const int pblock = (jb / NS) * 8 + xcd, pblocks = gridDim.x / NS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hi = lane >> 5;
+    const int tr = wv >> 1, half = wv & 1;
+
+    const int64_t rounds_total = (V + 127) / 128;
+    if (pblock >= rounds_total) return;
+    const int64_t nrounds = (rounds_total - pblock + pblocks - 1) / pblocks;
+    const int fcol = 64 * slice + 32 * half + r;
+
+    // staging unit = (matrix, output row n, k-octet): 1024 units, two per thread, 32 contiguous bytes each
+    const float* wsrc[2];
+    int ldst[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int u = tid + 512 * j;
+        const int mat = u / 512, rem = u % 512;
+        const int n = rem / 8, o = rem % 8;
+        wsrc[j] = (mat ? W_hh : W_ih) + (int64_t)(64 * slice + n) * 3 * H + 8 * o;
+        ldst[j] = mat * 3 * IMGC + n * 128 + ((o ^ ((n >> 1) & 7)) << 4);
+    }
+    f32x4 raw[2][2];
+    auto stage_load = [&](int ct) {                        // chunk ct = gate block ct / CPS, 64 columns at 64*(ct % CPS)
+        const int off = (ct / CPS) * H + 64 * (ct % CPS);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            raw[j][0] = *reinterpret_cast<const f32x4*>(wsrc[j] + off);
+            raw[j][1] = *reinterpret_cast<const f32x4*>(wsrc[j] + off + 4);
+        }
+    };
+    auto stage_write = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bf16x8 ph, pm, pl;
+            split8(raw[j][0], raw[j][1], ph, pm, pl);
+            char* base = smem + buf * BUF + ldst[j];
+            *reinterpret_cast<bf16x8*>(base) = ph;
+            *reinterpret_cast<bf16x8*>(base + IMGC) = pm;
+            *reinterpret_cast<bf16x8*>(base + 2 * IMGC) = pl;
+        }
+    };
+    auto bfrag = [&](int buf, int mat, int piece, int st) {
+        const int n = 32 * half + r;
+        const int o = 4 * hi + st;
+        return *reinterpret_cast<const bf16x8*>(smem + buf * BUF + (mat * 3 + piece) * IMGC + n * 128 +
+                                                ((o ^ ((n >> 1) & 7)) << 4));
+    };
+    // this lane's 32 floats of chunk ct of the gradient block `blk` for row tile `tile`
+    auto load_rows = [&](int64_t tile, int blk, int cc, f32x4 (&f)[8]) {
+        int64_t row = tile * 32 + r;
+        if (row >= V) row = V - 1;
+        const float* p = ws + row * LDW + blk * H + 64 * cc + 32 * hi;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) f[q] = *reinterpret_cast<const f32x4*>(p + 4 * q);
+    };
+
+    f32x16 d_m, d_h;
+    f32x4 a0[8], a1[8], b0[8], b1[8];                      // operand of dm (a*) and of dh (b*, only in the n block)
+    int cur = 0;
+    int64_t tile = (int64_t)pblock * 4 + tr;
+
+    auto chunk = [&](int ct, int64_t tile_next, f32x4 (&xa)[8], f32x4 (&xb)[8], f32x4 (&na)[8], f32x4 (&nb)[8]) {
+        __syncthreads();
+        const int cn = (ct + 1) % NCT;
+        const int gn = cn / CPS;
+        stage_load(cn);
+        load_rows(cn == 0 ? tile_next : tile, gn, cn % CPS, na);
+        if (gn == 2) load_rows(tile, 3, cn % CPS, nb);     // dnh (never the first chunk of a round)
+        __builtin_amdgcn_sched_barrier(0);
+        const bool shared = ct / CPS < 2;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            bf16x8 a_h, a_m, a_l;
+            split8(xa[2 * st], xa[2 * st + 1], a_h, a_m, a_l);
+            mma6(d_m, a_h, a_m, a_l, bfrag(cur, 0, 0, st), bfrag(cur, 0, 1, st), bfrag(cur, 0, 2, st));
+            __builtin_amdgcn_sched_barrier(0);
+            if (!shared) split8(xb[2 * st], xb[2 * st + 1], a_h, a_m, a_l);
+            mma6(d_h, a_h, a_m, a_l, bfrag(cur, 1, 0, st), bfrag(cur, 1, 1, st), bfrag(cur, 1, 2, st));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stage_write(cur ^ 1);
+        cur ^= 1;
+    };
+
+    stage_load(0);
+    stage_write(0);
+    load_rows(tile, 0, 0, a0);
+    for (int64_t rd = 0; rd < nrounds; ++rd) {
+        const int64_t tile_next = rd + 1 < nrounds ? tile + (int64_t)pblocks * 4 : tile;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { d_m[i] = 0.f; d_h[i] = 0.f; }
+#pragma unroll 1
+        for (int ct = 0; ct < NCT; ct += 2) {
+            chunk(ct, tile_next, a0, b0, a1, b1);
+            chunk(ct + 1, tile_next, a1, b1, a0, b0);
+        }
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            float prev[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int64_t row = tile * 32 + 8 * g4 + 4 * hi + u;
+                if (row >= V) row = V - 1;
+                prev[u] = dh[row * H + fcol];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = 4 * g4 + u;
+                const int64_t row = tile * 32 + 8 * g4 + 4 * hi + u;
+                if (row < V) {
+                    dm[row * H + fcol] = d_m[i];
+                    dh[row * H + fcol] = d_h[i] + prev[u];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        tile = tile_next;
+    }
+}
+
+template <int H>
+static int launch_dx_stream(const float* ws, const float* W_ih, const float* W_hh, float* dm, float* dh, int64_t V,
+                            hipStream_t s) {
+    constexpr int NS = H / 64;
+    const size_t lds = (size_t)2 * 6 * 64 * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gru_bwd_dx_stream_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr_done = true;
+    }
+    const int64_t rounds = (V + 127) / 128;
+    int64_t pblocks = 256 / NS;
+    if (pblocks > rounds) pblocks = rounds;
+    pblocks = (pblocks + 7) / 8 * 8;
+    hipLaunchKernelGGL(gru_bwd_dx_stream_kernel<H>, dim3((unsigned)(pblocks * NS)), dim3(512), lds, s, ws, W_ih, W_hh, dm,
+                       dh, V);
+    return launch_status("mpnn_gru_update_bwd_f32(dx, streamed weights)");
+}
+
+int launch_gru_bwd_dx_stream256(const float* ws, const float* W_ih, const float* W_hh, float* dm, float* dh, int64_t V,
+                                hipStream_t s) {
+    return launch_dx_stream<256>(ws, W_ih, W_hh, dm, dh, V, s);
+}
+int launch_gru_bwd_dx_stream128(const float* ws, const float* W_ih, const float* W_hh, float* dm, float* dh, int64_t V,
+                                hipStream_t s) {
+    return launch_dx_stream<128>(ws, W_ih, W_hh, dm, dh, V, s);
 }
 
 }  // namespace mpnn
