@@ -305,6 +305,8 @@ int launch_message_split128(const float* h, const float* A, const int32_t* src, 
                             const int32_t* type_ptr, const float* gate, float* msg, int64_t E, int K, hipStream_t s);
 int launch_message_dx_split128(const float* dmsg, const float* A, const int32_t* order, const int32_t* type_ptr,
                                float* dx, int64_t E, int K, hipStream_t s);
+int launch_message_stream256(const float* h, const float* A, const int32_t* src, const int32_t* order,
+                             const int32_t* type_ptr, const float* gate, float* msg, int64_t E, int K, hipStream_t s);
 int launch_message_split64(const float* h, const float* A, const int32_t* src, const int32_t* order,
                            const int32_t* type_ptr, const float* gate, float* msg, int64_t E, int K, hipStream_t s);
 int launch_message_dx_split64(const float* dmsg, const float* A, const int32_t* order, const int32_t* type_ptr,
@@ -356,6 +358,7 @@ extern "C" int mpnn_edge_message_f32(const float* h, const float* A, const int32
         if (nf == 64 && nb == 1) return launch_message_resident<64, 1, false>(h, A, src, order, type_ptr, gate, msg, E, K, mf, st);
         if (nf == 32 && nb == 1) return launch_message_resident<32, 1, false>(h, A, src, order, type_ptr, gate, msg, E, K, mf, st);
         if (nf == 128 && mf == 128 && !fp32_only()) return launch_message_split128(h, A, src, order, type_ptr, gate, msg, E, K, st);
+        if (nf == 256 && mf == 256 && !fp32_only()) return launch_message_stream256(h, A, src, order, type_ptr, gate, msg, E, K, st);
     }
     const int64_t tiles = ceil_div(E, kTileEdges) + K;   // upper bound; surplus blocks exit at once
     const dim3 grid((unsigned)tiles), block(256);

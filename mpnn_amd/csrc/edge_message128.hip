@@ -198,3 +198,175 @@ int launch_message_dx_split64(const float* dmsg, const float* A, const int32_t* 
 }
 
 }  // namespace mpnn
+
+// ---------------------------------------------------------------------------------------------------------------
+// nf = mf = 256: the three images of one A_k are 393 KB, so the matrix is STREAMED like the GRU weights at this width
+// (gru_split.hip, gru_update_stream_kernel): a block owns a 64-feature output slice, the contraction is cut into four
+// 64-wide chunks, all threads split the next chunk of the 64 matrix rows into a double-buffered LDS image while the
+// eight waves (one 32-edge tile each, 64 output features) multiply the current one.  Types are walked in order;
+// within a type a round is 256 edges.
+namespace mpnn {
+
+template <bool GATED>
+__global__ void __launch_bounds__(512) edge_message_stream256_kernel(
+    const float* __restrict__ h, const float* __restrict__ A, const int32_t* __restrict__ src,
+    const int32_t* __restrict__ order, const int32_t* __restrict__ type_ptr, const float* __restrict__ gate,
+    float* __restrict__ msg, int K) {
+    constexpr int F = 256, NS = F / 64, KC = 64, NCT = F / KC;
+    constexpr int IMGC = 64 * 2 * KC;          // one piece of a chunk image: 64 rows x 64 k bf16 = 8 KB
+    constexpr int BUF = 3 * IMGC;              // 24 KB
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int slice = jb % NS;
+    const int pblock = (jb / NS) * 8 + xcd, pblocks = gridDim.x / NS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hi = lane >> 5;
+
+    // staging unit = (matrix row n of the slice, k-octet of the chunk): 64 x 8 = 512 units, one per thread
+    const int sn = tid / 8, so = tid % 8;
+    const int wofs = (64 * slice + sn) * F + 8 * so;
+    const int ldst = sn * 2 * KC + ((so ^ ((sn >> 1) & 7)) << 4);
+    auto bfrag = [&](int buf, int piece, int nb, int st) {   // K step st (0..3) of the chunk, octet 4*hi + st
+        const int n = 32 * nb + r;
+        const int o = 4 * hi + st;
+        return *reinterpret_cast<const bf16x8*>(smem + buf * BUF + piece * IMGC + n * 2 * KC + ((o ^ ((n >> 1) & 7)) << 4));
+    };
+
+    int cur = 0;
+    for (int k = 0; k < K; ++k) {
+        const int tb = type_ptr[k], te = type_ptr[k + 1];
+        if (te == tb) continue;
+        const int rounds_total = (te - tb + 255) / 256;
+        if (pblock >= rounds_total) continue;                // block-uniform
+        const int nrounds = (rounds_total - pblock + pblocks - 1) / pblocks;
+        const float* Ak = A + (int64_t)k * F * F;
+
+        f32x4 raw[2];
+        auto stage_load = [&](int ct) {
+            raw[0] = *reinterpret_cast<const f32x4*>(Ak + wofs + KC * ct);
+            raw[1] = *reinterpret_cast<const f32x4*>(Ak + wofs + KC * ct + 4);
+        };
+        auto stage_write = [&](int buf) {
+            bf16x8 ph, pm, pl;
+            split8(raw[0], raw[1], ph, pm, pl);
+            char* base = smem + buf * BUF + ldst;
+            *reinterpret_cast<bf16x8*>(base) = ph;
+            *reinterpret_cast<bf16x8*>(base + IMGC) = pm;
+            *reinterpret_cast<bf16x8*>(base + 2 * IMGC) = pl;
+        };
+        // lane r owns edge slot tb + 32*tile + r; slots past the end reuse the type's first edge and are not stored
+        auto edge_of = [&](int tile) {
+            const int pos = tb + 32 * tile + r;
+            return order[pos < te ? pos : tb];
+        };
+        // 32 floats (chunk ct, this lane half) of the edge's source row / of its gate row
+        auto load_rows = [&](int s_row, int ct, f32x4 (&f)[8]) {
+            const float* p = h + (int64_t)s_row * F + KC * ct + 32 * hi;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) f[q] = *reinterpret_cast<const f32x4*>(p + 4 * q);
+        };
+        auto load_gate = [&](int e, int ct, f32x4 (&f)[8]) {
+            const float* g = gate + (int64_t)e * F + KC * ct + 32 * hi;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) f[q] = *reinterpret_cast<const f32x4*>(g + 4 * q);
+        };
+
+        int tile = pblock * 8 + wv;
+        int e_cur = edge_of(tile), s_cur = src[e_cur];
+        f32x4 x0[8], x1[8], gb[8];
+        f32x16 acc[2];
+        __syncthreads();                                     // the previous type is done with both buffers
+        stage_load(0);
+        stage_write(cur);
+        load_rows(s_cur, 0, x0);
+        if (GATED) {
+            load_gate(e_cur, 0, gb);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x0[q] *= gb[q];
+        }
+
+        // the gate chunk is multiplied in after the MFMAs of the running chunk are issued (see the 128 kernel)
+        auto chunk = [&](int ct, int e_n, int s_n, f32x4 (&xc)[8], f32x4 (&xn)[8]) {
+            __syncthreads();
+            const int cn = (ct + 1) % NCT;
+            stage_load(cn);
+            if (cn == 0) {
+                load_rows(s_n, 0, xn);
+                if (GATED) load_gate(e_n, 0, gb);
+            } else {
+                load_rows(s_cur, cn, xn);
+                if (GATED) load_gate(e_cur, cn, gb);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                bf16x8 a_h, a_m, a_l;
+                split8(xc[2 * st], xc[2 * st + 1], a_h, a_m, a_l);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    mma6(acc[nb], a_h, a_m, a_l, bfrag(cur, 0, nb, st), bfrag(cur, 1, nb, st), bfrag(cur, 2, nb, st));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (GATED) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) xn[q] *= gb[q];
+            }
+            stage_write(cur ^ 1);
+            cur ^= 1;
+        };
+
+        for (int rd = 0; rd < nrounds; ++rd) {
+            const int tile_next = rd + 1 < nrounds ? tile + pblocks * 8 : tile;
+            const int e_n = edge_of(tile_next), s_n = src[e_n];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+            chunk(0, e_n, s_n, x0, x1);
+            chunk(1, e_n, s_n, x1, x0);
+            chunk(2, e_n, s_n, x0, x1);
+            chunk(3, e_n, s_n, x1, x0);
+            const int rows = min(32, te - tb - 32 * tile);       // may be <= 0 on the ragged last round
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = acc_row(i, lane);
+                const int e_row = __shfl(e_cur, row);
+                if (row < rows) {
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+                        __builtin_nontemporal_store(acc[nb][i], msg + (int64_t)e_row * F + 64 * slice + 32 * nb + r);
+                }
+                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            tile = tile_next;
+            e_cur = e_n;
+            s_cur = s_n;
+        }
+    }
+}
+
+int launch_message_stream256(const float* h, const float* A, const int32_t* src, const int32_t* order,
+                             const int32_t* type_ptr, const float* gate, float* msg, int64_t E, int K, hipStream_t s) {
+    const size_t lds = (size_t)2 * 3 * 64 * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)edge_message_stream256_kernel<false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)edge_message_stream256_kernel<true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const dim3 grid(256), block(512);                       // 64 row groups x 4 slices = one block per CU
+    if (gate)
+        hipLaunchKernelGGL((edge_message_stream256_kernel<true>), grid, block, lds, s, h, A, src, order, type_ptr, gate,
+                           msg, K);
+    else
+        hipLaunchKernelGGL((edge_message_stream256_kernel<false>), grid, block, lds, s, h, A, src, order, type_ptr, gate,
+                           msg, K);
+    return launch_status("mpnn_edge_message_f32(bf16x6 256, streamed)");
+}
+
+}  // namespace mpnn
