@@ -112,3 +112,30 @@ def test_attention_model_at_c3_shape(dev):
         assert _rel(p.grad.cpu(), g_ref) < 5e-4, (k, _rel(p.grad.cpu(), g_ref))
         checked += 1
     assert checked >= 20
+
+
+def test_hoisted_message_matches_per_step_message(dev):
+    """BasicModel.hoist_message computes message + aggregate once per pass (their input is the constant afm,
+    models/basic_model.py:57): the node states are bit-identical, the gradients equal up to summation order."""
+    from mpnn_amd import synth
+    from mpnn_amd.graph import MolGraph
+    from mpnn_amd.models.basic_model import BasicModel
+    H = 64
+    mb = synth.make_molecules(400, H, seed=5)
+    g = MolGraph.from_molbatch(mb, dev)
+    torch.manual_seed(1)
+    model = BasicModel(H, 4, H, 50, 8, message_opts={}, agg_opts={}, update_opts={}, readout_opts={}, message_steps=3).to(dev)
+    afm = torch.from_numpy(mb.atom_feat).to(dev)
+    mask = torch.ones(afm.shape[0], 1, device=dev)
+    res = []
+    for hoist in (False, True):
+        model.hoist_message = hoist
+        for p in model.parameters():
+            p.grad = None
+        state, _ = model.message_passing(afm, g, g, mask)
+        state.square().sum().backward()
+        res.append((state.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    assert torch.equal(res[0][0], res[1][0])
+    for k in res[0][1]:
+        scale = max(1.0, float(res[0][1][k].abs().max()))
+        assert max_err(res[0][1][k], res[1][1][k]) / scale < 1e-5, k
