@@ -362,25 +362,27 @@ __global__ void __launch_bounds__(512) gru_bwd_fused_split_kernel(
         }
         if (ablate == 1 || (ablate == 3 && !dw_role) || (ablate == 4 && dw_role)) {
         } else if (dw_role) {
+            // wave (mat, jg): BOTH 32-row blocks of X_mat against three of the six 32-column gate blocks, so a step
+            // splits 2 + 3 column fragments (it was 1 + 6 when a wave owned one row block and all six columns)
             const int noff = mat == 0 ? 2 * H : 3 * H;    // W_ih's n-gate column uses dan, W_hh's uses dnh
+            const int jg = iblk;
+            const int c0 = jg == 0 ? 0 : H + 32, c1 = jg == 0 ? 32 : noff, c2 = jg == 0 ? H : noff + 32;
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 const int row0 = 16 * st + 8 * hi;        // this lane half's 8 rows of the K=16 step
-                bf16x8 ah, am, al, bh, bm, bl;
-                column_frag(X + row0 * LDX + mat * H + 32 * iblk + i, LDX, ah, am, al);
+                bf16x8 a0h, a0m, a0l, a1h, a1m, a1l, bh, bm, bl;
+                column_frag(X + row0 * LDX + mat * H + i, LDX, a0h, a0m, a0l);
+                column_frag(X + row0 * LDX + mat * H + 32 + i, LDX, a1h, a1m, a1l);
                 const float* gcol = G + row0 * LDG + i;
-                column_frag(gcol, LDG, bh, bm, bl);
-                mma6(R[0], ah, am, al, bh, bm, bl);
-                column_frag(gcol + 32, LDG, bh, bm, bl);
-                mma6(R[1], ah, am, al, bh, bm, bl);
-                column_frag(gcol + H, LDG, bh, bm, bl);
-                mma6(R[2], ah, am, al, bh, bm, bl);
-                column_frag(gcol + H + 32, LDG, bh, bm, bl);
-                mma6(R[3], ah, am, al, bh, bm, bl);
-                column_frag(gcol + noff, LDG, bh, bm, bl);
-                mma6(R[4], ah, am, al, bh, bm, bl);
-                column_frag(gcol + noff + 32, LDG, bh, bm, bl);
-                mma6(R[5], ah, am, al, bh, bm, bl);
+                column_frag(gcol + c0, LDG, bh, bm, bl);
+                mma6(R[0], a0h, a0m, a0l, bh, bm, bl);
+                mma6(R[3], a1h, a1m, a1l, bh, bm, bl);
+                column_frag(gcol + c1, LDG, bh, bm, bl);
+                mma6(R[1], a0h, a0m, a0l, bh, bm, bl);
+                mma6(R[4], a1h, a1m, a1l, bh, bm, bl);
+                column_frag(gcol + c2, LDG, bh, bm, bl);
+                mma6(R[2], a0h, a0m, a0l, bh, bm, bl);
+                mma6(R[5], a1h, a1m, a1l, bh, bm, bl);
             }
         } else {
             f32x16 d;
@@ -427,10 +429,10 @@ __global__ void __launch_bounds__(512) gru_bwd_fused_split_kernel(
         float* dW = mat == 0 ? dW_ih : dW_hh;
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            const int col = 32 * j + i;
+            const int col = 32 * (3 * iblk + j % 3) + i;      // R[a*3 + b]: row block a, column block 3*jg + b
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const int row = 32 * iblk + acc_row(q, lane);
+                const int row = 32 * (j / 3) + acc_row(q, lane);
                 atomicAdd(dW + (int64_t)row * 3 * H + col, R[j][q]);
             }
         }
