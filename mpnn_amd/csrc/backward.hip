@@ -311,14 +311,15 @@ __global__ void __launch_bounds__(256) tn_accumulate_kernel(const float* __restr
 // and leave through one float-atomic flush per block.
 // With `dst` given the left operand is NOT a materialised dmsg: row e is  w[e] * dagg[dst[e]]  (the
 // aggregator's backward folded into this kernel, saving the E x F write + read).
-__global__ void __launch_bounds__(512) edge_dA_direct64_kernel(const float* __restrict__ dmsg,
-                                                               const float* __restrict__ h,
-                                                               const int32_t* __restrict__ src,
-                                                               const int32_t* __restrict__ order,
-                                                               const int32_t* __restrict__ type_ptr,
-                                                               const float* __restrict__ gate, float* dA, int K,
-                                                               const int32_t* __restrict__ dst,
-                                                               const float* __restrict__ w) {
+template <bool HAS_DST, bool HAS_W, bool GATED>
+__global__ void __launch_bounds__(512, 4) edge_dA_direct64_kernel(const float* __restrict__ dmsg,
+                                                                  const float* __restrict__ h,
+                                                                  const int32_t* __restrict__ src,
+                                                                  const int32_t* __restrict__ order,
+                                                                  const int32_t* __restrict__ type_ptr,
+                                                                  const float* __restrict__ gate, float* dA, int K,
+                                                                  const int32_t* __restrict__ dst,
+                                                                  const float* __restrict__ w) {
     constexpr int F = 64;
     __shared__ float red[F * F];                        // block-level partial of the current type
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -342,41 +343,53 @@ __global__ void __launch_bounds__(512) edge_dA_direct64_kernel(const float* __re
             any = true;
             const int pos = tb + 32 * t + i;            // both lane halves hold the tile's 32 edge ids
             const bool ok = pos < te;
-            const int e_l = ok ? order[pos] : order[tb + 32 * t];
+            const int e_l = order[ok ? pos : tb + 32 * t];
             const int s_l = src[e_l];
-            const int d_l = dst ? dst[e_l] : e_l;        // row of the left operand
-            const float w_l = (dst && w) ? w[e_l] : 1.0f;
+            const int d_l = HAS_DST ? dst[e_l] : e_l;   // row of the left operand
+            const float w_l = HAS_W ? w[e_l] : 1.0f;
             const int rows = min(32, te - tb - 32 * t);
+            // Two batches of 8 steps.  A batch issues ALL its loads before anything looks at a loaded value (the
+            // flags are template parameters and the ragged-tile mask is applied afterwards): with run-time branches
+            // around the gate / weight factors the compiler waited for memory once per step, 16 round trips a tile.
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                // this step multiplies rows s (lanes 0-31) and 16+s (lanes 32-63)
-                const int e_lo = __builtin_amdgcn_readlane(e_l, s), e_hi = __builtin_amdgcn_readlane(e_l, 16 + s);
-                const int s_lo = __builtin_amdgcn_readlane(s_l, s), s_hi = __builtin_amdgcn_readlane(s_l, 16 + s);
-                const int e_r = hi ? e_hi : e_lo;
-                const int s_r = hi ? s_hi : s_lo;
-                const int d_lo = __builtin_amdgcn_readlane(d_l, s), d_hi = __builtin_amdgcn_readlane(d_l, 16 + s);
-                const int d_r = hi ? d_hi : d_lo;
-                const bool live = (hi ? 16 + s : s) < rows;
-                const float* pa = dmsg + (int64_t)d_r * F + i;
-                const float* pb = h + (int64_t)s_r * F + i;
-                float a0 = pa[0], a1 = pa[32];
-                if (dst && w) {
-                    const float w_lo = readlane_f(w_l, s), w_hi = readlane_f(w_l, 16 + s);
-                    const float w_r = hi ? w_hi : w_lo;
-                    a0 *= w_r;
-                    a1 *= w_r;
+            for (int half = 0; half < 2; ++half) {
+                float a0[8], a1[8], b0[8], b1[8], g0[8], g1[8], wr[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int s = 8 * half + u;         // this step multiplies rows s (lanes 0-31) and 16+s (32-63)
+                    const int s_lo = __builtin_amdgcn_readlane(s_l, s), s_hi = __builtin_amdgcn_readlane(s_l, 16 + s);
+                    const int d_lo = __builtin_amdgcn_readlane(d_l, s), d_hi = __builtin_amdgcn_readlane(d_l, 16 + s);
+                    const float* pa = dmsg + (int64_t)(hi ? d_hi : d_lo) * F + i;
+                    const float* pb = h + (int64_t)(hi ? s_hi : s_lo) * F + i;
+                    a0[u] = pa[0];
+                    a1[u] = pa[32];
+                    b0[u] = pb[0];
+                    b1[u] = pb[32];
+                    if (GATED) {
+                        const int e_lo = __builtin_amdgcn_readlane(e_l, s), e_hi = __builtin_amdgcn_readlane(e_l, 16 + s);
+                        const float* pg = gate + (int64_t)(hi ? e_hi : e_lo) * F + i;
+                        g0[u] = pg[0];
+                        g1[u] = pg[32];
+                    }
+                    if (HAS_W) {
+                        const float w_lo = readlane_f(w_l, s), w_hi = readlane_f(w_l, 16 + s);
+                        wr[u] = hi ? w_hi : w_lo;
+                    }
                 }
-                float b0 = pb[0], b1 = pb[32];
-                if (gate) {
-                    const float* pg = gate + (int64_t)e_r * F + i;
-                    b0 *= pg[0];
-                    b1 *= pg[32];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int s = 8 * half + u;
+                    const bool live = (hi ? 16 + s : s) < rows;
+                    float x0 = a0[u], x1 = a1[u], y0 = b0[u], y1 = b1[u];
+                    if (HAS_W) { x0 *= wr[u]; x1 *= wr[u]; }
+                    if (GATED) { y0 *= g0[u]; y1 *= g1[u]; }
+                    if (!live) { x0 = 0.f; x1 = 0.f; }
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y0, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y1, acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y0, acc[2], 0, 0, 0);
+                    acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y1, acc[3], 0, 0, 0);
                 }
-                if (!live) { a0 = 0.f; a1 = 0.f; }
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[2], 0, 0, 0);
-                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[3], 0, 0, 0);
             }
         }
         if (any) {
@@ -613,8 +626,12 @@ extern "C" int mpnn_edge_message_bwd_f32(const float* h, const float* A, const i
         int64_t gx = 512;                               // 2 blocks of 8 waves per CU
         const int64_t need = ceil_div(ceil_div(E, 32) + K, 8);
         if (gx > need) gx = need;
-        hipLaunchKernelGGL(edge_dA_direct64_kernel, dim3((unsigned)gx), dim3(512), 0, s, dmsg, h, src, order, type_ptr,
-                           gate, dA, K, (const int32_t*)nullptr, (const float*)nullptr);
+        if (gate)
+            hipLaunchKernelGGL((edge_dA_direct64_kernel<false, false, true>), dim3((unsigned)gx), dim3(512), 0, s, dmsg, h,
+                               src, order, type_ptr, gate, dA, K, (const int32_t*)nullptr, (const float*)nullptr);
+        else
+            hipLaunchKernelGGL((edge_dA_direct64_kernel<false, false, false>), dim3((unsigned)gx), dim3(512), 0, s, dmsg,
+                               h, src, order, type_ptr, gate, dA, K, (const int32_t*)nullptr, (const float*)nullptr);
         rc = launch_status("mpnn_edge_message_bwd_f32(dA direct)");
     } else if (dA && mf == 128 && nf == 128 && K <= 64 && !math_fp32_only()) {
         rc = launch_edge_da_split128(dmsg, h, src, nullptr, nullptr, order, type_ptr, gate, dA, E, K, s);
@@ -743,7 +760,11 @@ extern "C" int mpnn_edge_message_agg_bwd_da_f32(const float* dagg, const float* 
     int64_t gx = 512;
     const int64_t need = ceil_div(ceil_div(E, 32) + K, 8);
     if (gx > need) gx = need;
-    hipLaunchKernelGGL(edge_dA_direct64_kernel, dim3((unsigned)gx), dim3(512), 0, (hipStream_t)stream, dagg, h, src,
-                       order, type_ptr, gate, dA, K, dst, w);
+#define MPNN_DA64(W, G)                                                                                              \
+    hipLaunchKernelGGL((edge_dA_direct64_kernel<true, W, G>), dim3((unsigned)gx), dim3(512), 0, (hipStream_t)stream, dagg, \
+                       h, src, order, type_ptr, gate, dA, K, dst, w)
+    if (w) { if (gate) MPNN_DA64(true, true); else MPNN_DA64(true, false); }
+    else { if (gate) MPNN_DA64(false, true); else MPNN_DA64(false, false); }
+#undef MPNN_DA64
     return launch_status("mpnn_edge_message_agg_bwd_da_f32");
 }
