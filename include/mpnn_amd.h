@@ -97,6 +97,20 @@ int mpnn_edge_message_agg_bwd_da_f32(const float* dagg, const float* h, const in
                                      const int32_t* order, const int32_t* type_ptr, const float* gate,
                                      float* dA, int64_t V, int64_t E, int K, int nf, int mf, void* stream);
 
+/*
+ * Feature gate of AttEdgeNetwork: gate[e, :] = softmax_f( z_atom[dst[e], :] + q[type[e], :] )
+ * replaces: mpnn_functions/message/att_edge_network.py:18-21 (cat[h_i, e_ij], Linear(nf+ef -> nf), Softmax(dim=-1))
+ * after the caller split the Linear into its atom part z_atom[i] = W_h h_i + b  [V,F] and its bond part
+ * q[k] = W_e e_k  [K,F] (one row per distinct bond-feature row).  dst[E] = destination atom of each edge.
+ * F a multiple of 4, <= 256.
+ * Backward, from d(gate): dz = gate * (dgate - <gate, dgate>);
+ *   dz_atom[i, :] = sum_{e in row i} dz[e, :]  (written),  dq[k, :] += sum_{e of type k} dz[e, :]  (caller zeroes dq).
+ */
+int mpnn_att_gate_f32(const float* z_atom, const float* q, const int32_t* dst, const int32_t* edge_type,
+                      float* gate, int64_t V, int64_t E, int K, int F, void* stream);
+int mpnn_att_gate_bwd_f32(const float* gate, const float* dgate, const int32_t* row_ptr, const int32_t* edge_type,
+                          float* dz_atom, float* dq, int64_t V, int64_t E, int K, int F, void* stream);
+
 /* ------------------------------------------------------------------ edge tower ----- */
 /*
  * The run of n_layers aliased Linear(L, L, bias=False) + ReLU blocks of the bond-feature tower

@@ -30,7 +30,13 @@ class AttEdgeNetwork(EdgeNetwork):
         h = g.node_view(afm)
         W_h, W_e = self.attn.weight[:, :self.nf], self.attn.weight[:, self.nf:]
         z_atom = h @ W_h.t() + self.attn.bias                 # (V, nf): destination-atom part
-        # per-edge logits: the atom part is broadcast along CSR rows (backward = the aggregator kernel),
-        # the bond part is a thin GEMM on the edge features (backward = a GEMM) -- no index_put backward
-        gate = self.attn_act(ops.expand_rows(z_atom, g) + g.edge_features @ W_e.t())
+        if isinstance(self.attn_act, nn.Softmax) and self.attn_act.dim in (-1, 1) and self.nf % 4 == 0 and self.nf <= 256:
+            # default activation: one streaming kernel gathers both parts of the logits and applies the softmax
+            # over the feature axis (mpnn_att_gate_f32); the bond part is a (K, nf) table, one row per distinct
+            # bond-feature row
+            gate = ops.att_gate(z_atom, g.type_feat @ W_e.t(), g)
+        else:
+            # any other activation: the atom part is broadcast along CSR rows (backward = the aggregator kernel),
+            # the bond part is a thin GEMM on the edge features (backward = a GEMM) -- no index_put backward
+            gate = self.attn_act(ops.expand_rows(z_atom, g) + g.edge_features @ W_e.t())
         return EdgeMessages(None, g, h, emb.A0, row_gate=self.attn_act(z_atom), recipe=(emb.A, gate))

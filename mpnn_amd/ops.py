@@ -423,6 +423,42 @@ def expand_rows(x, graph):
     return _ExpandRows.apply(x, graph)
 
 
+class AttGate(torch.autograd.Function):
+    """gate[e] = softmax_f(z_atom[dst(e)] + q[type(e)])  (E,F); see include/mpnn_amd.h."""
+
+    @staticmethod
+    def forward(ctx, z_atom, q, graph):
+        lib = _lib.load()
+        z_atom, q = z_atom.contiguous(), q.contiguous()
+        E, F = graph.num_edges, int(z_atom.shape[1])
+        gate = _empty((E, F), z_atom)
+        if E:
+            _lib.check(lib.mpnn_att_gate_f32(_lib.fptr(z_atom), _lib.fptr(q), _lib.iptr(graph.edge_dst),
+                                             _lib.iptr(graph.edge_type), _lib.fptr(gate), graph.num_nodes, E,
+                                             int(q.shape[0]), F, _lib.stream()), "mpnn_att_gate_f32")
+        ctx.save_for_backward(gate)
+        ctx.graph, ctx.K = graph, int(q.shape[0])
+        return gate
+
+    @staticmethod
+    def backward(ctx, dgate):
+        lib = _lib.load()
+        gate, = ctx.saved_tensors
+        g = ctx.graph
+        V, E, F = g.num_nodes, g.num_edges, int(gate.shape[1])
+        dz_atom = torch.zeros((V, F), dtype=torch.float32, device=gate.device) if E == 0 else _empty((V, F), gate)
+        dq = torch.zeros((ctx.K, F), dtype=torch.float32, device=gate.device)
+        if V and E:
+            _lib.check(lib.mpnn_att_gate_bwd_f32(_lib.fptr(gate), _lib.fptr(dgate.contiguous()), _lib.iptr(g.row_ptr),
+                                                 _lib.iptr(g.edge_type), _lib.fptr(dz_atom), _lib.fptr(dq), V, E, ctx.K,
+                                                 F, _lib.stream()), "mpnn_att_gate_bwd_f32")
+        return dz_atom, dq, None
+
+
+def att_gate(z_atom, q, graph):
+    return AttGate.apply(z_atom, q, graph)
+
+
 class TowerChain(torch.autograd.Function):
     """n applications of relu(x W^T) with ONE shared W (the tower's 50 aliased layers) in one kernel."""
 

@@ -296,3 +296,30 @@ def test_masked_bn_forward_backward(dev, V, F, variant):
     assert max_err(out.cpu(), ref) < 2e-5
     for a, bb in zip(ggpu, gref):
         assert max_err(a.cpu(), bb) < 2e-5 * max(1.0, float(bb.abs().max()))
+
+
+# ----------------------------------------------------------------------------- attention gate
+@pytest.mark.parametrize("V,F,K", [(300, 128, 4), (1000, 64, 5), (77, 8, 3), (500, 24, 40), (400, 256, 2), (900, 100, 700)])
+def test_att_gate_forward_backward(dev, V, F, K):
+    """gate[e] = softmax_f(z_atom[dst e] + q[type e]) and its backward (dz_atom by destination row, dq by type)
+    against float64 autograd of the same expression."""
+    from mpnn_amd import ops
+    from mpnn_amd.graph import MolGraph
+    rng = np.random.default_rng(V + F + K)
+    row_ptr, col = _rand_graph(rng, V, 6)
+    E = int(row_ptr[-1])
+    et = rng.integers(0, K, E).astype(np.int32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    g = MolGraph(t(row_ptr), t(col), None, t(et), torch.zeros(K, 1, device=dev),
+                 torch.tensor([0, V], dtype=torch.int32, device=dev))
+    z = torch.from_numpy(rng.standard_normal((V, F)).astype(np.float32) * 2).to(dev).requires_grad_(True)
+    q = torch.from_numpy(rng.standard_normal((K, F)).astype(np.float32)).to(dev).requires_grad_(True)
+    cot = torch.from_numpy(rng.standard_normal((E, F)).astype(np.float32)).to(dev)
+    gate = ops.att_gate(z, q, g)
+    gate.backward(cot)
+    z64, q64 = z.detach().double().requires_grad_(True), q.detach().double().requires_grad_(True)
+    ref = torch.softmax(z64[g.edge_dst.long()] + q64[g.edge_type.long()], dim=-1)
+    ref.backward(cot.double())
+    assert max_err(gate.detach(), ref.detach()) < 2e-6
+    assert max_err(z.grad, z64.grad) < 1e-5
+    assert max_err(q.grad, q64.grad) / max(1.0, float(q64.grad.abs().max())) < 1e-5
