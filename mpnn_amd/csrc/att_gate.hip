@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256) att_gate_fwd_kernel(const float* __restri
 }
 
 // dz = gate * (dgate - <gate, dgate>);  dz_atom[i] = sum over row i;  dq[type] += dz (LDS partials when K is small)
-template <int LPR>
+template <int LPR, int KREG>
 __global__ void __launch_bounds__(256) att_gate_bwd_kernel(const float* __restrict__ gate, const float* __restrict__ dgate,
                                                            const int32_t* __restrict__ row_ptr,
                                                            const int32_t* __restrict__ edge_type,
@@ -63,6 +63,11 @@ __global__ void __launch_bounds__(256) att_gate_bwd_kernel(const float* __restri
     const bool live = c < F;
     for (int idx = threadIdx.x; idx < k_lds * F; idx += 256) part[idx] = 0.f;
     __syncthreads();
+    // KREG > 0 (K <= KREG): a lane keeps its own partial of every type's dq columns in registers (predicated adds,
+    // no atomics in the loop) and adds them to the LDS partial once at the end
+    f32x4 qacc[KREG > 0 ? KREG : 1];
+#pragma unroll
+    for (int k = 0; k < (KREG > 0 ? KREG : 1); ++k) qacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
     for (int64_t v0 = wave * RPW; v0 < V; v0 += nwaves * RPW) {
         const int64_t v = v0 + sub;
@@ -85,7 +90,12 @@ __global__ void __launch_bounds__(256) att_gate_bwd_kernel(const float* __restri
             for (int o = 1; o < LPR; o <<= 1) dot += __shfl_xor(dot, o);
             const f32x4 dz = g * (dg - dot);
             acc += dz;
-            if (live && has) {
+            if (KREG > 0) {
+                const int t = (live && has) ? edge_type[e] : -1;
+#pragma unroll
+                for (int k = 0; k < KREG; ++k)
+                    if (t == k) qacc[k] += dz;
+            } else if (live && has) {
                 const int t = edge_type[e];
                 if (t < k_lds) {                           // LDS float adds (ds_add_f32), flushed once per block
                     float* p = part + t * F + c;
@@ -97,6 +107,14 @@ __global__ void __launch_bounds__(256) att_gate_bwd_kernel(const float* __restri
             }
         }
         if (ok && live) *reinterpret_cast<f32x4*>(dz_atom + v * F + c) = acc;
+    }
+    if (KREG > 0 && live) {
+#pragma unroll
+        for (int k = 0; k < KREG; ++k)
+            if (k < K) {
+                float* p = part + k * F + c;
+                atomicAdd(p, qacc[k].x); atomicAdd(p + 1, qacc[k].y); atomicAdd(p + 2, qacc[k].z); atomicAdd(p + 3, qacc[k].w);
+            }
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < k_lds * F; idx += 256) {
@@ -154,8 +172,12 @@ extern "C" int mpnn_att_gate_bwd_f32(const float* gate, const float* dgate, cons
     hipStream_t s = (hipStream_t)stream;
 #define MPNN_GATE_CASE(L)                                                                                          \
     case L:                                                                                                        \
-        hipLaunchKernelGGL((att_gate_bwd_kernel<L>), grid, block, lds, s, gate, dgate, row_ptr, edge_type, dz_atom, dq, \
-                           V, K, F, k_lds);                                                                        \
+        if (K <= 8)                                                                                                \
+            hipLaunchKernelGGL((att_gate_bwd_kernel<L, 8>), grid, block, lds, s, gate, dgate, row_ptr, edge_type, dz_atom, \
+                               dq, V, K, F, k_lds);                                                                \
+        else                                                                                                       \
+            hipLaunchKernelGGL((att_gate_bwd_kernel<L, 0>), grid, block, lds, s, gate, dgate, row_ptr, edge_type, dz_atom, \
+                               dq, V, K, F, k_lds);                                                                \
         break;
     switch (lpr) {
         MPNN_GATE_CASE(1) MPNN_GATE_CASE(2) MPNN_GATE_CASE(4) MPNN_GATE_CASE(8) MPNN_GATE_CASE(16) MPNN_GATE_CASE(32)

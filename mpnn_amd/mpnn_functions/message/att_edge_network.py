@@ -29,7 +29,7 @@ class AttEdgeNetwork(EdgeNetwork):
         g = emb.graph
         h = g.node_view(afm)
         W_h, W_e = self.attn.weight[:, :self.nf], self.attn.weight[:, self.nf:]
-        z_atom = h @ W_h.t() + self.attn.bias                 # (V, nf): destination-atom part
+        z_atom = ops.tall_linear(h, W_h, self.attn.bias)      # (V, nf): destination-atom part
         if isinstance(self.attn_act, nn.Softmax) and self.attn_act.dim in (-1, 1) and self.nf % 4 == 0 and self.nf <= 256:
             # default activation: one streaming kernel gathers both parts of the logits and applies the softmax
             # over the feature axis (mpnn_att_gate_f32); the bond part is a (K, nf) table, one row per distinct
