@@ -179,6 +179,90 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
         }
 }
 
+
+// ---- vectorised twins of the two apply kernels for F = 4 * 2^k (<= 1024): a thread keeps ONE group of four
+// columns for the whole kernel, so the per-column constants (1/scale, shift; the five backward coefficients) are
+// computed once instead of per element (the scalar kernels spend their time on a 64-bit divide, a square root and a
+// divide per element: 1.6 ms for 3 GB of traffic), and rows move as nontemporal float4.
+__global__ void __launch_bounds__(256) bn_apply_vec_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                                           const float* __restrict__ weight, const float* __restrict__ bias,
+                                                           const float* __restrict__ ws, float* __restrict__ y,
+                                                           float* __restrict__ mean_io, float* __restrict__ var_io,
+                                                           float* __restrict__ count_out, int64_t V, int F, float eps,
+                                                           int flags) {
+    const int tpr = F / 4, rpb = 256 / tpr;                // threads per row, rows per block pass
+    const int c = 4 * (threadIdx.x % tpr), rsub = threadIdx.x / tpr;
+    const bool given = flags & kBnUseStats;
+    const float cnt = given ? 1.f : ws[3 * F];
+    f32x4 sc, sh;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const float mean = given ? mean_io[c + u] : ws[c + u] / cnt;
+        const float var = given ? var_io[c + u] : ws[F + c + u] / cnt;
+        const float inv = 1.0f / bn_scale(var, eps, flags);
+        const float g = weight ? weight[c + u] : 1.0f, b = weight ? bias[c + u] : 0.0f;
+        sc[u] = g * inv;                                   // y = (x - mean) * g / s + b
+        sh[u] = b - mean * g * inv;
+    }
+    for (int64_t row = (int64_t)blockIdx.x * rpb + rsub; row < V; row += (int64_t)gridDim.x * rpb) {
+        const float mk = mask ? mask[row] : 1.0f;
+        const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + row * F + c));
+        __builtin_nontemporal_store((v * sc + sh) * mk, reinterpret_cast<f32x4*>(y + row * F + c));
+    }
+    if (!given && blockIdx.x == 0) {
+        for (int cc = threadIdx.x; cc < F; cc += 256) {
+            mean_io[cc] = ws[cc] / cnt;
+            var_io[cc] = ws[F + cc] / cnt;
+        }
+        if (threadIdx.x == 0 && count_out) *count_out = cnt;
+    }
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_apply_vec_kernel(const float* __restrict__ dout, const float* __restrict__ x,
+                                                               const float* __restrict__ mask,
+                                                               const float* __restrict__ weight,
+                                                               const float* __restrict__ mean, const float* __restrict__ var,
+                                                               const float* __restrict__ ws, float* __restrict__ dx,
+                                                               float* __restrict__ dweight, float* __restrict__ dbias,
+                                                               int64_t V, int F, float eps, int flags,
+                                                               const float* __restrict__ count_dev) {
+    const int tpr = F / 4, rpb = 256 / tpr;
+    const int c = 4 * (threadIdx.x % tpr), rsub = threadIdx.x / tpr;
+    const float count = *count_dev;
+    // dx = dout*mk*k1 + (x - mean)*mk*mk*k2 + k3*(masked mean ? mk : 1)
+    f32x4 k1, k2, k3, mu;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const float gamma = weight ? weight[c + u] : 1.0f;
+        const float s = bn_scale(var[c + u], eps, flags), rs = 1.0f / s;
+        const float Sb = ws[c + u], Sg = ws[F + c + u], Sc = ws[2 * F + c + u];
+        const float root = (flags & kBnEpsInside) ? s : sqrtf(var[c + u]);
+        const float dvar = (root > 0.f) ? (-gamma * Sg * rs * rs) / (2.0f * root) : 0.f;
+        k1[u] = gamma * rs;
+        k2[u] = dvar * 2.0f / count;
+        k3[u] = -(gamma * Sb * rs + dvar * 2.0f * Sc / count) / count;
+        mu[u] = mean[c + u];
+    }
+    const bool masked_mean = flags & kBnMaskedMean;
+    for (int64_t row = (int64_t)blockIdx.x * rpb + rsub; row < V; row += (int64_t)gridDim.x * rpb) {
+        const float mk = mask ? mask[row] : 1.0f;
+        const f32x4 xv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + row * F + c));
+        const f32x4 dv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dout + row * F + c));
+        const f32x4 r = dv * mk * k1 + (xv - mu) * (mk * mk) * k2 + k3 * (masked_mean ? mk : 1.0f);
+        __builtin_nontemporal_store(r, reinterpret_cast<f32x4*>(dx + row * F + c));
+    }
+    if (blockIdx.x == 0 && dweight)
+        for (int cc = threadIdx.x; cc < F; cc += 256) {
+            dweight[cc] = ws[F + cc] / bn_scale(var[cc], eps, flags);
+            dbias[cc] = ws[cc];
+        }
+}
+
+static bool bn_vectorisable(int F) {
+    const int g = F / 4;
+    return (F & 3) == 0 && g >= 1 && g <= 256 && (g & (g - 1)) == 0;
+}
+
 static int bn_grid(int64_t V, int F) {
     const int cg = (F + 3) / 4, tpr = cg < 256 ? cg : 256, rl = 256 / tpr;
     int64_t g = ceil_div(V, (int64_t)rl * 8);
@@ -216,8 +300,16 @@ extern "C" int mpnn_masked_bn_fwd_f32(const float* x, const float* mask, const f
         hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(g), dim3(256), 0, s, x, mask, (const float*)nullptr,
                            (const float*)nullptr, ws, V, F, flags);
     }
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)ag), dim3(256), 0, s, x, mask, weight, bias, ws, y, mean, var,
-                       count_out, V, F, eps, flags);
+    const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y);
+    if (bn_vectorisable(F) && al % 16 == 0) {
+        int64_t vg = ceil_div(V, (int64_t)(256 / (F / 4)));
+        if (vg > 256 * 16) vg = 256 * 16;
+        hipLaunchKernelGGL(bn_apply_vec_kernel, dim3((unsigned)vg), dim3(256), 0, s, x, mask, weight, bias, ws, y, mean, var,
+                           count_out, V, F, eps, flags);
+    } else {
+        hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)ag), dim3(256), 0, s, x, mask, weight, bias, ws, y, mean, var,
+                           count_out, V, F, eps, flags);
+    }
     return launch_status("mpnn_masked_bn_fwd_f32");
 }
 
@@ -240,7 +332,15 @@ extern "C" int mpnn_masked_bn_bwd_f32(const float* dout, const float* x, const f
     hipLaunchKernelGGL((bn_reduce_kernel<2>), dim3(bn_grid(V, F)), dim3(256), 0, s, x, mask, dout, mean, ws, V, F, flags);
     int64_t ag = ceil_div(V * F, 256);
     if (ag > 256 * 32) ag = 256 * 32;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)ag), dim3(256), 0, s, dout, x, mask, weight, mean, var, ws, dx,
-                       dweight, dbias, V, F, eps, flags, count);
+    const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(dx);
+    if (bn_vectorisable(F) && al % 16 == 0) {
+        int64_t vg = ceil_div(V, (int64_t)(256 / (F / 4)));
+        if (vg > 256 * 16) vg = 256 * 16;
+        hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3((unsigned)vg), dim3(256), 0, s, dout, x, mask, weight, mean, var, ws,
+                           dx, dweight, dbias, V, F, eps, flags, count);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)ag), dim3(256), 0, s, dout, x, mask, weight, mean, var, ws, dx,
+                           dweight, dbias, V, F, eps, flags, count);
+    }
     return launch_status("mpnn_masked_bn_bwd_f32");
 }
