@@ -17,9 +17,16 @@ class EdgeMessages:
         self.graph = graph
         self.h = h                # (V, nf) node features the messages were computed from
         self.A0 = A0              # (mf, nf) matrix of a zero bond-feature row, or None (== 0)
-        self.row_gate = row_gate  # (V, nf) AttEdgeNetwork gate of atom i towards a zero-feature pair
+        self._row_gate = row_gate  # (V, nf) AttEdgeNetwork gate of atom i towards a zero-feature pair, or a thunk
         self.recipe = recipe      # (A, gate): how to compute `values`; lets AdjMsgAgg run message+sum as one
                                   # autograd node (ops.message_aggregate) whose backward skips the (E, mf) gradient
+
+    @property
+    def row_gate(self):
+        """Evaluated on first use: only the non-member corrections and to_dense() need it."""
+        if callable(self._row_gate):
+            self._row_gate = self._row_gate()
+        return self._row_gate
 
     @property
     def values(self):

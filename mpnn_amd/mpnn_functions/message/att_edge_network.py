@@ -39,4 +39,4 @@ class AttEdgeNetwork(EdgeNetwork):
             # any other activation: the atom part is broadcast along CSR rows (backward = the aggregator kernel),
             # the bond part is a thin GEMM on the edge features (backward = a GEMM) -- no index_put backward
             gate = self.attn_act(ops.expand_rows(z_atom, g) + g.edge_features @ W_e.t())
-        return EdgeMessages(None, g, h, emb.A0, row_gate=self.attn_act(z_atom), recipe=(emb.A, gate))
+        return EdgeMessages(None, g, h, emb.A0, row_gate=lambda: self.attn_act(z_atom), recipe=(emb.A, gate))

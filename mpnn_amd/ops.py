@@ -262,7 +262,8 @@ class MessageAggregate(torch.autograd.Function):
         if gate is not None:
             if ctx.needs_input_grad[2]:
                 dgate = dx * h[g.col_idx.to(torch.int64)]
-            dx = dx * gate
+            if ctx.needs_input_grad[0]:
+                dx = dx * gate
         dh = segsum_gather_raw(dx, t_row_ptr, t_eid, None, g.num_nodes) if ctx.needs_input_grad[0] else None
         return dh, dA, dgate, None, None
 
