@@ -55,8 +55,8 @@ with open(ROOT + "/profiles/r01_c2_train_kernel_stats.md", "w") as f:
                                                              "%.2f" % v["mfma_busy_frac"] if v["mfma_busy_frac"] is not None else "n/a"))
     except FileNotFoundError:
         pass
-    f.write("\nOther workloads (`profiles/r01_bench_c{3,4,5}.json`, same commit; hidden 128 runs on the bf16x6 kernels, hidden 256 "
-            "partly on the generic fp32 kernels):\n\n| workload | training step ms | forward pass ms | aggregator frac of 8 TB/s |\n|---|---|---|---|\n")
+    f.write("\nOther workloads (`profiles/r01_bench_c{3,4,5}.json`, same commit; all widths on the bf16x6 kernels: resident slices at 128, "
+            "streamed weights at 256):\n\n| workload | training step ms | forward pass ms | aggregator frac of 8 TB/s |\n|---|---|---|---|\n")
     for w in ("c3", "c4", "c5"):
         d = json.load(open(ROOT + "/profiles/r01_bench_%s.json" % w))
         f.write("| %s | %.1f | %.1f | %.3f |\n" % (d["config"]["workload"][:70], d["ms_per_step"], d["forward"]["ms_per_step"], d["roofline"]["frac"]))
