@@ -571,8 +571,8 @@ int launch_edge_da_split256(const float* Y, const float* h, const int32_t* src, 
 int launch_edge_da_split64(const float* Y, const float* h, const int32_t* src, const int32_t* dst, const float* w,
                            const int32_t* order, const int32_t* type_ptr, const float* gate, float* dA, int64_t E,
                            int K, hipStream_t s);
-static bool da64_split() {
-    static const bool v = getenv("MPNN_DA64_SPLIT") != nullptr;
+static bool da64_split() {     // default since the index pipeline; MPNN_DA64_DIRECT=1 selects the fp32 register-direct kernel
+    static const bool v = getenv("MPNN_DA64_DIRECT") == nullptr;
     return v;
 }
 static bool math_fp32_only() {

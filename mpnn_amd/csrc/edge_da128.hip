@@ -46,28 +46,33 @@ __global__ void __launch_bounds__(F >= 128 ? 512 : 256) edge_da_split_kernel(
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[b][q] = 0.f;
 
-        // The step's edge ids are wave-uniform, so order / dst / src / w come through the scalar cache.  Everything
-        // in the fetch is branch-free (flags are template parameters, the y / x role is one wave-uniform branch
-        // around the whole body): a per-element branch makes the compiler wait for each load before the next one.
-        // Masking and the w / gate factors are applied when the step is parked, so nothing waits at issue time.
-        // Data is fetched TWO steps ahead (raw0 / raw1 alternate).
-        auto load_raw = [&](int st, float (&raw)[16], float (&aux)[16]) {
-            const int p0 = tb + EPS * st + 16 * og;
-            int e[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) e[u] = order[p0 + u < te ? p0 + u : tb];
-            if (is_y) {
+        // Index pipeline.  Lane (l & 15) of a wave carries edge slot 16*og + (l & 15) of a step: `order` is read four
+        // steps ahead, dst / src / w three steps ahead and the data rows two steps ahead, so an iteration never waits
+        // for the dependent chain order -> row -> data (it used to: two scalar round trips before the data loads of
+        // every step could even be issued).  Everything in the fetch is branch-free: flags are template parameters
+        // and the y / x role only selects pointers.  Masking and the w / gate factors are applied when the step is
+        // parked, so nothing waits at issue time.
+        const int slot = 16 * og + (lane & 15);
+        auto fetch_e = [&](int st) {                       // st may run past the type: clamped, masked at park()
+            const int pos = tb + EPS * st + slot;
+            return order[pos < te ? pos : tb];
+        };
+        auto fetch_r = [&](int e_l, int& r_l, float& w_l) {
+            r_l = is_y ? (HAS_DST ? dst[e_l] : e_l) : src[e_l];
+            w_l = (HAS_W && is_y) ? w[e_l] : 1.0f;
+        };
+        auto load_raw = [&](float (&raw)[16], float (&aux)[16], int e_l, int r_l, float w_l) {
+            if (is_y) {                                    // one wave-uniform branch around the whole batch
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
-                    const int row = HAS_DST ? dst[e[u]] : e[u];
-                    raw[u] = Y[(int64_t)row * F + fcol];
-                    aux[u] = HAS_W ? w[e[u]] : 1.0f;
+                    raw[u] = Y[(int64_t)__builtin_amdgcn_readlane(r_l, u) * F + fcol];
+                    aux[u] = HAS_W ? readlane_f(w_l, u) : 1.0f;
                 }
             } else {
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
-                    raw[u] = h[(int64_t)src[e[u]] * F + fcol];
-                    aux[u] = GATED ? gate[(int64_t)e[u] * F + fcol] : 1.0f;
+                    raw[u] = h[(int64_t)__builtin_amdgcn_readlane(r_l, u) * F + fcol];
+                    aux[u] = GATED ? gate[(int64_t)__builtin_amdgcn_readlane(e_l, u) * F + fcol] : 1.0f;
                 }
             }
         };
@@ -100,15 +105,30 @@ __global__ void __launch_bounds__(F >= 128 ? 512 : 256) edge_da_split_kernel(
         const int g = gridDim.x;
         int cur = 0;
         __syncthreads();                                    // the previous type's last buffer is no longer read
+        int e2 = 0, e3 = 0, r2 = 0;
+        float w2 = 1.0f;
         if (st < steps) {
-            load_raw(st, raw0, aux0);
+            int e0 = fetch_e(st), r0;
+            float w0;
+            fetch_r(e0, r0, w0);
+            load_raw(raw0, aux0, e0, r0, w0);
             park(0, st, raw0, aux0);
-            if (st + g < steps) load_raw(st + g, raw0, aux0);
+            int e1 = fetch_e(st + g), r1;
+            float w1;
+            fetch_r(e1, r1, w1);
+            load_raw(raw0, aux0, e1, r1, w1);               // step st+g, parked by the first iteration
+            e2 = fetch_e(st + 2 * g);
+            fetch_r(e2, r2, w2);
+            e3 = fetch_e(st + 3 * g);
         }
         // one step: fetch step st+2g into `rin`, multiply step st out of LDS, park step st+g (already in `rout`)
         auto step = [&](int st_now, float (&rout)[16], float (&aout)[16], float (&rin)[16], float (&ain)[16]) {
             __syncthreads();
-            if (st_now + 2 * g < steps) load_raw(st_now + 2 * g, rin, ain);
+            const int e4 = fetch_e(st_now + 4 * g);         // consumed two iterations from now
+            int r3;
+            float w3;
+            fetch_r(e3, r3, w3);                            // consumed next iteration
+            load_raw(rin, ain, e2, r2, w2);                 // harmless clamped re-read past the last step
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < EPS / 16; ++ks) {
@@ -124,6 +144,10 @@ __global__ void __launch_bounds__(F >= 128 ? 512 : 256) edge_da_split_kernel(
             __builtin_amdgcn_sched_barrier(0);
             if (st_now + g < steps) park(cur ^ 1, st_now + g, rout, aout);
             cur ^= 1;
+            e2 = e3;
+            r2 = r3;
+            w2 = w3;
+            e3 = e4;
         };
         for (; st < steps; st += 2 * g) {
             step(st, raw0, aux0, raw1, aux1);
