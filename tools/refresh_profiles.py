@@ -25,8 +25,9 @@ pm = json.load(open(ROOT + "/profiles/r01_pmc_c2.json"))
 agg = [v for k, v in pm["kernels"].items() if "segsum" in k and "bwd" not in k][0]
 with open(ROOT + "/profiles/r01_c2_train_kernel_stats.md", "w") as f:
     f.write("# Round 1, final state: `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu` (c2; default mode = "
-            "training step, the run also times the forward-only pass)\n\n13 forward-only passes + 13 training passes "
-            "(3 warm-up + 10 timed each), 3 message-passing steps per pass.\n\n| kernel | calls | avg ms | % of GPU time |\n|---|---|---|---|\n")
+            "training step, the run also times the forward-only pass and, as a side field, both with hoist_message)\n\n26 forward-only passes + "
+            "26 training passes (3 warm-up + 10 timed each; half of them with BasicModel.hoist_message, i.e. message + aggregate once "
+            "per pass instead of per step), 3 message-passing steps per pass, plus 13 launches of the stream calibration.\n\n| kernel | calls | avg ms | % of GPU time |\n|---|---|---|---|\n")
     for r in rows[:12]:
         f.write("| `%s` | %s | %.3f | %.1f |\n" % (r["Name"].split("(")[0][:80], r["Calls"], float(r["AverageNs"]) / 1e6,
                                                   100 * float(r["TotalDurationNs"]) / tot))
