@@ -3,6 +3,8 @@
 Each Function enqueues its kernel on torch's current stream and owns nothing: torch tensors
 are the buffers.  Backward passes call the matching *_bwd kernels.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -242,7 +244,8 @@ class MessageAggregate(torch.autograd.Function):
         dout = dout.contiguous()
         need_dx = ctx.needs_input_grad[0] or (gate is not None and ctx.needs_input_grad[2])
         K, mf, nf = (int(s) for s in A.shape)
-        if not need_dx and mf == nf and mf in (64, 128, 256) and K <= 64:
+        fused_widths = (64, 128) if os.environ.get("MPNN_GRU_MATH") == "fp32" else (64, 128, 256)   # no fp32 twin at 256
+        if not need_dx and mf == nf and mf in fused_widths and K <= 64:
             if not ctx.needs_input_grad[1]:
                 return None, None, None, None, None
             lib = _lib.load()
