@@ -50,6 +50,14 @@ class MolGraph:
         self._unit_weights = None
         self._adj_ptr = None
 
+    def with_type_feat(self, type_feat):
+        """The same graph with another (K, ef) table of bond-feature rows (index arrays and their caches shared)."""
+        import copy
+        g = copy.copy(self)
+        g.type_feat = type_feat
+        g.edge_feat = None
+        return g
+
     # ------------------------------------------------------------------ derived index arrays
     @property
     def order(self):

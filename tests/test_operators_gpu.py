@@ -279,3 +279,34 @@ def test_edge_network_continuous_features_many_types(dev):
             continue
         scale = max(1.0, float(params[k].grad.abs().max()))
         assert max_err(p.grad.cpu(), params[k].grad) / scale < 2e-4, k
+
+
+def test_batch_norm_graph_wrapper(dev):
+    """models/batch_norm_graph_wrapper.py:5-17: masked norm of afm and of bfm*adj, then BasicModel -- dense batch and
+    compact batch against the oracle (mask_bn + basic_model_forward)."""
+    from mpnn_amd import synth
+    from mpnn_amd.graph import MolGraph
+    from mpnn_amd.models.basic_model import BasicModel
+    from mpnn_amd.models.batch_norm_graph_wrapper import GraphWrapper
+    H, T = 16, 2
+    mb = synth.make_molecules(40, H, seed=8)
+    dense = {k: torch.from_numpy(v) for k, v in synth.to_dense(mb).items()}
+    torch.manual_seed(2)
+    model = GraphWrapper(BasicModel(H, 4, H, 50, 5, message_opts={}, agg_opts={}, update_opts={}, readout_opts={},
+                                    message_steps=T))
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if "bias" in k:
+                p.uniform_(-0.1, 0.1)
+    params = {k[len("graph_model."):]: v.detach().clone() for k, v in model.state_dict().items()}
+    afm_n = O.mask_bn(dense["afm"], dense["mask"])
+    bfm_n = O.mask_bn(dense["bfm"] * dense["adj"].unsqueeze(-1), dense["adj"])
+    ref = O.basic_model_forward(params, afm_n, bfm_n, dense["adj"], dense["mask"], T)
+    model = model.to(dev)
+    with torch.no_grad():
+        out_dense = model({k: v.to(dev) for k, v in dense.items()})
+        g = MolGraph.from_molbatch(mb, dev)
+        afm = torch.from_numpy(mb.atom_feat).to(dev)
+        out_compact = model({"afm": afm, "graph": g, "mask": torch.ones(afm.shape[0], 1, device=dev)})
+    assert max_err(out_dense.cpu(), ref) < 5e-5
+    assert max_err(out_compact.cpu(), ref) < 5e-5
