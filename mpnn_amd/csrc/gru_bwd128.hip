@@ -386,7 +386,7 @@ int launch_gru_bwd_dw256(const float* m, const float* h, const float* ws, float*
         attr_done = true;
     }
     const int64_t steps = (V + 15) / 16;
-    int64_t gx = 43;                                        // x 6 (matrix, gate) jobs ~ one block per CU
+    int64_t gx = 42;                                        // x 6 (matrix, gate) jobs = 252 blocks: one per CU, ONE wave of blocks (43 x 6 = 258 left two blocks for a second pass and doubled the kernel time)
     if (gx > steps) gx = steps;
     hipLaunchKernelGGL(gru_bwd_dw256_kernel, dim3((unsigned)gx, 6), dim3(512), lds, s, m, h, ws, dW_ih, dW_hh, db_ih,
                        db_hh, V);
