@@ -415,12 +415,10 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_stream_kernel(const float* __r
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hi = lane >> 5;
-    const int tr = wv >> 1, half = wv & 1;
 
-    const int64_t rounds_total = (V + 127) / 128;
+    const int64_t rounds_total = (V + 255) / 256;              // a round = 256 rows: every wave its own 32-row tile
     if (pblock >= rounds_total) return;
     const int64_t nrounds = (rounds_total - pblock + pblocks - 1) / pblocks;
-    const int fcol = 64 * slice + 32 * half + r;
 
     // staging unit = (matrix, output row n, k-octet): 1024 units, two per thread, 32 contiguous bytes each
     const float* wsrc[2];
@@ -453,8 +451,8 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_stream_kernel(const float* __r
             *reinterpret_cast<bf16x8*>(base + 2 * IMGC) = pl;
         }
     };
-    auto bfrag = [&](int buf, int mat, int piece, int st) {
-        const int n = 32 * half + r;
+    auto bfrag = [&](int buf, int mat, int piece, int nb, int st) {
+        const int n = 32 * nb + r;
         const int o = 4 * hi + st;
         return *reinterpret_cast<const bf16x8*>(smem + buf * BUF + (mat * 3 + piece) * IMGC + n * 128 +
                                                 ((o ^ ((n >> 1) & 7)) << 4));
@@ -468,10 +466,10 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_stream_kernel(const float* __r
         for (int q = 0; q < 8; ++q) f[q] = *reinterpret_cast<const f32x4*>(p + 4 * q);
     };
 
-    f32x16 d_m, d_h;
+    f32x16 d_m[2], d_h[2];                                 // 32 rows x 64 features of dm and of dh per wave
     f32x4 a0[8], a1[8], b0[8], b1[8];                      // operand of dm (a*) and of dh (b*, only in the n block)
     int cur = 0;
-    int64_t tile = (int64_t)pblock * 4 + tr;
+    int64_t tile = (int64_t)pblock * 8 + wv;
 
     auto chunk = [&](int ct, int64_t tile_next, f32x4 (&xa)[8], f32x4 (&xb)[8], f32x4 (&na)[8], f32x4 (&nb)[8]) {
         __syncthreads();
@@ -486,11 +484,17 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_stream_kernel(const float* __r
         for (int st = 0; st < 4; ++st) {
             bf16x8 a_h, a_m, a_l;
             split8(xa[2 * st], xa[2 * st + 1], a_h, a_m, a_l);
-            mma6(d_m, a_h, a_m, a_l, bfrag(cur, 0, 0, st), bfrag(cur, 0, 1, st), bfrag(cur, 0, 2, st));
-            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                mma6(d_m[nb], a_h, a_m, a_l, bfrag(cur, 0, 0, nb, st), bfrag(cur, 0, 1, nb, st), bfrag(cur, 0, 2, nb, st));
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (!shared) split8(xb[2 * st], xb[2 * st + 1], a_h, a_m, a_l);
-            mma6(d_h, a_h, a_m, a_l, bfrag(cur, 1, 0, st), bfrag(cur, 1, 1, st), bfrag(cur, 1, 2, st));
-            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                mma6(d_h[nb], a_h, a_m, a_l, bfrag(cur, 1, 0, nb, st), bfrag(cur, 1, 1, nb, st), bfrag(cur, 1, 2, nb, st));
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         stage_write(cur ^ 1);
         cur ^= 1;
@@ -500,33 +504,37 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_stream_kernel(const float* __r
     stage_write(0);
     load_rows(tile, 0, 0, a0);
     for (int64_t rd = 0; rd < nrounds; ++rd) {
-        const int64_t tile_next = rd + 1 < nrounds ? tile + (int64_t)pblocks * 4 : tile;
+        const int64_t tile_next = rd + 1 < nrounds ? tile + (int64_t)pblocks * 8 : tile;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { d_m[i] = 0.f; d_h[i] = 0.f; }
+        for (int i = 0; i < 16; ++i) { d_m[0][i] = 0.f; d_m[1][i] = 0.f; d_h[0][i] = 0.f; d_h[1][i] = 0.f; }
 #pragma unroll 1
         for (int ct = 0; ct < NCT; ct += 2) {
             chunk(ct, tile_next, a0, b0, a1, b1);
             chunk(ct + 1, tile_next, a1, b1, a0, b0);
         }
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            float prev[4];
+        for (int nb = 0; nb < 2; ++nb) {
+            const int fcol = 64 * slice + 32 * nb + r;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int64_t row = tile * 32 + 8 * g4 + 4 * hi + u;
-                if (row >= V) row = V - 1;
-                prev[u] = dh[row * H + fcol];
-            }
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float prev[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = 4 * g4 + u;
-                const int64_t row = tile * 32 + 8 * g4 + 4 * hi + u;
-                if (row < V) {
-                    dm[row * H + fcol] = d_m[i];
-                    dh[row * H + fcol] = d_h[i] + prev[u];
+                for (int u = 0; u < 4; ++u) {
+                    int64_t row = tile * 32 + 8 * g4 + 4 * hi + u;
+                    if (row >= V) row = V - 1;
+                    prev[u] = dh[row * H + fcol];
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = 4 * g4 + u;
+                    const int64_t row = tile * 32 + 8 * g4 + 4 * hi + u;
+                    if (row < V) {
+                        dm[row * H + fcol] = d_m[nb][i];
+                        dh[row * H + fcol] = d_h[nb][i] + prev[u];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
         tile = tile_next;
     }
@@ -543,7 +551,7 @@ static int launch_dx_stream(const float* ws, const float* W_ih, const float* W_h
                                   (int)lds);
         attr_done = true;
     }
-    const int64_t rounds = (V + 127) / 128;
+    const int64_t rounds = (V + 255) / 256;
     int64_t pblocks = 256 / NS;
     if (pblocks > rounds) pblocks = rounds;
     pblocks = (pblocks + 7) / 8 * 8;
