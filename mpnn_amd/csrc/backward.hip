@@ -687,9 +687,11 @@ extern "C" int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const 
                            H);
         rc = launch_status("mpnn_gru_update_bwd_f32(gates)");
         if (rc) return rc;
-        static const bool stream128 = getenv("MPNN_GRU128_STREAM") != nullptr;
+        // hidden 128: the streamed kernel (2 output slices, 32 x 64 tile per wave) beats the resident-slice one
+        // (4 slices) by ~1 ms on c4; MPNN_GRU128_SLICED_DX=1 selects the latter
+        static const bool sliced_dx = getenv("MPNN_GRU128_SLICED_DX") != nullptr;
         if (H == 256) rc = launch_gru_bwd_dx_stream256(ws, W_ih, W_hh, dm, dh, V, s);
-        else if (stream128) rc = launch_gru_bwd_dx_stream128(ws, W_ih, W_hh, dm, dh, V, s);
+        else if (!sliced_dx) rc = launch_gru_bwd_dx_stream128(ws, W_ih, W_hh, dm, dh, V, s);
         else rc = launch_gru_bwd_dx128(ws, W_ih, W_hh, dm, dh, V, s);
         if (rc) return rc;
         if (H == 256) return launch_gru_bwd_dw256(m, h, ws, dW_ih, dW_hh, db_ih, db_hh, V, s);
