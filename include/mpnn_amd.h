@@ -111,6 +111,17 @@ int mpnn_att_gate_f32(const float* z_atom, const float* q, const int32_t* dst, c
 int mpnn_att_gate_bwd_f32(const float* gate, const float* dgate, const int32_t* row_ptr, const int32_t* edge_type,
                           float* dz_atom, float* dq, int64_t V, int64_t E, int K, int F, void* stream);
 
+/*
+ * Backward of gated message FOLLOWED BY adjacency-weighted aggregation, gate-gradient part, without a materialised
+ * dmsg or dx:  dgate[e, :] = (A[type e]^T . (w[e] * dagg[dst[e], :])) * h[src[e], :].
+ * replaces: the autograd of att_edge_network.py:26-31 composed with adjacent_message_agg.py:18 for d(gate).
+ * nf = mf in {64, 128}, K <= 64 only (MPNN_EINVAL otherwise: callers use segsum_bwd + edge_message_bwd + a product).
+ */
+int mpnn_edge_message_agg_bwd_dgate_f32(const float* dagg, const float* A, const float* h, const int32_t* src,
+                                        const int32_t* dst, const float* w /* may be NULL */,
+                                        const int32_t* order, const int32_t* type_ptr, float* dgate,
+                                        int64_t V, int64_t E, int K, int nf, int mf, void* stream);
+
 /* ------------------------------------------------------------------ edge tower ----- */
 /*
  * The run of n_layers aliased Linear(L, L, bias=False) + ReLU blocks of the bond-feature tower

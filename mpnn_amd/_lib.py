@@ -31,6 +31,8 @@ _SIGNATURES = {
                                                  i64, i64, i32, i32, i32, c_v]),
     "mpnn_edge_message_agg_bwd_da_f32": (ctypes.c_int, [c_f, c_f, c_i, c_i, c_f, c_i, c_i, c_f, c_f,
                                                         i64, i64, i32, i32, i32, c_v]),
+    "mpnn_edge_message_agg_bwd_dgate_f32": (ctypes.c_int, [c_f, c_f, c_f, c_i, c_i, c_f, c_i, c_i, c_f,
+                                                           i64, i64, i32, i32, i32, c_v]),
     "mpnn_att_gate_f32": (ctypes.c_int, [c_f, c_f, c_i, c_i, c_f, i64, i64, i32, i32, c_v]),
     "mpnn_att_gate_bwd_f32": (ctypes.c_int, [c_f, c_f, c_i, c_i, c_f, c_f, i64, i64, i32, i32, c_v]),
     "mpnn_tower_chain_f32": (ctypes.c_int, [c_f, c_f, c_f, i32, i32, i32, c_v]),

@@ -588,6 +588,9 @@ int launch_gru_bwd_dw256(const float* m, const float* h, const float* ws, float*
 int launch_edge_pertype(int mode, const float* h, const float* A, const int32_t* src, const int32_t* order,
                         const int32_t* type_ptr, const float* gate, const float* dmsg, float* out, float* dA, int K,
                         int nf, int mf, hipStream_t s);
+int launch_message_dgate(const float* dagg, const float* A, const int32_t* dst, const float* w, const int32_t* order,
+                         const int32_t* type_ptr, const float* hmul, const int32_t* hsrc, float* dgate, int64_t E, int K,
+                         int F, hipStream_t s);
 // fused H = 64 path (gru_bwd.hip)
 int launch_gru_bwd_fused64(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
                            const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
@@ -731,6 +734,19 @@ extern "C" int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const 
                        6 * H, 3 * H, (const int32_t*)nullptr, (const int32_t*)nullptr, (const float*)nullptr,
                        (const int32_t*)nullptr, 1, dW_hh, db_hh, V);
     return launch_status("mpnn_gru_update_bwd_f32(dW)");
+}
+
+extern "C" int mpnn_edge_message_agg_bwd_dgate_f32(const float* dagg, const float* A, const float* h, const int32_t* src,
+                                                   const int32_t* dst, const float* w, const int32_t* order,
+                                                   const int32_t* type_ptr, float* dgate, int64_t V, int64_t E, int K,
+                                                   int nf, int mf, void* stream) {
+    MPNN_REQUIRE(E >= 0 && V >= 0 && K >= 0, "mpnn_edge_message_agg_bwd_dgate_f32: negative size");
+    MPNN_REQUIRE(nf == mf && (nf == 64 || nf == 128) && K <= 64,
+                 "mpnn_edge_message_agg_bwd_dgate_f32: only nf = mf in {64, 128}, K <= 64 (got %d, %d, %d)", nf, mf, K);
+    if (E == 0) return MPNN_OK;
+    MPNN_REQUIRE(dagg && A && h && src && dst && order && type_ptr && dgate && K > 0,
+                 "mpnn_edge_message_agg_bwd_dgate_f32: NULL buffer");
+    return launch_message_dgate(dagg, A, dst, w, order, type_ptr, h, src, dgate, E, K, nf, (hipStream_t)stream);
 }
 
 extern "C" int mpnn_edge_message_agg_bwd_da_f32(const float* dagg, const float* h, const int32_t* src,

@@ -12,11 +12,16 @@
 
 namespace mpnn {
 
-template <int F, int NW, bool BWD, bool GATED>
+// DGATE (with BWD): the gate gradient of message + adjacency-weighted sum in one pass,
+//   out[e] = (A_k^T (w[e] * dagg[dst(e)])) * hmul[hsrc(e)]      -- rows of `h` (= dagg) gathered through `rowidx` (= dst),
+// so neither d(msg) nor dx is ever written.
+template <int F, int NW, bool BWD, bool GATED, bool DGATE = false>
 __global__ void __launch_bounds__(64 * NW, (F == 64 && !GATED) ? 4 : 1) edge_message_split_kernel(
     const float* __restrict__ h, const float* __restrict__ A, const int32_t* __restrict__ src,
     const int32_t* __restrict__ order, const int32_t* __restrict__ type_ptr, const float* __restrict__ gate,
-    float* __restrict__ msg, int K) {
+    float* __restrict__ msg, int K, const int32_t* __restrict__ rowidx = nullptr,
+    const float* __restrict__ wrow = nullptr, const float* __restrict__ hmul = nullptr,
+    const int32_t* __restrict__ hsrc = nullptr) {
     constexpr int ROWB = 2 * F, IMG = F * ROWB;
     constexpr int NCH = F / 32;                // 16-float chunks in a lane's half-row
     constexpr int NB = F / 32;                 // 32-column output blocks
@@ -60,7 +65,7 @@ __global__ void __launch_bounds__(64 * NW, (F == 64 && !GATED) ? 4 : 1) edge_mes
             const int pos = tb + 32 * tile + r;
             return order[pos < te ? pos : tb + 32 * tile];
         };
-        auto src_of = [&](int e) { return BWD ? e : src[e]; };
+        auto src_of = [&](int e) { return BWD ? (DGATE ? rowidx[e] : e) : src[e]; };
         // chunk j (0..NCH-1): 16 floats at 16*j of the lane half's F/2 floats of the row
         auto load_chunk = [&](int s_row, int j, f32x4 (&f)[4]) {
             const float* p = h + (int64_t)s_row * F + hi * (F / 2) + 16 * j;
@@ -139,9 +144,17 @@ __global__ void __launch_bounds__(64 * NW, (F == 64 && !GATED) ? 4 : 1) edge_mes
                 const int row = acc_row(i, lane);
                 const int e_row = __shfl(e_cur, row);
                 if (row < rows) {
+                    if (DGATE) {
+                        const float wv = wrow ? wrow[e_row] : 1.0f;
+                        const float* hm = hmul + (int64_t)hsrc[e_row] * F + r;
 #pragma unroll
-                    for (int n = 0; n < NB; ++n)
-                        __builtin_nontemporal_store(acc[n][i], msg + (int64_t)e_row * F + 32 * n + r);
+                        for (int n = 0; n < NB; ++n)
+                            __builtin_nontemporal_store(acc[n][i] * wv * hm[32 * n], msg + (int64_t)e_row * F + 32 * n + r);
+                    } else {
+#pragma unroll
+                        for (int n = 0; n < NB; ++n)
+                            __builtin_nontemporal_store(acc[n][i], msg + (int64_t)e_row * F + 32 * n + r);
+                    }
                 }
                 if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
@@ -188,6 +201,36 @@ int launch_message_dx_split128(const float* dmsg, const float* A, const int32_t*
                                float* dx, int64_t E, int K, hipStream_t s) {
     return launch_split<128, true>(dmsg, A, nullptr, order, type_ptr, nullptr, dx, E, K, s);
 }
+template <int F>
+static int launch_dgate(const float* dagg, const float* A, const int32_t* dst, const float* w, const int32_t* order,
+                        const int32_t* type_ptr, const float* hmul, const int32_t* hsrc, float* dgate, int64_t E, int K,
+                        hipStream_t s) {
+    constexpr int NW = F == 128 ? 8 : 4;
+    const size_t lds = (size_t)3 * F * 2 * F;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)edge_message_split_kernel<F, NW, true, false, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    int64_t blocks = F == 128 ? 256 : 1024;
+    const int64_t need = ceil_div(ceil_div(E, 32) + K, NW);
+    if (blocks > need) blocks = need;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((edge_message_split_kernel<F, NW, true, false, true>), dim3((unsigned)blocks), dim3(64 * NW), lds, s,
+                       dagg, A, (const int32_t*)nullptr, order, type_ptr, (const float*)nullptr, dgate, K, dst, w, hmul,
+                       hsrc);
+    return launch_status("mpnn_edge_message_agg_bwd_dgate_f32");
+}
+
+int launch_message_dgate(const float* dagg, const float* A, const int32_t* dst, const float* w, const int32_t* order,
+                         const int32_t* type_ptr, const float* hmul, const int32_t* hsrc, float* dgate, int64_t E, int K,
+                         int F, hipStream_t s) {
+    if (F == 128) return launch_dgate<128>(dagg, A, dst, w, order, type_ptr, hmul, hsrc, dgate, E, K, s);
+    if (F == 64) return launch_dgate<64>(dagg, A, dst, w, order, type_ptr, hmul, hsrc, dgate, E, K, s);
+    return 1;
+}
+
 int launch_message_split64(const float* h, const float* A, const int32_t* src, const int32_t* order,
                            const int32_t* type_ptr, const float* gate, float* msg, int64_t E, int K, hipStream_t s) {
     return launch_split<64, false>(h, A, src, order, type_ptr, gate, msg, E, K, s);

@@ -256,6 +256,24 @@ class MessageAggregate(torch.autograd.Function):
                     _lib.iptr(g.order), _lib.iptr(g.type_ptr), _lib.fptr(gate), _lib.fptr(dA), g.num_nodes,
                     g.num_edges, K, nf, mf, _lib.stream()), "mpnn_edge_message_agg_bwd_da_f32")
             return None, dA, None, None, None
+        if (gate is not None and ctx.needs_input_grad[2] and not ctx.needs_input_grad[0] and mf == nf
+                and mf in (64, 128) and K <= 64 and os.environ.get("MPNN_GRU_MATH") != "fp32"):
+            # attention models: the node features feeding the message are constants, only the gate (and A) want
+            # gradients -- both come straight from dout[dst(e)]; d(msg) and dx are never written
+            lib = _lib.load()
+            dA = torch.zeros_like(A) if ctx.needs_input_grad[1] else None
+            dgate = _empty((g.num_edges, nf), h)
+            if g.num_edges:
+                if dA is not None:
+                    _lib.check(lib.mpnn_edge_message_agg_bwd_da_f32(
+                        _lib.fptr(dout), _lib.fptr(h), _lib.iptr(g.col_idx), _lib.iptr(g.edge_dst), _lib.fptr(w),
+                        _lib.iptr(g.order), _lib.iptr(g.type_ptr), _lib.fptr(gate), _lib.fptr(dA), g.num_nodes,
+                        g.num_edges, K, nf, mf, _lib.stream()), "mpnn_edge_message_agg_bwd_da_f32")
+                _lib.check(lib.mpnn_edge_message_agg_bwd_dgate_f32(
+                    _lib.fptr(dout), _lib.fptr(A), _lib.fptr(h), _lib.iptr(g.col_idx), _lib.iptr(g.edge_dst), _lib.fptr(w),
+                    _lib.iptr(g.order), _lib.iptr(g.type_ptr), _lib.fptr(dgate), g.num_nodes, g.num_edges, K, nf, mf,
+                    _lib.stream()), "mpnn_edge_message_agg_bwd_dgate_f32")
+            return None, dA, dgate, None, None
         dmsg = segsum_bwd_raw(dout, g.row_ptr, w, g.num_edges)
         dx, dA = edge_message_bwd_raw(h, A, g, gate, dmsg, need_dx=need_dx, need_dA=ctx.needs_input_grad[1])
         if not need_dx:

@@ -285,3 +285,41 @@ def test_aggregators_on_sparse_messages_backward(dev, kind):
         assert _rel(prm.grad.cpu(), ref_g) < 1e-4, k
         checked += 1
     assert checked >= 4
+
+
+@pytest.mark.parametrize("H,K,V", [(64, 4, 2500), (128, 4, 900), (64, 1, 300), (32, 3, 400)])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_gated_message_aggregate_gate_gradient(dev, H, K, V, weighted):
+    """Gated message + adjacency-weighted sum with gradients wanted for the gate and A but not for the node features
+    (the attention models): at widths 64 / 128 both come from dout[dst(e)] directly (mpnn_edge_message_agg_bwd_dgate_f32,
+    _da_f32); other widths take the unfused route.  float64 reference."""
+    from mpnn_amd import ops
+    from mpnn_amd.graph import MolGraph
+    rng = np.random.default_rng(H + K + V + 7 * weighted)
+    deg = rng.integers(0, 6, V)
+    row_ptr = np.zeros(V + 1, np.int32)
+    np.cumsum(deg, out=row_ptr[1:])
+    E = int(row_ptr[-1])
+    col = rng.integers(0, V, E).astype(np.int32)
+    et = rng.integers(0, K, E).astype(np.int32)
+    h = torch.from_numpy(rng.standard_normal((V, H)).astype(np.float32))
+    A = torch.from_numpy((rng.standard_normal((K, H, H)) / np.sqrt(H)).astype(np.float32))
+    gate = torch.from_numpy(rng.random((E, H)).astype(np.float32))
+    w = torch.from_numpy((rng.random(E) + 0.5).astype(np.float32)) if weighted else None
+    cot = torch.from_numpy(rng.standard_normal((V, H)).astype(np.float32))
+    dst = np.repeat(np.arange(V), deg)
+    Ad, gd = A.double().requires_grad_(True), gate.double().requires_grad_(True)
+    msg = torch.einsum("emn,en->em", Ad[et.astype(np.int64)], gd * h.double()[col.astype(np.int64)])
+    if weighted:
+        msg = msg * w.double().unsqueeze(1)
+    ref = torch.zeros(V, H, dtype=torch.float64).index_add(0, torch.from_numpy(dst), msg)
+    gref = torch.autograd.grad((ref * cot.double()).sum(), [Ad, gd])
+    t = lambda a: torch.from_numpy(a).to(dev)
+    g = MolGraph(t(row_ptr), t(col), None, t(et), torch.zeros(K, 1, device=dev),
+                 torch.tensor([0, V], dtype=torch.int32, device=dev))
+    Ag, gg = A.to(dev).requires_grad_(True), gate.to(dev).requires_grad_(True)
+    out = ops.message_aggregate(h.to(dev), Ag, g, w.to(dev) if weighted else None, gate=gg)
+    ggpu = torch.autograd.grad((out * cot.to(dev)).sum(), [Ag, gg])
+    assert _rel(out.detach().cpu(), ref.detach()) < 1e-5
+    for a, b, name in zip(ggpu, gref, ("dA", "dgate")):
+        assert _rel(a.cpu(), b) < 2e-5, (name, _rel(a.cpu(), b))
