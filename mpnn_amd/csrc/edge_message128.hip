@@ -85,6 +85,15 @@ __global__ void __launch_bounds__(64 * NW, (F == 64 && !GATED) ? 4 : 1) edge_mes
         int s_cur = src_of(e_cur);
         int e_nxt = e_cur, s_nxt = s_cur;
         if (t + nw < tiles) { e_nxt = edge_of(t + nw); s_nxt = src_of(e_nxt); }
+        // DGATE epilogue operands of lane r's own edge (broadcast by shuffle later): fetched a tile ahead with the
+        // other indices, so the epilogue only issues the independent hmul row loads
+        int hs_cur = 0, hs_nxt = 0;
+        float w_cur = 1.0f, w_nxt = 1.0f;
+        if (DGATE) {
+            hs_cur = hsrc[e_cur];
+            hs_nxt = hsrc[e_nxt];
+            if (wrow) { w_cur = wrow[e_cur]; w_nxt = wrow[e_nxt]; }
+        }
         // Gated rows: the gate chunk travels in its own one-deep buffer and is multiplied in AFTER the MFMAs of the
         // running chunk are issued (a multiply at fetch time would wait for both loads before any MFMA goes out).
         f32x4 ring[RD][4], gbuf[4];
@@ -143,10 +152,11 @@ __global__ void __launch_bounds__(64 * NW, (F == 64 && !GATED) ? 4 : 1) edge_mes
             for (int i = 0; i < 16; ++i) {
                 const int row = acc_row(i, lane);
                 const int e_row = __shfl(e_cur, row);
+                const float wv = DGATE ? __shfl(w_cur, row) : 1.0f;      // shuffles stay outside the divergent branch
+                const int hs_row = DGATE ? __shfl(hs_cur, row) : 0;
                 if (row < rows) {
                     if (DGATE) {
-                        const float wv = wrow ? wrow[e_row] : 1.0f;
-                        const float* hm = hmul + (int64_t)hsrc[e_row] * F + r;
+                        const float* hm = hmul + (int64_t)hs_row * F + r;
 #pragma unroll
                         for (int n = 0; n < NB; ++n)
                             __builtin_nontemporal_store(acc[n][i] * wv * hm[32 * n], msg + (int64_t)e_row * F + 32 * n + r);
@@ -162,6 +172,12 @@ __global__ void __launch_bounds__(64 * NW, (F == 64 && !GATED) ? 4 : 1) edge_mes
             s_cur = s_nxt;
             e_nxt = e_nn;
             s_nxt = s_nn;
+            if (DGATE) {
+                hs_cur = hs_nxt;
+                w_cur = w_nxt;
+                hs_nxt = hsrc[e_nxt];
+                if (wrow) w_nxt = wrow[e_nxt];
+            }
         }
     }
 }
