@@ -20,16 +20,33 @@ def _flatten(tensor, mask):
 
 
 class MaskBatchNorm(nn.Module):
+    sync_stats = False        # True: moments over all ranks of the default process group (parallel.synced_masked_batch_norm)
+
     def forward(self, tensor, mask, eps=1e-6):
+        if self.sync_stats:
+            from mpnn_amd import parallel
+            return parallel.synced_masked_batch_norm(tensor, mask, None, None, eps, masked_mean=False, eps_inside=True)[0]
         y, mk = _flatten(tensor, mask)
         out, _, _ = ops.masked_batch_norm(y, mk, None, None, None, eps, ops.BN_EPS_INSIDE)
         return out.view(tensor.shape)
 
 
 class MaskBatchNorm1d(nn.BatchNorm1d):
+    sync_stats = False        # True (training mode): moments over all ranks of the default process group
+
     def forward(self, tensor, mask):
         y, mk = _flatten(tensor, mask)
         w, b = (self.weight, self.bias) if self.affine else (None, None)
+        if self.sync_stats and (self.training or not self.track_running_stats):
+            from mpnn_amd import parallel
+            out, mean, var = parallel.synced_masked_batch_norm(tensor, mask, w, b, self.eps, masked_mean=True,
+                                                               eps_inside=False)
+            if self.track_running_stats:
+                with torch.no_grad():
+                    keep = 1 - self.momentum
+                    self.running_mean = keep * self.running_mean + self.momentum * mean
+                    self.running_var = keep * self.running_var + self.momentum * var
+            return out
         if (not self.training) and self.track_running_stats:
             out, _, _ = ops.masked_batch_norm(y, mk, w, b, (self.running_mean, self.running_var), self.eps,
                                               ops.BN_MASKED_MEAN | ops.BN_USE_STATS)

@@ -74,3 +74,34 @@ def global_count(local_count, device, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(t, group=group)
     return float(t.item())
+
+
+def synced_masked_batch_norm(x, mask, weight=None, bias=None, eps=1e-5, masked_mean=True, eps_inside=False, group=None):
+    """Masked batch norm whose statistics span ALL ranks of `group` (the lipo / attention models' norms take
+    their moments over every atom of the batch, so a batch sharded by graph needs the three sums all-reduced to keep
+    single-process results).  Same arithmetic as models/mask_batch_norm.py:5-38 -- mean numerator masked or not,
+    variance around the mean, eps inside or outside the root -- written in differentiable torch ops with the
+    collective inside the autograd graph (its backward is another all-reduce).  Returns (y, mean, var).
+    Without an initialised process group (or world size 1) it is the single-process formula."""
+    from torch.distributed.nn.functional import all_reduce as ar
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    mk = mask.reshape(-1, 1)
+    y = x.reshape(-1, x.shape[-1])
+    s = torch.cat([mk.sum().reshape(1), ((y * mk) if masked_mean else y).sum(dim=0)])
+    if multi:
+        s = ar(s, group=group)
+    cnt, mean = s[0], s[1:] / s[0]
+    c = (y - mean) * mk
+    q = (c * c).sum(dim=0)
+    if multi:
+        q = ar(q, group=group)
+    var = q / cnt
+    scale = (var + eps).sqrt() if eps_inside else var.sqrt() + eps
+    if masked_mean:                      # MaskBatchNorm1d: affine on the unmasked normalised value, mask last
+        out = (y - mean) / scale
+        if weight is not None:
+            out = weight * out + bias
+        out = out * mk
+    else:                                # MaskBatchNorm: mask inside, no parameters
+        out = c / scale
+    return out.view(x.shape), mean, var

@@ -75,3 +75,61 @@ def test_two_rank_gradient_equals_single_process():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert np.abs(got - ref).max() < 1e-6
+
+
+def _bn_worker(rank, world, port, x, mask, w, b, cot, rows, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = {}
+    for name, kw in (("bn", dict(masked_mean=False, eps_inside=True, eps=1e-6)),
+                     ("bn1d", dict(masked_mean=True, eps_inside=False, eps=1e-5))):
+        ids = rows[rank]
+        xs = x[ids].clone().requires_grad_(True)
+        ws, bs = (w.clone().requires_grad_(True), b.clone().requires_grad_(True)) if name == "bn1d" else (None, None)
+        y, mean, var = parallel.synced_masked_batch_norm(xs, mask[ids], ws, bs, **kw)
+        (y * cot[ids]).sum().backward()
+        res[name] = (y.detach().numpy(), xs.grad.numpy(), mean.detach().numpy(), var.detach().numpy(),
+                     None if ws is None else ws.grad.numpy())
+    out.put((rank, res))
+    dist.destroy_process_group()
+
+
+def test_synced_masked_batch_norm_matches_single_process():
+    """Statistics all-reduced over 2 gloo ranks == the oracle's masked norms on the whole batch: outputs, moments,
+    and gradients wrt the inputs (the weight gradient is each rank's share, summed by the gradient all-reduce)."""
+    from oracle import dense_ref as O
+    torch.manual_seed(0)
+    V, F = 91, 6
+    x = torch.randn(V, F)
+    mask = (torch.rand(V, 1) > 0.2).float()
+    x = x * mask
+    w, b = torch.rand(F) + 0.5, torch.rand(F) - 0.5
+    cot = torch.randn(V, F)
+    rows = [torch.arange(0, 40), torch.arange(40, V)]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bn_worker, args=(r, 2, port, x, mask, w, b, cot, rows, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(out.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    # references on the whole batch
+    xr = x.clone().requires_grad_(True)
+    ref = O.mask_bn(xr, mask)
+    (ref * cot).sum().backward()
+    y = np.concatenate([got[0]["bn"][0], got[1]["bn"][0]])
+    gx = np.concatenate([got[0]["bn"][1], got[1]["bn"][1]])
+    assert np.abs(y - ref.detach().numpy()).max() < 1e-5
+    assert np.abs(gx - xr.grad.numpy()).max() < 1e-5
+    params = {"weight": w.clone().requires_grad_(True), "bias": b.clone().requires_grad_(True)}
+    xr2 = x.clone().requires_grad_(True)
+    ref1 = O.mask_bn1d(xr2, mask, params["weight"], params["bias"], training=True)[0]
+    (ref1 * cot).sum().backward()
+    y1 = np.concatenate([got[0]["bn1d"][0], got[1]["bn1d"][0]])
+    gx1 = np.concatenate([got[0]["bn1d"][1], got[1]["bn1d"][1]])
+    assert np.abs(y1 - ref1.detach().numpy()).max() < 1e-5
+    assert np.abs(gx1 - xr2.grad.numpy()).max() < 2e-5
+    assert np.abs(got[0]["bn1d"][4] + got[1]["bn1d"][4] - params["weight"].grad.numpy()).max() < 2e-5
+    assert np.abs(got[0]["bn1d"][2] - got[1]["bn1d"][2]).max() == 0          # both ranks hold the same moments
