@@ -139,3 +139,58 @@ def test_hoisted_message_matches_per_step_message(dev):
     for k in res[0][1]:
         scale = max(1.0, float(res[0][1][k].abs().max()))
         assert max_err(res[0][1][k], res[1][1][k]) / scale < 1e-5, k
+
+
+@pytest.mark.parametrize("H", [64, 128, 256])
+@pytest.mark.parametrize("case", ["single_atoms", "one_molecule", "isolated_atoms", "tiny_many"])
+def test_degenerate_batches_at_fast_path_widths(dev, H, case):
+    """Degenerate dense batches through the width-specific kernels (64 / 128 / 256): molecules of one atom (no edges
+    at all), a single molecule, atoms without bonds inside a molecule, many two-atom molecules -- forward and the GRU /
+    message parameter gradients against the oracle."""
+    from mpnn_amd.models.basic_model import BasicModel
+    g = torch.Generator().manual_seed(H + sum(map(ord, case)))
+    if case == "single_atoms":
+        B, N = 5, 1
+        adj = torch.zeros(B, N, N)
+    elif case == "one_molecule":
+        B, N = 1, 9
+        adj = (torch.rand(B, N, N, generator=g) < 0.3).float()
+    elif case == "isolated_atoms":
+        B, N = 3, 7
+        adj = (torch.rand(B, N, N, generator=g) < 0.3).float()
+        adj[:, 2, :] = 0
+        adj[:, :, 2] = 0                                   # atom 2 of every molecule has no bond
+    else:
+        B, N = 40, 2
+        adj = torch.ones(B, N, N)
+    adj = ((adj + adj.transpose(1, 2)) > 0).float() * (1 - torch.eye(N))
+    mask = torch.ones(B, N, 1)
+    if case == "isolated_atoms":
+        mask[1, 5:] = 0                                    # and molecule 1 is shorter (padded rows)
+        adj[1, 5:, :] = 0
+        adj[1, :, 5:] = 0
+    types = torch.randint(0, 4, (B, N, N), generator=g)
+    types = torch.triu(types, 1)
+    types = types + types.transpose(1, 2)
+    bfm = torch.nn.functional.one_hot(types, 4).float() * adj.unsqueeze(-1)
+    afm = (torch.rand(B, N, H, generator=g) * 2 - 1) * mask
+    torch.manual_seed(5)
+    model = BasicModel(H, 4, H, N, 4, message_opts={}, agg_opts={}, update_opts={}, readout_opts={}, message_steps=2)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if "bias" in k:
+                p.uniform_(-0.1, 0.1)
+    params = _shared_leaves(model)
+    cot = torch.rand(B, 4, generator=g) - 0.5
+    ref, ref_state = O.basic_model_forward(params, afm, bfm, adj, mask, 2, True)
+    (ref * cot).sum().backward()
+    model = model.to(dev)
+    out = model(afm.to(dev), bfm.to(dev), adj.to(dev), mask.to(dev))
+    state, _ = model.message_passing(afm.to(dev), bfm.to(dev), adj.to(dev), mask.to(dev))
+    (out * cot.to(dev)).sum().backward()
+    assert _rel(state.detach().cpu(), ref_state) < 2e-5
+    assert _rel(out.detach().cpu(), ref) < 5e-5
+    for k, p in model.named_parameters():
+        if params[k].grad is None or p.grad is None:
+            continue
+        assert _rel(p.grad.cpu(), params[k].grad) < 5e-4, (k, _rel(p.grad.cpu(), params[k].grad))
