@@ -308,7 +308,10 @@ def main():
             "config": {"workload": "%s: %s" % (args.workload, desc), "mode": ("train: forward + backward + flat-gradient all-reduce" if args.mode == "train" else "forward only"), "mols_per_gpu": mols,
                        "atoms_per_gpu": V, "edges_per_gpu": E, "hidden": hidden, "mp_steps": T,
                        "edge_features": 4, "edge_types": graph.num_types, "parallelism": "dp%d" % world,
-                       "edges_counted": "directed edges x MP steps per pass"},
+                       "edges_counted": "directed edges x MP steps per pass",
+                       "math": ("fp32 matrix pipe (MPNN_GRU_MATH=fp32)" if os.environ.get("MPNN_GRU_MATH") == "fp32" else
+                                "fp32 data and accumulation; dense contractions as three-way bf16 operand splits "
+                                "(six bf16 MFMAs per fp32 product), parity 1e-5 as the fp32 kernels")},
             "roofline": {"kernel": "segsum_pair_kernel (aggregator, mpnn_segsum_f32)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": seg_ms, "algorithmic_bytes_per_launch": alg_bytes},
