@@ -54,7 +54,7 @@ class EdgeMessages:
         mf = self.num_features
         if self.A0 is None:
             return torch.zeros(g.num_nodes, mf, device=self.h.device)
-        rest = ops.molecule_sum(self.h, g)[g.node_graph] - ops.neighbour_sum(self.h, g)
+        rest = ops.molecule_broadcast(ops.molecule_sum(self.h, g), g) - ops.neighbour_sum(self.h, g)
         if self.row_gate is not None:
             rest = rest * self.row_gate
         return rest @ self.A0.t()

@@ -59,13 +59,15 @@ def _timed(name, fn):
 
 
 # --------------------------------------------------------------------------- raw launches
-def segsum_raw(msg, row_ptr, w, num_rows):
+def segsum_raw(msg, row_ptr, w, num_rows, label="segsum"):
+    """`label` names the launch for ops.KernelTimer: "segsum" is reserved for the aggregator proper (message rows
+    summed per destination atom), so per-molecule sums and gradient scatters do not dilute its measured time."""
     lib = _lib.load()
     F = int(msg.shape[-1])
     if msg.shape[0] == 0 or num_rows == 0:          # no edges at all: every row is an empty sum
         return torch.zeros(num_rows, F, dtype=torch.float32, device=msg.device)
     out = _empty((num_rows, F), msg)
-    _lib.check(_timed("segsum", lambda: lib.mpnn_segsum_f32(
+    _lib.check(_timed(label, lambda: lib.mpnn_segsum_f32(
         _lib.fptr(msg), _lib.iptr(row_ptr), _lib.fptr(w), _lib.fptr(out), num_rows, F, _lib.stream())),
         "mpnn_segsum_f32")
     return out
@@ -400,7 +402,7 @@ class _MoleculeSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, graph):
         ctx.graph = graph
-        return segsum_raw(x.contiguous(), graph.graph_ptr, None, graph.num_graphs)
+        return segsum_raw(x.contiguous(), graph.graph_ptr, None, graph.num_graphs, label="molecule_sum")
 
     @staticmethod
     def backward(ctx, dout):
@@ -419,7 +421,7 @@ class _MoleculeBroadcast(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         g = ctx.graph
-        return segsum_raw(dout.contiguous(), g.graph_ptr, None, g.num_graphs), None
+        return segsum_raw(dout.contiguous(), g.graph_ptr, None, g.num_graphs, label="molecule_sum"), None
 
 
 def molecule_broadcast(x, graph):
@@ -439,7 +441,7 @@ class _ExpandRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         g = ctx.graph
-        return segsum_raw(dout.contiguous(), g.row_ptr, None, g.num_nodes), None
+        return segsum_raw(dout.contiguous(), g.row_ptr, None, g.num_nodes, label="row_sum_bwd"), None
 
 
 def expand_rows(x, graph):
