@@ -25,6 +25,13 @@ class AttMsgAgg(nn.Module):
     def forward(self, messages, adj):
         if isinstance(messages, EdgeMessages):
             g = messages.graph
+            if isinstance(self.att[1], nn.Softmax) and self.att[1].dim == -1 and messages._values is None:
+                # default activation: a softmax over the size-1 last axis is identically 1 (and its gradient towards the
+                # Linear is identically 0), so the member pairs are a plain sum -- message + sum as ONE autograd node,
+                # exactly as AdjMsgAgg does -- and every non-member pair of the padded row joins with weight 1
+                A, gate = messages.recipe
+                out = ops.message_aggregate(messages.h, A, g, None, gate) + messages.nonedge_sum()
+                return g.node_unview(out)
             w = self.att(edge_adjacency(messages, adj).unsqueeze(-1)).squeeze(-1).contiguous()
             w0 = self.att(torch.zeros(1, 1, device=w.device)).reshape(())
             out = ops.segsum(messages.values, g.row_ptr, w) + w0 * messages.nonedge_sum()
