@@ -538,6 +538,176 @@ __global__ void __launch_bounds__(512) gru_update_stream_kernel(
     }
 }
 
+template <int H, bool HAS_MASK>
+__global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
+    const float* __restrict__ m, const float* __restrict__ h, const float* __restrict__ mask,
+    const float* __restrict__ W_ih, const float* __restrict__ W_hh, const float* __restrict__ b_ih,
+    const float* __restrict__ b_hh, float* __restrict__ out, float* __restrict__ saved, int64_t V) {
+    constexpr int NS = H / 64, NCHUNK = H / 32, COLS = 192;
+    constexpr int IMGC = COLS * 64;            // bytes of one (matrix, piece) chunk image: 192 columns x 32 k bf16
+    constexpr int BUF = 6 * IMGC;              // 72 KB
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][2 matrices][3 pieces][192][32] bf16
+
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int slice = jb % NS;                                 // the NS slice blocks of a row group share an XCD
+    const int pblock = (jb / NS) * 8 + xcd, pblocks = gridDim.x / NS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hi = lane >> 5;
+
+    const int64_t rounds_total = (V + 255) / 256;              // a round = 256 rows: every wave its own 32-row tile
+    if (pblock >= rounds_total) return;                        // block-uniform
+    const int64_t nrounds = (rounds_total - pblock + pblocks - 1) / pblocks;
+
+
+
+    // ---- weight staging: unit = (matrix, k-octet of the chunk, column); 1536 units, three per thread ----
+    // per-thread constants of its three units: source pointer at chunk 0 and LDS byte offset
+    const float* wsrc[3];
+    int ldst[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int u = tid + 512 * j;
+        const int mat = u / 768, rem = u % 768;
+        const int o = rem / COLS, cl = rem % COLS;
+        wsrc[j] = (mat ? W_hh : W_ih) + (int64_t)(8 * o) * 3 * H + (cl / 64) * H + 64 * slice + (cl % 64);
+        ldst[j] = mat * 3 * IMGC + cl * 64 + ((o ^ ((cl >> 2) & 3)) << 4);
+    }
+    // one staging unit at a time (8 registers live): loaded before a third of the chunk's MFMAs, written after it
+    float raw[8];
+    auto stage_load1 = [&](int c, int j) {
+        const float* W = wsrc[j] + (int64_t)(32 * c) * 3 * H;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) raw[i] = W[(int64_t)i * 3 * H];
+    };
+    auto stage_write1 = [&](int buf, int j) {
+        const f32x4 x0 = {raw[0], raw[1], raw[2], raw[3]};
+        const f32x4 x1 = {raw[4], raw[5], raw[6], raw[7]};
+        bf16x8 ph, pm, pl;
+        split8(x0, x1, ph, pm, pl);
+        char* base = smem + buf * BUF + ldst[j];
+        *reinterpret_cast<bf16x8*>(base) = ph;
+        *reinterpret_cast<bf16x8*>(base + IMGC) = pm;
+        *reinterpret_cast<bf16x8*>(base + 2 * IMGC) = pl;
+    };
+    // B fragment: column cl = gate*64 + 32*nb + r, k-octet 2*hi + st of the chunk
+    auto bfrag = [&](int buf, int mat, int piece, int gate, int nb, int st) {
+        const int cl = gate * 64 + 32 * nb + r;
+        const int o = 2 * hi + st;
+        return *reinterpret_cast<const bf16x8*>(smem + buf * BUF + (mat * 3 + piece) * IMGC + cl * 64 +
+                                                ((o ^ ((cl >> 2) & 3)) << 4));
+    };
+    // this lane's 16 floats of chunk c of operand X for row tile `tile`
+    auto load_rows = [&](const float* __restrict__ X, int64_t tile, int c, f32x4 (&f)[4]) {
+        int64_t row = tile * 32 + r;
+        if (row >= V) row = V - 1;
+        const float* p = X + row * H + 32 * c + 16 * hi;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f[q] = *reinterpret_cast<const f32x4*>(p + 4 * q);
+    };
+
+    f32x16 acc_r[2], acc_z[2], acc_ni[2], acc_nh[2];       // 32 rows x 64 features per wave
+    f32x4 a0[4], a1[4];                                     // operand half-chunks: one multiplying, one in flight
+    int cur = 0;
+    int64_t tile = ((int64_t)pblock) * 8 + wv;
+
+    // Half-chunk hc of a round: operand hc & 1 (m, h) of K chunk hc >> 1.  While it multiplies (six groups x two
+    // column blocks = 72 MFMAs), the next half-chunk's rows are in flight and one or two units of the NEXT chunk's
+    // weights are split and parked; the barrier sits at the start of every chunk.
+    auto half = [&](int hc, int64_t tile_next, f32x4 (&x)[4], f32x4 (&nx)[4]) {
+        const int c = hc >> 1, mat = hc & 1;
+        if (mat == 0) __syncthreads();                     // buffer `cur` is complete, `cur ^ 1` is free
+        const int hn = (hc + 1) % (2 * NCHUNK);
+        load_rows((hn & 1) ? h : m, hn == 0 ? tile_next : tile, hn >> 1, nx);
+        const int cn = (c + 1) % NCHUNK;
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 a_h, a_m, a_l;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int st = i / 3, gate = i % 3;
+            if (i % 3 == 0) {
+                // staging units: 0 and 1 ride on the m half, 2 on the h half
+                if (mat == 0) stage_load1(cn, i / 3);
+                else if (i == 0) stage_load1(cn, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                split8(x[2 * st], x[2 * st + 1], a_h, a_m, a_l);
+            }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                f32x16& acc = gate == 0 ? acc_r[nb] : gate == 1 ? acc_z[nb] : (mat == 0 ? acc_ni[nb] : acc_nh[nb]);
+                mma6(acc, a_h, a_m, a_l, bfrag(cur, mat, 0, gate, nb, st), bfrag(cur, mat, 1, gate, nb, st),
+                     bfrag(cur, mat, 2, gate, nb, st));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (i % 3 == 2) {
+                if (mat == 0) stage_write1(cur ^ 1, i / 3);
+                else if (i == 2) stage_write1(cur ^ 1, 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (mat == 1) cur ^= 1;
+    };
+
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        stage_load1(0, j);
+        stage_write1(0, j);
+    }
+    load_rows(m, tile, 0, a0);
+    for (int64_t rd = 0; rd < nrounds; ++rd) {
+        const int64_t tile_next = rd + 1 < nrounds ? tile + (int64_t)pblocks * 8 : tile;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) { acc_r[nb][i] = 0.f; acc_z[nb][i] = 0.f; acc_ni[nb][i] = 0.f; acc_nh[nb][i] = 0.f; }
+#pragma unroll 1
+        for (int hc = 0; hc < 2 * NCHUNK; hc += 2) {
+            half(hc, tile_next, a0, a1);
+            half(hc + 1, tile_next, a1, a0);
+        }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int fcol = 64 * slice + 32 * nb + r;         // this lane's output feature
+            const float br = b_ih[fcol] + b_hh[fcol], bz = b_ih[H + fcol] + b_hh[H + fcol];
+            const float bni = b_ih[2 * H + fcol], bnh = b_hh[2 * H + fcol];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float mk4[4], hv4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int64_t row = tile * 32 + 8 * g + 4 * hi + u;
+                if (row >= V) row = V - 1;
+                mk4[u] = HAS_MASK ? mask[row] : 1.0f;
+                hv4[u] = h[row * H + fcol];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = 4 * g + u;
+                const int64_t row = tile * 32 + 8 * g + 4 * hi + u;
+                const float mk = mk4[u];
+                const float rg = sigmoid_fast(acc_r[nb][i] + br) * mk;
+                const float zg = sigmoid_fast(acc_z[nb][i] + bz) * mk;
+                const float nh = acc_nh[nb][i] + bnh;
+                const float ng = tanh_fast(acc_ni[nb][i] + bni + rg * nh) * mk;
+                const float o = ((1.0f - zg) * ng + zg * hv4[u]) * mk;
+                if (row < V) {
+                    __builtin_nontemporal_store(o, out + row * H + fcol);
+                    if (saved) {
+                        float* sv = saved + row * 4 * H + fcol;
+                        __builtin_nontemporal_store(rg, sv);
+                        __builtin_nontemporal_store(zg, sv + H);
+                        __builtin_nontemporal_store(ng, sv + 2 * H);
+                        __builtin_nontemporal_store(nh, sv + 3 * H);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        }
+        tile = tile_next;
+    }
+}
+
 template <int H>
 static int launch_stream(const float* m, const float* h, const float* mask, const float* W_ih, const float* W_hh,
                          const float* b_ih, const float* b_hh, float* out, float* saved, int64_t V, hipStream_t s) {
@@ -565,13 +735,42 @@ static int launch_stream(const float* m, const float* h, const float* mask, cons
     return launch_status("mpnn_gru_update_f32(bf16x6, streamed weights)");
 }
 
+template <int H>
+static int launch_stream_wide(const float* m, const float* h, const float* mask, const float* W_ih, const float* W_hh,
+                         const float* b_ih, const float* b_hh, float* out, float* saved, int64_t V, hipStream_t s) {
+    constexpr int NS = H / 64;
+    const size_t lds = (size_t)2 * 6 * 192 * 64;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gru_update_stream_wide_kernel<H, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gru_update_stream_wide_kernel<H, false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int64_t rounds = (V + 255) / 256;
+    int64_t pblocks = 256 / NS;                             // x NS slices = one block per CU (144 KB of LDS)
+    if (pblocks > rounds) pblocks = rounds;
+    pblocks = (pblocks + 7) / 8 * 8;                        // XCD-aware numbering wants groups of 8 row blocks
+    const dim3 grid((unsigned)(pblocks * NS)), block(512);
+    if (mask)
+        hipLaunchKernelGGL((gru_update_stream_wide_kernel<H, true>), grid, block, lds, s, m, h, mask, W_ih, W_hh, b_ih, b_hh,
+                           out, saved, V);
+    else
+        hipLaunchKernelGGL((gru_update_stream_wide_kernel<H, false>), grid, block, lds, s, m, h, mask, W_ih, W_hh, b_ih, b_hh,
+                           out, saved, V);
+    return launch_status("mpnn_gru_update_f32(bf16x6, streamed weights, wide tile)");
+}
+
 // returns 1 when the width has no split-precision path
 int launch_gru_split(const float* m, const float* h, const float* mask, const float* W_ih, const float* W_hh,
                      const float* b_ih, const float* b_hh, float* out, float* saved, int64_t V, int H, hipStream_t s) {
     if (H == 64) return launch_split<64, 2, 8>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, s);
     static const bool stream128 = getenv("MPNN_GRU128_STREAM") != nullptr;
-    if (H == 128 && stream128) return launch_stream<128>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, s);
+    if (H == 128 && stream128) return launch_stream_wide<128>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, s);
     if (H == 128) return launch_split128(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, s);
+    static const bool narrow256 = getenv("MPNN_GRU256_NARROW") != nullptr;
+    if (H == 256 && !narrow256) return launch_stream_wide<256>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, s);
     if (H == 256) return launch_stream<256>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, s);
     return 1;
 }
