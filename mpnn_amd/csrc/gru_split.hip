@@ -18,6 +18,7 @@
 //   * activations are split in registers right before use (8 floats -> 3 x bf16x8 per K=16 step).
 #include <stdlib.h>
 
+#include <type_traits>
 #include "split_math.h"
 
 namespace mpnn {
@@ -36,7 +37,7 @@ __device__ __forceinline__ int col_swizzle(int col) {
     return H == 64 ? ((col >> 1) & 7) : (col & 15);
 }
 
-template <int H, int NCS, int NW, bool HAS_MASK>
+template <int H, int NCS, int NW, bool HAS_MASK, bool SAVE>
 __global__ void __launch_bounds__(64 * NW) gru_update_split_kernel(
     const float* __restrict__ m, const float* __restrict__ h, const float* __restrict__ mask,
     const float* __restrict__ W_ih, const float* __restrict__ W_hh, const float* __restrict__ b_ih,
@@ -77,29 +78,34 @@ __global__ void __launch_bounds__(64 * NW) gru_update_split_kernel(
     __syncthreads();
 
     const int r = lane & 31, hi = lane >> 5;
-    float br[NCS], bz[NCS], bni[NCS], bnh[NCS];
-#pragma unroll
-    for (int s = 0; s < NCS; ++s) {
-        const int col = c0 + 32 * s + r;
-        br[s] = b_ih[col] + b_hh[col];
-        bz[s] = b_ih[H + col] + b_hh[H + col];
-        bni[s] = b_ih[2 * H + col];
-        bnh[s] = b_hh[2 * H + col];
+    // gate biases of this block's columns live in LDS ([r | z | n_i | n_h][CS]) and are read at the start of every
+    // epilogue: as loop-invariant registers they are the first thing the allocator spills
+    float* bias_lds = reinterpret_cast<float*>(smem + 6 * IMG);
+    for (int idx = tid; idx < CS; idx += 64 * NW) {
+        const int col = c0 + idx;
+        bias_lds[idx] = b_ih[col] + b_hh[col];
+        bias_lds[CS + idx] = b_ih[H + col] + b_hh[H + col];
+        bias_lds[2 * CS + idx] = b_ih[2 * H + col];
+        bias_lds[3 * CS + idx] = b_hh[2 * H + col];
     }
+    __syncthreads();
 
     const int64_t tiles = (V + 31) / 32;
     const int64_t stride = (int64_t)pblocks * NW;
-    int64_t t = (int64_t)pblock * NW + wv;
+    // the wave index is uniform: as a scalar it keeps the tile counter and every row base pointer in SGPRs
+    int64_t t = (int64_t)pblock * NW + __builtin_amdgcn_readfirstlane(wv);
     if (t >= tiles) return;
 
     f32x4 fa[NF4], fb[NF4];
-    auto load_frags = [&](const float* __restrict__ X, int64_t tile, f32x4 (&f)[NF4]) {
-        int64_t row = tile * 32 + r;
-        if (row >= V) row = V - 1;
-        const float* p = X + row * H + hi * (H / 2);
+    auto load_part = [&](const float* __restrict__ X, int64_t tile, f32x4 (&f)[NF4], int q0, int q1) {
+        const int64_t left = V - tile * 32;                      // rows this tile really has (scalar)
+        const int rr = left >= 32 ? r : (r < (int)left ? r : (int)left - 1);
+        const float* p = X + tile * 32 * H;                      // scalar base + 32-bit lane offset
+        const unsigned off = (unsigned)(rr * H + hi * (H / 2));
 #pragma unroll
-        for (int q = 0; q < NF4; ++q) f[q] = *reinterpret_cast<const f32x4*>(p + 4 * q);
+        for (int q = q0; q < q1; ++q) f[q] = *reinterpret_cast<const f32x4*>(p + off + 4 * q);
     };
+    auto load_frags = [&](const float* __restrict__ X, int64_t tile, f32x4 (&f)[NF4]) { load_part(X, tile, f, 0, NF4); };
     // B fragment of (matrix, piece) for weight column `col`, K step `s`
     auto bfrag = [&](int mat, int piece, int col, int s) {
         const int chunk = hi * (NCH / 2) + s;
@@ -116,6 +122,7 @@ __global__ void __launch_bounds__(64 * NW) gru_update_split_kernel(
             for (int i = 0; i < 16; ++i) { acc_r[s][i] = 0.f; acc_z[s][i] = 0.f; acc_ni[s][i] = 0.f; acc_nh[s][i] = 0.f; }
 
         load_frags(h, t, fb);                            // in flight while the m-products run
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int st = 0; st < STEPS; ++st) {
             bf16x8 ah, am, al;
@@ -128,8 +135,8 @@ __global__ void __launch_bounds__(64 * NW) gru_update_split_kernel(
                 mma6(acc_ni[s], ah, am, al, bfrag(0, 0, 2 * CS + cr, st), bfrag(0, 1, 2 * CS + cr, st),
                      bfrag(0, 2, 2 * CS + cr, st));
             }
+            __builtin_amdgcn_sched_barrier(0);           // bounds how far ahead weight fragments are read (registers)
         }
-        if (t + stride < tiles) load_frags(m, t + stride, fa);
 #pragma unroll
         for (int st = 0; st < STEPS; ++st) {
             bf16x8 ah, am, al;
@@ -142,36 +149,75 @@ __global__ void __launch_bounds__(64 * NW) gru_update_split_kernel(
                 mma6(acc_nh[s], ah, am, al, bfrag(1, 0, 2 * CS + cr, st), bfrag(1, 1, 2 * CS + cr, st),
                      bfrag(1, 2, 2 * CS + cr, st));
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // epilogue: 4 groups of 4 consecutive atoms, loads unconditional (row clamped), stores predicated
+        // epilogue.  Every load of the tile (its h values in accumulator layout, one mask value per lane) is requested
+        // before the first store: vmcnt retires in issue order and counts a store until L2 acknowledges it, so a load
+        // issued behind a group of stores would wait for every one of them.  The registers of the h fragments are free
+        // by now.  A full tile addresses everything as one base + compile-time offsets; the last, ragged tile clamps
+        // its loads and predicates its stores.
+        auto epilogue = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            __builtin_amdgcn_sched_barrier(0);                       // keep these loads below the last MFMA phase
+            int zero = 0;
+            asm volatile("" : "+v"(zero));                           // opaque: keeps the bias reads inside the loop
+            float br[NCS], bz[NCS], bni[NCS], bnh[NCS];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float mk4[4], hv4[4][NCS];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int64_t row = t * 32 + 8 * g + 4 * hi + u;
-                if (row >= V) row = V - 1;
-                mk4[u] = HAS_MASK ? mask[row] : 1.0f;
-#pragma unroll
-                for (int s = 0; s < NCS; ++s) hv4[u][s] = h[row * H + c0 + 32 * s + r];
+            for (int s = 0; s < NCS; ++s) {
+                br[s] = bias_lds[zero + 32 * s + r];
+                bz[s] = bias_lds[zero + CS + 32 * s + r];
+                bni[s] = bias_lds[zero + 2 * CS + 32 * s + r];
+                bnh[s] = bias_lds[zero + 3 * CS + 32 * s + r];
             }
+            const int64_t row0 = t * 32 + 4 * hi;                    // + 8*(i>>2) + (i&3)
+            const unsigned eo = (unsigned)(4 * hi * H + c0 + r);
+            const float* hb = h + t * 32 * H + eo;                   // scalar tile base + lane offset; the rest is immediates
+            float hv[16][NCS];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = 4 * g + u;
-                const int64_t row = t * 32 + 8 * g + 4 * hi + u;
-                const float mk = mk4[u];
+            for (int i = 0; i < 16; ++i) {
+                const int dr = 8 * (i >> 2) + (i & 3);
+#pragma unroll
+                for (int s = 0; s < NCS; ++s)
+                    if (FULL) hv[i][s] = hb[dr * H + 32 * s];        // (the ragged tile reads its h values row by row)
+            }
+            float mkl = 1.0f;
+            if (HAS_MASK) {
+                const int left = FULL ? 32 : (int)(V - t * 32);
+                mkl = (mask + t * 32)[(unsigned)(r < left ? r : left - 1)];   // lane j (< 32): mask of the tile's row j
+            }
+            // next tile's m rows: behind the epilogue loads, ahead of the stores (both operand fragments are dead here);
+            // the ragged tile is the last one
+            // (unconditional, tile index clamped: under a condition the old fragments would stay live as the other arm)
+            if (FULL) load_frags(m, t + stride < tiles ? t + stride : t, fa);
+            else {
+#pragma unroll
+                for (int q = 0; q < NF4; ++q) fa[q] = f32x4{0.f, 0.f, 0.f, 0.f};   // last tile: defined, never used
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float* ob = out + t * 32 * H + eo;
+            float* sb = saved + t * 32 * 4 * H + (unsigned)(4 * hi * 4 * H + c0 + r);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int dr = 8 * (i >> 2) + (i & 3);
+                // mask of row 4*hi + dr: two scalar lane reads and a select (a shuffle would keep 16 lane indices live)
+                float mk = 1.0f;
+                if (HAS_MASK) {
+                    const float mk_lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mkl), dr));
+                    const float mk_hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mkl), 4 + dr));
+                    mk = hi ? mk_hi : mk_lo;
+                }
 #pragma unroll
                 for (int s = 0; s < NCS; ++s) {
-                    const int col = c0 + 32 * s + r;
                     const float rg = sigmoid_fast(acc_r[s][i] + br[s]) * mk;
                     const float zg = sigmoid_fast(acc_z[s][i] + bz[s]) * mk;
                     const float nh = acc_nh[s][i] + bnh[s];
                     const float ng = tanh_fast(acc_ni[s][i] + bni[s] + rg * nh) * mk;
-                    const float o = ((1.0f - zg) * ng + zg * hv4[u][s]) * mk;
-                    if (row < V) {
-                        __builtin_nontemporal_store(o, out + row * H + col);
-                        if (saved) {                     // 16*H bytes per atom, read back once by the backward
-                            float* sv = saved + row * 4 * H + col;
+                    const float hval = FULL ? hv[i][s] : (row0 + dr < V ? hb[dr * H + 32 * s] : 0.f);
+                    const float o = ((1.0f - zg) * ng + zg * hval) * mk;
+                    if (FULL || row0 + dr < V) {
+                        __builtin_nontemporal_store(o, ob + dr * H + 32 * s);
+                        if (SAVE) {                                  // 16*H bytes per atom, read back once by the backward
+                            float* sv = sb + dr * 4 * H + 32 * s;
                             __builtin_nontemporal_store(rg, sv);
                             __builtin_nontemporal_store(zg, sv + H);
                             __builtin_nontemporal_store(ng, sv + 2 * H);
@@ -179,8 +225,11 @@ __global__ void __launch_bounds__(64 * NW) gru_update_split_kernel(
                         }
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);                   // row by row: nothing is gained by hoisting gate math
             }
-        }
+        };
+        if (t * 32 + 32 <= V) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
     }
 }
 
@@ -189,13 +238,14 @@ static int launch_split(const float* m, const float* h, const float* mask, const
                         const float* b_ih, const float* b_hh, float* out, float* saved, int64_t V, hipStream_t s) {
     constexpr int CS = 32 * NCS;
     constexpr int slices = H / CS;
-    const size_t lds = (size_t)2 * 3 * (3 * CS) * (2 * H);
+    const size_t lds = (size_t)2 * 3 * (3 * CS) * (2 * H) + 16 * CS;    // weight images + gate biases
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gru_update_split_kernel<H, NCS, NW, true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)gru_update_split_kernel<H, NCS, NW, false>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const int n = (int)lds;
+        (void)hipFuncSetAttribute((const void*)gru_update_split_kernel<H, NCS, NW, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
+        (void)hipFuncSetAttribute((const void*)gru_update_split_kernel<H, NCS, NW, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
+        (void)hipFuncSetAttribute((const void*)gru_update_split_kernel<H, NCS, NW, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
+        (void)hipFuncSetAttribute((const void*)gru_update_split_kernel<H, NCS, NW, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
         attr_done = true;
     }
     const int64_t tiles = (V + 31) / 32;
@@ -203,12 +253,14 @@ static int launch_split(const float* m, const float* h, const float* mask, const
     if (pblocks * NW > tiles) pblocks = (tiles + NW - 1) / NW;
     if (pblocks < 1) pblocks = 1;
     const dim3 grid((unsigned)(pblocks * slices)), block(64 * NW);
-    if (mask)
-        hipLaunchKernelGGL((gru_update_split_kernel<H, NCS, NW, true>), grid, block, lds, s, m, h, mask, W_ih, W_hh, b_ih,
-                           b_hh, out, saved, V, slices);
-    else
-        hipLaunchKernelGGL((gru_update_split_kernel<H, NCS, NW, false>), grid, block, lds, s, m, h, mask, W_ih, W_hh,
-                           b_ih, b_hh, out, saved, V, slices);
+#define MPNN_LAUNCH_SPLIT(MASKED, SAVED)                                                                                   \
+    hipLaunchKernelGGL((gru_update_split_kernel<H, NCS, NW, MASKED, SAVED>), grid, block, lds, s, m, h, mask, W_ih, W_hh,  \
+                       b_ih, b_hh, out, saved, V, slices)
+    if (mask && saved) MPNN_LAUNCH_SPLIT(true, true);
+    else if (mask) MPNN_LAUNCH_SPLIT(true, false);
+    else if (saved) MPNN_LAUNCH_SPLIT(false, true);
+    else MPNN_LAUNCH_SPLIT(false, false);
+#undef MPNN_LAUNCH_SPLIT
     return launch_status("mpnn_gru_update_f32(bf16x6)");
 }
 
