@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(512) gru_bwd_fused_split_kernel(
     const float* __restrict__ dout, const float* __restrict__ m, const float* __restrict__ h,
     const float* __restrict__ mask, const float* __restrict__ W_ih, const float* __restrict__ W_hh,
     const float* __restrict__ saved, float* __restrict__ dm, float* __restrict__ dh, float* dW_ih, float* dW_hh,
-    float* db_ih, float* db_hh, int64_t V, int ablate /* timing experiments only: 1 = no GEMMs, 2 = no tile loads */) {
+    float* db_ih, float* db_hh, int64_t V) {
     static_assert(H == 64, "role split below is laid out for H = 64");
     constexpr int LDG = 5 * H + 4;
     constexpr int LDX = 2 * H;
@@ -263,44 +263,10 @@ __global__ void __launch_bounds__(512) gru_bwd_fused_split_kernel(
     const int mat = (wv >> 1) & 1, iblk = wv & 1;
     const int which = ((wv - 4) >> 1) & 1, nb = (wv - 4) & 1;
 
-    // ONE 144-register set per wave: dW waves use R[0..5] as their six accumulators; dx waves keep the
-    // 36 bf16x8 fragments (3 gates x 4 K-steps x 3 pieces) of their weight slice in it.
-    f32x16 R[9];
-    auto wfrag = [&](int g, int st, int piece) {
-        const int p = (g * 4 + st) * 3 + piece;           // 0..35, four fragments per f32x16
-        const f32x4 v = {R[p >> 2][(p & 3) * 4 + 0], R[p >> 2][(p & 3) * 4 + 1], R[p >> 2][(p & 3) * 4 + 2],
-                         R[p >> 2][(p & 3) * 4 + 3]};
-        return __builtin_bit_cast(bf16x8, v);
-    };
-    if (dw_role) {
-#pragma unroll
-        for (int j = 0; j < 9; ++j)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) R[j][q] = 0.f;
-    } else {
-        const float* Wsrc = (which == 0 ? W_ih : W_hh) + (int64_t)(32 * nb + i) * 3 * H + hi * (H / 2);
-#pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wsrc + g * H + 8 * st);
-                const f32x4 w1 = *reinterpret_cast<const f32x4*>(Wsrc + g * H + 8 * st + 4);
-                bf16x8 ph, pm, pl;
-                split8(w0, w1, ph, pm, pl);
-                const bf16x8 pc[3] = {ph, pm, pl};
-#pragma unroll
-                for (int piece = 0; piece < 3; ++piece) {
-                    const int p = (g * 4 + st) * 3 + piece;
-                    const f32x4 v = __builtin_bit_cast(f32x4, pc[piece]);
-                    R[p >> 2][(p & 3) * 4 + 0] = v.x;
-                    R[p >> 2][(p & 3) * 4 + 1] = v.y;
-                    R[p >> 2][(p & 3) * 4 + 2] = v.z;
-                    R[p >> 2][(p & 3) * 4 + 3] = v.w;
-                }
-            }
-    }
-    float colsum = 0.f;
-
+    // The two roles run SEPARATE tile loops (same number of block barriers in each): inside one shared loop every
+    // register of one role is live through the other role's branch -- 144 weight registers through the dW code, the
+    // 58 staging registers through the dx code -- and the allocator spills; a spill reload is a scratch access, which
+    // shares vmcnt with the tile loads in flight and drains them before the first MFMA.
     struct Staged { f32x4 v_do, vh, vm, v_r, v_z, v_n, v_nh; float mk; bool ok; };
     auto stage_load = [&](int64_t t, int half) {
         Staged q;
@@ -342,31 +308,35 @@ __global__ void __launch_bounds__(512) gru_bwd_fused_split_kernel(
         split8(x0, x1, ph, pm, pl);
     };
 
-    int64_t t = blockIdx.x;
-    int cur = 0;
-    if (t < tiles && dw_role) {
-        const Staged q0 = stage_load(t, 0), q1 = stage_load(t, 1);
-        stage_write(q0, 0, buf, buf + 32 * LDG);
-        stage_write(q1, 1, buf, buf + 32 * LDG);
-    }
-    for (; t < tiles; t += gridDim.x) {
-        __syncthreads();
-        float* G = buf + cur * TILE_F;
-        float* X = G + 32 * LDG;
-        const bool more = t + gridDim.x < tiles;
-        Staged nx0, nx1;
-        if (more && dw_role) {
-            const int64_t tn = ablate == 2 ? (int64_t)blockIdx.x : t + gridDim.x;
-            nx0 = stage_load(tn, 0);
-            nx1 = stage_load(tn, 1);
+    const int64_t t0 = blockIdx.x, tstep = gridDim.x;
+    if (dw_role) {
+        // ---- dW waves: stage the next tile (registers), accumulate six 32x32 blocks of dW_ih | dW_hh ----
+        f32x16 R[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) R[j][q] = 0.f;
+        if (t0 < tiles) {
+            const Staged q0 = stage_load(t0, 0), q1 = stage_load(t0, 1);
+            stage_write(q0, 0, buf, buf + 32 * LDG);
+            stage_write(q1, 1, buf, buf + 32 * LDG);
         }
-        if (ablate == 1 || (ablate == 3 && !dw_role) || (ablate == 4 && dw_role)) {
-        } else if (dw_role) {
-            // wave (mat, jg): BOTH 32-row blocks of X_mat against three of the six 32-column gate blocks, so a step
-            // splits 2 + 3 column fragments (it was 1 + 6 when a wave owned one row block and all six columns)
-            const int noff = mat == 0 ? 2 * H : 3 * H;    // W_ih's n-gate column uses dan, W_hh's uses dnh
-            const int jg = iblk;
-            const int c0 = jg == 0 ? 0 : H + 32, c1 = jg == 0 ? 32 : noff, c2 = jg == 0 ? H : noff + 32;
+        // wave (mat, jg): BOTH 32-row blocks of X_mat against three of the six 32-column gate blocks, so a step
+        // splits 2 + 3 column fragments (it was 1 + 6 when a wave owned one row block and all six columns)
+        const int noff = mat == 0 ? 2 * H : 3 * H;        // W_ih's n-gate column uses dan, W_hh's uses dnh
+        const int jg = iblk;
+        const int c0 = jg == 0 ? 0 : H + 32, c1 = jg == 0 ? 32 : noff, c2 = jg == 0 ? H : noff + 32;
+        int cur = 0;
+        for (int64_t t = t0; t < tiles; t += tstep) {
+            __syncthreads();
+            float* G = buf + cur * TILE_F;
+            float* X = G + 32 * LDG;
+            const bool more = t + tstep < tiles;
+            // Staging is unconditional (past the end the tile index is clamped and the staged tile is never read):
+            // under `if (more)` the compiler sinks the loads into that branch, i.e. behind the MFMAs they should cover
+            const int64_t tn = more ? t + tstep : t;
+            const Staged nx0 = stage_load(tn, 0), nx1 = stage_load(tn, 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 const int row0 = 16 * st + 8 * hi;        // this lane half's 8 rows of the K=16 step
@@ -384,48 +354,14 @@ __global__ void __launch_bounds__(512) gru_bwd_fused_split_kernel(
                 mma6(R[2], a0h, a0m, a0l, bh, bm, bl);
                 mma6(R[5], a1h, a1m, a1l, bh, bm, bl);
             }
-        } else {
-            f32x16 d;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) d[q] = 0.f;
-            const float* ga = G + i * LDG + hi * (H / 2);
-#pragma unroll
-            for (int g = 0; g < 3; ++g) {
-                const int seg = (g == 2 && which == 1) ? 3 : g;
-#pragma unroll
-                for (int st = 0; st < 4; ++st) {
-                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(ga + seg * H + 8 * st);
-                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(ga + seg * H + 8 * st + 4);
-                    bf16x8 ah, am, al;
-                    split8(a0, a1, ah, am, al);
-                    mma6(d, ah, am, al, wfrag(g, st, 0), wfrag(g, st, 1), wfrag(g, st, 2));
-                }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                float* Gn = buf + (cur ^ 1) * TILE_F;
+                stage_write(nx0, 0, Gn, Gn + 32 * LDG);
+                stage_write(nx1, 1, Gn, Gn + 32 * LDG);
             }
-            float* outp = which == 0 ? dm : dh;
-            const int col = 32 * nb + i;
-            if (which == 1) {                             // scalar branch; the 16 LDS reads go out together
-#pragma unroll
-                for (int q = 0; q < 16; ++q) d[q] += G[acc_row(q, lane) * LDG + 4 * H + col];
-            }
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int64_t row = t * 32 + acc_row(q, lane);
-                if (row < V) outp[row * H + col] = d[q];
-            }
-            const int c = tid - 256;
-            float part = 0.f;
-#pragma unroll 8
-            for (int rr = 0; rr < 32; ++rr) part += G[rr * LDG + c];
-            colsum += part;
+            cur ^= 1;
         }
-        if (more && dw_role) {
-            float* Gn = buf + (cur ^ 1) * TILE_F;
-            stage_write(nx0, 0, Gn, Gn + 32 * LDG);
-            stage_write(nx1, 1, Gn, Gn + 32 * LDG);
-        }
-        cur ^= 1;
-    }
-    if (dw_role) {
         float* dW = mat == 0 ? dW_ih : dW_hh;
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -436,7 +372,84 @@ __global__ void __launch_bounds__(512) gru_bwd_fused_split_kernel(
                 atomicAdd(dW + (int64_t)row * 3 * H + col, R[j][q]);
             }
         }
-    } else if (blockIdx.x < tiles) {
+        return;
+    }
+
+    // ---- dx waves: 36 bf16x8 fragments (3 gates x 4 K-steps x 3 pieces) of their weight slice stay in registers ----
+    f32x16 R[9];
+    auto wfrag = [&](int g, int st, int piece) {
+        const int p = (g * 4 + st) * 3 + piece;           // 0..35, four fragments per f32x16
+        const f32x4 v = {R[p >> 2][(p & 3) * 4 + 0], R[p >> 2][(p & 3) * 4 + 1], R[p >> 2][(p & 3) * 4 + 2],
+                         R[p >> 2][(p & 3) * 4 + 3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    {
+        const float* Wsrc = (which == 0 ? W_ih : W_hh) + (int64_t)(32 * nb + i) * 3 * H + hi * (H / 2);
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wsrc + g * H + 8 * st);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(Wsrc + g * H + 8 * st + 4);
+                bf16x8 ph, pm, pl;
+                split8(w0, w1, ph, pm, pl);
+                const bf16x8 pc[3] = {ph, pm, pl};
+#pragma unroll
+                for (int piece = 0; piece < 3; ++piece) {
+                    const int p = (g * 4 + st) * 3 + piece;
+                    const f32x4 v = __builtin_bit_cast(f32x4, pc[piece]);
+                    R[p >> 2][(p & 3) * 4 + 0] = v.x;
+                    R[p >> 2][(p & 3) * 4 + 1] = v.y;
+                    R[p >> 2][(p & 3) * 4 + 2] = v.z;
+                    R[p >> 2][(p & 3) * 4 + 3] = v.w;
+                }
+            }
+    }
+    float colsum = 0.f;
+    float* outp = which == 0 ? dm : dh;
+    const int col = 32 * nb + i;
+    const unsigned lane_off = (unsigned)(4 * hi * H + col);   // acc_row(q, lane) = 4*hi + (q&3) + 8*(q>>2)
+    int cur = 0;
+    for (int64_t t = t0; t < tiles; t += tstep) {
+        __syncthreads();
+        const float* G = buf + cur * TILE_F;
+        f32x16 d;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) d[q] = 0.f;
+        const float* ga = G + i * LDG + hi * (H / 2);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const int seg = (g == 2 && which == 1) ? 3 : g;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(ga + seg * H + 8 * st);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(ga + seg * H + 8 * st + 4);
+                bf16x8 ah, am, al;
+                split8(a0, a1, ah, am, al);
+                mma6(d, ah, am, al, wfrag(g, st, 0), wfrag(g, st, 1), wfrag(g, st, 2));
+            }
+        }
+        if (which == 1) {                                 // scalar branch; the 16 LDS reads go out together
+#pragma unroll
+            for (int q = 0; q < 16; ++q) d[q] += G[acc_row(q, lane) * LDG + 4 * H + col];
+        }
+        float* ob = outp + t * 32 * H + lane_off;         // scalar tile base + lane offset; rows are immediates
+        if (t * 32 + 32 <= V) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) ob[((q & 3) + 8 * (q >> 2)) * H] = d[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (t * 32 + acc_row(q, lane) < V) ob[((q & 3) + 8 * (q >> 2)) * H] = d[q];
+        }
+        const int c = tid - 256;
+        float part = 0.f;
+#pragma unroll 8
+        for (int rr = 0; rr < 32; ++rr) part += G[rr * LDG + c];
+        colsum += part;
+        cur ^= 1;
+    }
+    if (blockIdx.x < tiles) {
         const int c = tid - 256;
         const int seg = c / H, cc = c % H;
         if (seg < 2) {
@@ -664,7 +677,6 @@ int launch_gru_bwd_fused64(const float* dout, const float* m, const float* h, co
     int64_t blocks = 256;                                  // one 8-wave block per CU (116 KB of LDS)
     if (blocks > tiles) blocks = tiles;
     static const bool fp32_only = getenv("MPNN_GRU_MATH") && !strcmp(getenv("MPNN_GRU_MATH"), "fp32");
-    static const int ablate = getenv("MPNN_GRU_BWD_ABLATE") ? atoi(getenv("MPNN_GRU_BWD_ABLATE")) : 0;
     static const bool uniform = getenv("MPNN_GRU_BWD_UNIFORM") != nullptr;  // A/B: all-waves-identical arrangement
     if (!fp32_only && uniform) {
         static bool attr3 = false;
@@ -694,10 +706,10 @@ int launch_gru_bwd_fused64(const float* dout, const float* m, const float* h, co
         }
         if (mask)
             hipLaunchKernelGGL((gru_bwd_fused_split_kernel<H, true>), dim3((unsigned)blocks), dim3(512), lds, s, dout, m,
-                               h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, V, ablate);
+                               h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, V);
         else
             hipLaunchKernelGGL((gru_bwd_fused_split_kernel<H, false>), dim3((unsigned)blocks), dim3(512), lds, s, dout, m,
-                               h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, V, ablate);
+                               h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, V);
         return launch_status("mpnn_gru_update_bwd_f32(fused bf16x6)");
     }
     if (mask)
