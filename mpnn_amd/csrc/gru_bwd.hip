@@ -660,6 +660,10 @@ __global__ void __launch_bounds__(512) gru_bwd_uniform_kernel(
     }
 }
 
+int launch_gru_bwd_presplit64(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
+                              const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
+                              float* db_ih, float* db_hh, int64_t V, hipStream_t s);   // gru_bwd_presplit.hip
+
 int launch_gru_bwd_fused64(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
                            const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
                            float* db_ih, float* db_hh, int64_t V, hipStream_t s) {
@@ -695,6 +699,11 @@ int launch_gru_bwd_fused64(const float* dout, const float* m, const float* h, co
                                mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, V);
         return launch_status("mpnn_gru_update_bwd_f32(uniform)");
     }
+    // default: gate gradients split once at staging (gru_bwd_presplit.hip); MPNN_GRU_BWD_FP32TILE=1 keeps the fp32
+    // tile whose consumers split what they read
+    static const bool fp32_tile = getenv("MPNN_GRU_BWD_FP32TILE") != nullptr;
+    if (!fp32_only && !fp32_tile)
+        return launch_gru_bwd_presplit64(dout, m, h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, V, s);
     if (!fp32_only) {
         static bool attr2 = false;
         if (!attr2) {
