@@ -17,7 +17,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmpnn_amd.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
-         "-fno-fast-math"]
+         "-fno-fast-math"] + os.environ.get("MPNN_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def sources():
