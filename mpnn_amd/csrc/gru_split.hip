@@ -590,7 +590,7 @@ __global__ void __launch_bounds__(512) gru_update_stream_kernel(
     }
 }
 
-template <int H, bool HAS_MASK>
+template <int H, bool HAS_MASK, bool SAVE>
 __global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
     const float* __restrict__ m, const float* __restrict__ h, const float* __restrict__ mask,
     const float* __restrict__ W_ih, const float* __restrict__ W_hh, const float* __restrict__ b_ih,
@@ -717,45 +717,66 @@ __global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
             half(hc, tile_next, a0, a1);
             half(hc + 1, tile_next, a1, a0);
         }
+        // epilogue: every load of the tile (h values in accumulator layout, one mask value per lane) goes out before
+        // the first store -- vmcnt retires in order and counts a store until L2 acknowledges it, so a load issued
+        // behind stores waits for all of them.  A full tile is one scalar base + lane offset + immediates; the last,
+        // ragged tile reads row by row and predicates its stores.
+        auto epilogue = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            const int64_t row0 = tile * 32 + 4 * hi;                   // + 8*(i>>2) + (i&3)
+            const unsigned eo = (unsigned)(4 * hi * H + 64 * slice + r);
+            const float* hb = h + tile * 32 * H + eo;
+            float hv[2][16];
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            const int fcol = 64 * slice + 32 * nb + r;         // this lane's output feature
-            const float br = b_ih[fcol] + b_hh[fcol], bz = b_ih[H + fcol] + b_hh[H + fcol];
-            const float bni = b_ih[2 * H + fcol], bnh = b_hh[2 * H + fcol];
+            for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float mk4[4], hv4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int64_t row = tile * 32 + 8 * g + 4 * hi + u;
-                if (row >= V) row = V - 1;
-                mk4[u] = HAS_MASK ? mask[row] : 1.0f;
-                hv4[u] = h[row * H + fcol];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = 4 * g + u;
-                const int64_t row = tile * 32 + 8 * g + 4 * hi + u;
-                const float mk = mk4[u];
-                const float rg = sigmoid_fast(acc_r[nb][i] + br) * mk;
-                const float zg = sigmoid_fast(acc_z[nb][i] + bz) * mk;
-                const float nh = acc_nh[nb][i] + bnh;
-                const float ng = tanh_fast(acc_ni[nb][i] + bni + rg * nh) * mk;
-                const float o = ((1.0f - zg) * ng + zg * hv4[u]) * mk;
-                if (row < V) {
-                    __builtin_nontemporal_store(o, out + row * H + fcol);
-                    if (saved) {
-                        float* sv = saved + row * 4 * H + fcol;
-                        __builtin_nontemporal_store(rg, sv);
-                        __builtin_nontemporal_store(zg, sv + H);
-                        __builtin_nontemporal_store(ng, sv + 2 * H);
-                        __builtin_nontemporal_store(nh, sv + 3 * H);
-                    }
-                }
+                for (int i = 0; i < 16; ++i)
+                    if (FULL) hv[nb][i] = hb[(8 * (i >> 2) + (i & 3)) * H + 32 * nb];
+            float mkl = 1.0f;
+            if (HAS_MASK) {
+                const int left = FULL ? 32 : (int)(V - tile * 32);
+                mkl = (mask + tile * 32)[(unsigned)(r < left ? r : left - 1)];   // lane j (< 32): mask of the tile's row j
             }
             __builtin_amdgcn_sched_barrier(0);
-        }
-        }
+            float* ob = out + tile * 32 * H + eo;
+            float* sb = saved + tile * 32 * 4 * H + (unsigned)(4 * hi * 4 * H + 64 * slice + r);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const int fcol = 64 * slice + 32 * nb + r;             // this lane's output feature
+                const float br = b_ih[fcol] + b_hh[fcol], bz = b_ih[H + fcol] + b_hh[H + fcol];
+                const float bni = b_ih[2 * H + fcol], bnh = b_hh[2 * H + fcol];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int dr = 8 * (i >> 2) + (i & 3);
+                    float mk = 1.0f;
+                    if (HAS_MASK) {
+                        const float mk_lo = readlane_f(mkl, dr), mk_hi = readlane_f(mkl, 4 + dr);
+                        mk = hi ? mk_hi : mk_lo;
+                    }
+                    const float rg = sigmoid_fast(acc_r[nb][i] + br) * mk;
+                    const float zg = sigmoid_fast(acc_z[nb][i] + bz) * mk;
+                    const float nh = acc_nh[nb][i] + bnh;
+                    const float ng = tanh_fast(acc_ni[nb][i] + bni + rg * nh) * mk;
+                    const float hval = FULL ? hv[nb][i] : (row0 + dr < V ? hb[dr * H + 32 * nb] : 0.f);
+                    const float o = ((1.0f - zg) * ng + zg * hval) * mk;
+                    if (FULL || row0 + dr < V) {
+                        __builtin_nontemporal_store(o, ob + dr * H + 32 * nb);
+                        if (SAVE) {
+                            float* sv = sb + dr * 4 * H + 32 * nb;
+                            __builtin_nontemporal_store(rg, sv);
+                            __builtin_nontemporal_store(zg, sv + H);
+                            __builtin_nontemporal_store(ng, sv + 2 * H);
+                            __builtin_nontemporal_store(nh, sv + 3 * H);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        // (in the last round a wave's whole tile can lie past V: nothing to do then)
+        if (tile * 32 + 32 <= V) epilogue(std::true_type{});
+        else if (tile * 32 < V) epilogue(std::false_type{});
         tile = tile_next;
     }
 }
@@ -794,10 +815,11 @@ static int launch_stream_wide(const float* m, const float* h, const float* mask,
     const size_t lds = (size_t)2 * 6 * 192 * 64;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gru_update_stream_wide_kernel<H, true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)gru_update_stream_wide_kernel<H, false>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const int n = (int)lds;
+        (void)hipFuncSetAttribute((const void*)gru_update_stream_wide_kernel<H, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
+        (void)hipFuncSetAttribute((const void*)gru_update_stream_wide_kernel<H, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
+        (void)hipFuncSetAttribute((const void*)gru_update_stream_wide_kernel<H, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
+        (void)hipFuncSetAttribute((const void*)gru_update_stream_wide_kernel<H, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
         attr_done = true;
     }
     const int64_t rounds = (V + 255) / 256;
@@ -805,12 +827,14 @@ static int launch_stream_wide(const float* m, const float* h, const float* mask,
     if (pblocks > rounds) pblocks = rounds;
     pblocks = (pblocks + 7) / 8 * 8;                        // XCD-aware numbering wants groups of 8 row blocks
     const dim3 grid((unsigned)(pblocks * NS)), block(512);
-    if (mask)
-        hipLaunchKernelGGL((gru_update_stream_wide_kernel<H, true>), grid, block, lds, s, m, h, mask, W_ih, W_hh, b_ih, b_hh,
-                           out, saved, V);
-    else
-        hipLaunchKernelGGL((gru_update_stream_wide_kernel<H, false>), grid, block, lds, s, m, h, mask, W_ih, W_hh, b_ih, b_hh,
-                           out, saved, V);
+#define MPNN_LAUNCH_WIDE(MASKED, SAVED)                                                                                  \
+    hipLaunchKernelGGL((gru_update_stream_wide_kernel<H, MASKED, SAVED>), grid, block, lds, s, m, h, mask, W_ih, W_hh, \
+                       b_ih, b_hh, out, saved, V)
+    if (mask && saved) MPNN_LAUNCH_WIDE(true, true);
+    else if (mask) MPNN_LAUNCH_WIDE(true, false);
+    else if (saved) MPNN_LAUNCH_WIDE(false, true);
+    else MPNN_LAUNCH_WIDE(false, false);
+#undef MPNN_LAUNCH_WIDE
     return launch_status("mpnn_gru_update_f32(bf16x6, streamed weights, wide tile)");
 }
 
