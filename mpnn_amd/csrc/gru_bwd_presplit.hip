@@ -193,8 +193,7 @@ __global__ void __launch_bounds__(512) gru_bwd_presplit64_kernel(
                     const bf16x8 bh = ps_tr8(c0, c1);
                     const bf16x8 bm = ps_tr8(c0 + 2 * PS_IMG, c1 + 2 * PS_IMG);
                     const bf16x8 bl = ps_tr8(c0 + 4 * PS_IMG, c1 + 4 * PS_IMG);
-                    mma6(R[b], a0h, a0m, a0l, bh, bm, bl);
-                    mma6(R[3 + b], a1h, a1m, a1l, bh, bm, bl);
+                    mma6x2_b(R[b], R[3 + b], a0h, a0m, a0l, a1h, a1m, a1l, bh, bm, bl);   // independent neighbours
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -288,19 +287,27 @@ __global__ void __launch_bounds__(512) gru_bwd_presplit64_kernel(
     for (int64_t t = t0; t < tiles; t += tstep) {
         __syncthreads();
         const char* T = smem + cur * PS_TILE;
-        f32x16 d;
+        // two accumulators (even / odd K steps) issued alternately: a single one is a chain of 72 dependent MFMAs
+        f32x16 d, d1;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) d[q] = 0.f;
+        for (int q = 0; q < 16; ++q) { d[q] = 0.f; d1[q] = 0.f; }
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
-            for (int st = 0; st < 4; ++st) {
+            for (int st = 0; st < 4; st += 2) {
                 const char* a = T + DA[g][st];
+                const char* b = T + DA[g][st + 1];
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(a);
                 const bf16x8 am = *reinterpret_cast<const bf16x8*>(a + 2 * PS_IMG);
                 const bf16x8 al = *reinterpret_cast<const bf16x8*>(a + 4 * PS_IMG);
-                mma6(d, ah, am, al, wfrag(g, st, 0), wfrag(g, st, 1), wfrag(g, st, 2));
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(b);
+                const bf16x8 bm = *reinterpret_cast<const bf16x8*>(b + 2 * PS_IMG);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(b + 4 * PS_IMG);
+                mma6x2(d, ah, am, al, wfrag(g, st, 0), wfrag(g, st, 1), wfrag(g, st, 2), d1, bh, bm, bl,
+                       wfrag(g, st + 1, 0), wfrag(g, st + 1, 1), wfrag(g, st + 1, 2));
             }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) d[q] += d1[q];
         if (which == 1) {                                 // scalar branch; the 16 LDS reads go out together
             const float* GZ = reinterpret_cast<const float*>(T + PS_P);
 #pragma unroll

@@ -127,6 +127,15 @@ __global__ void __launch_bounds__(64 * NW) gru_update_split_kernel(
         for (int st = 0; st < STEPS; ++st) {
             bf16x8 ah, am, al;
             split8(fa[2 * st], fa[2 * st + 1], ah, am, al);
+            if (NCS == 2) {
+                // the two slices of a gate are independent accumulators: issued alternately (split_math.h)
+                auto pair = [&](f32x16 (&acc)[NCS], int g) {
+                    const int c0_ = g * CS + r, c1_ = g * CS + 32 + r;
+                    mma6x2_a(acc[0], acc[NCS - 1], ah, am, al, bfrag(0, 0, c0_, st), bfrag(0, 1, c0_, st), bfrag(0, 2, c0_, st),
+                             bfrag(0, 0, c1_, st), bfrag(0, 1, c1_, st), bfrag(0, 2, c1_, st));
+                };
+                pair(acc_r, 0); pair(acc_z, 1); pair(acc_ni, 2);
+            } else {
 #pragma unroll
             for (int s = 0; s < NCS; ++s) {
                 const int cr = 32 * s + r;
@@ -135,12 +144,21 @@ __global__ void __launch_bounds__(64 * NW) gru_update_split_kernel(
                 mma6(acc_ni[s], ah, am, al, bfrag(0, 0, 2 * CS + cr, st), bfrag(0, 1, 2 * CS + cr, st),
                      bfrag(0, 2, 2 * CS + cr, st));
             }
+            }
             __builtin_amdgcn_sched_barrier(0);           // bounds how far ahead weight fragments are read (registers)
         }
 #pragma unroll
         for (int st = 0; st < STEPS; ++st) {
             bf16x8 ah, am, al;
             split8(fb[2 * st], fb[2 * st + 1], ah, am, al);
+            if (NCS == 2) {
+                auto pair = [&](f32x16 (&acc)[NCS], int g) {
+                    const int c0_ = g * CS + r, c1_ = g * CS + 32 + r;
+                    mma6x2_a(acc[0], acc[NCS - 1], ah, am, al, bfrag(1, 0, c0_, st), bfrag(1, 1, c0_, st), bfrag(1, 2, c0_, st),
+                             bfrag(1, 0, c1_, st), bfrag(1, 1, c1_, st), bfrag(1, 2, c1_, st));
+                };
+                pair(acc_r, 0); pair(acc_z, 1); pair(acc_nh, 2);
+            } else {
 #pragma unroll
             for (int s = 0; s < NCS; ++s) {
                 const int cr = 32 * s + r;
@@ -148,6 +166,7 @@ __global__ void __launch_bounds__(64 * NW) gru_update_split_kernel(
                 mma6(acc_z[s], ah, am, al, bfrag(1, 0, CS + cr, st), bfrag(1, 1, CS + cr, st), bfrag(1, 2, CS + cr, st));
                 mma6(acc_nh[s], ah, am, al, bfrag(1, 0, 2 * CS + cr, st), bfrag(1, 1, 2 * CS + cr, st),
                      bfrag(1, 2, 2 * CS + cr, st));
+            }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -684,11 +703,11 @@ __global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
                 __builtin_amdgcn_sched_barrier(0);
                 split8(x[2 * st], x[2 * st + 1], a_h, a_m, a_l);
             }
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                f32x16& acc = gate == 0 ? acc_r[nb] : gate == 1 ? acc_z[nb] : (mat == 0 ? acc_ni[nb] : acc_nh[nb]);
-                mma6(acc, a_h, a_m, a_l, bfrag(cur, mat, 0, gate, nb, st), bfrag(cur, mat, 1, gate, nb, st),
-                     bfrag(cur, mat, 2, gate, nb, st));
+            {   // the two column blocks are independent accumulators: issued alternately (split_math.h)
+                f32x16(&acc)[2] = gate == 0 ? acc_r : gate == 1 ? acc_z : (mat == 0 ? acc_ni : acc_nh);
+                mma6x2_a(acc[0], acc[1], a_h, a_m, a_l, bfrag(cur, mat, 0, gate, 0, st), bfrag(cur, mat, 1, gate, 0, st),
+                         bfrag(cur, mat, 2, gate, 0, st), bfrag(cur, mat, 0, gate, 1, st), bfrag(cur, mat, 1, gate, 1, st),
+                         bfrag(cur, mat, 2, gate, 1, st));
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (i % 3 == 2) {

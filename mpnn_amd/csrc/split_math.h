@@ -42,4 +42,61 @@ __device__ __forceinline__ void mma6(f32x16& acc, const bf16x8& ah, const bf16x8
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
 }
 
+// Two independent accumulators, issued alternately.  On gfx950 an MFMA that accumulates into the result of the
+// previous one costs ~45 cycles even with two waves per SIMD interleaving their chains; with an independent MFMA in
+// between the pipe runs at its 32 (tools/microbench/mfma_valu_overlap.hip: 7.6 vs 5.4 ms for the same MFMA count).
+// mma6x2_a: both products share the A pieces (two column blocks); mma6x2_b: both share the B pieces (two row blocks).
+__device__ __forceinline__ void mma6x2_a(f32x16& c0, f32x16& c1, const bf16x8& ah, const bf16x8& am, const bf16x8& al,
+                                         const bf16x8& b0h, const bf16x8& b0m, const bf16x8& b0l, const bf16x8& b1h,
+                                         const bf16x8& b1m, const bf16x8& b1l) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b0m, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b1m, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b0h, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b1h, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0l, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1l, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b0h, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b1h, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0m, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1m, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0h, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1h, c1, 0, 0, 0);
+}
+
+__device__ __forceinline__ void mma6x2_b(f32x16& c0, f32x16& c1, const bf16x8& a0h, const bf16x8& a0m, const bf16x8& a0l,
+                                         const bf16x8& a1h, const bf16x8& a1m, const bf16x8& a1l, const bf16x8& bh,
+                                         const bf16x8& bm, const bf16x8& bl) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0m, bm, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1m, bm, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, bh, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, bh, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, bl, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, bl, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0m, bh, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1m, bh, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, bm, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, bm, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, bh, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, bh, c1, 0, 0, 0);
+}
+
+// general form: two unrelated products
+__device__ __forceinline__ void mma6x2(f32x16& c0, const bf16x8& a0h, const bf16x8& a0m, const bf16x8& a0l,
+                                       const bf16x8& b0h, const bf16x8& b0m, const bf16x8& b0l, f32x16& c1,
+                                       const bf16x8& a1h, const bf16x8& a1m, const bf16x8& a1l, const bf16x8& b1h,
+                                       const bf16x8& b1m, const bf16x8& b1l) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0m, b0m, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1m, b1m, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b0h, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b1h, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0l, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1l, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0m, b0h, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1m, b1h, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0m, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1m, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0h, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1h, c1, 0, 0, 0);
+}
+
 }  // namespace mpnn
