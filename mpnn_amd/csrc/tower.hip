@@ -73,6 +73,7 @@ __global__ void __launch_bounds__(1024) tower_chain_kernel(const float* __restri
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < kTowerRows; ++r) {
+            if (r >= nr) break;                           // block-uniform: K+1 = 5 real rows of the 8 (nobody reads the rest)
             const float* xr = &xs[cur][r][q * kTowerQ];
             float acc = 0.f;
 #pragma unroll
