@@ -5,7 +5,8 @@
 // features de-duplicated the tower runs on R = K+1 rows (R ~ 5), so each layer is a 5 x 256 x 256
 // product: as separate library GEMM + ReLU launches that is ~100 launches of ~9 us of pure latency per
 // pass.  Here the shared matrix is loaded ONCE into registers -- 1024 threads x 64 weights = the whole
-// 256 x 256 matrix -- and the chain runs inside one block per 8 rows with two barriers per layer.
+// 256 x 256 matrix -- and the chain runs inside one block per row (per 8 rows when there are many) with two barriers
+// per layer.
 //
 //   forward   acts[0] = x ;  acts[l+1] = relu(acts[l] W^T)                 (all activations kept: backward)
 //   backward  g_n = dout ;   dy_l = g_{l+1} * (acts[l+1] > 0) ;  g_l = dy_l W     (dys kept)
@@ -19,13 +20,14 @@
 
 namespace mpnn {
 
-constexpr int kTowerRows = 8;       // rows per block
 constexpr int kTowerQ = 68;         // padded quarter stride (floats)
 constexpr int kTowerLd = 4 * kTowerQ;
 
 __device__ __forceinline__ int tower_slot(int i) { return (i >> 6) * kTowerQ + (i & 63); }
 
-template <bool BWD>
+// kTowerRows rows per block: 8 when there are many rows (continuous bond features), 1 for the usual handful of distinct
+// bond types -- the rows are independent chains, so K+1 = 5 blocks on 5 CUs finish in a fifth of the time of one block
+template <bool BWD, int kTowerRows>
 __global__ void __launch_bounds__(1024) tower_chain_kernel(const float* __restrict__ xin,   // fwd: x [R,L]; bwd: dout [R,L]
                                                            const float* __restrict__ W,     // [L,L] (out, in)
                                                            float* __restrict__ acts,        // [(n+1),R,L] (fwd: written; bwd: read)
@@ -113,9 +115,12 @@ extern "C" int mpnn_tower_chain_f32(const float* x, const float* W, float* acts,
     MPNN_REQUIRE(L > 0 && L <= 256, "mpnn_tower_chain_f32: width L=%d unsupported (1..256)", L);
     if (R == 0) return MPNN_OK;
     MPNN_REQUIRE(x && W && acts, "mpnn_tower_chain_f32: NULL buffer");
-    const int blocks = (R + kTowerRows - 1) / kTowerRows;
-    hipLaunchKernelGGL((tower_chain_kernel<false>), dim3(blocks), dim3(1024), 0, (hipStream_t)stream, x, W, acts,
-                       (float*)nullptr, (float*)nullptr, R, L, n_layers);
+    if (R <= 64)
+        hipLaunchKernelGGL((tower_chain_kernel<false, 1>), dim3(R), dim3(1024), 0, (hipStream_t)stream, x, W, acts,
+                           (float*)nullptr, (float*)nullptr, R, L, n_layers);
+    else
+        hipLaunchKernelGGL((tower_chain_kernel<false, 8>), dim3((R + 7) / 8), dim3(1024), 0, (hipStream_t)stream, x, W,
+                           acts, (float*)nullptr, (float*)nullptr, R, L, n_layers);
     return launch_status("mpnn_tower_chain_f32");
 }
 
@@ -125,8 +130,11 @@ extern "C" int mpnn_tower_chain_bwd_f32(const float* dout, const float* W, const
     MPNN_REQUIRE(L > 0 && L <= 256, "mpnn_tower_chain_bwd_f32: width L=%d unsupported (1..256)", L);
     if (R == 0) return MPNN_OK;
     MPNN_REQUIRE(dout && W && acts && dys && dx, "mpnn_tower_chain_bwd_f32: NULL buffer");
-    const int blocks = (R + kTowerRows - 1) / kTowerRows;
-    hipLaunchKernelGGL((tower_chain_kernel<true>), dim3(blocks), dim3(1024), 0, (hipStream_t)stream, dout, W,
-                       const_cast<float*>(acts), dys, dx, R, L, n_layers);
+    if (R <= 64)
+        hipLaunchKernelGGL((tower_chain_kernel<true, 1>), dim3(R), dim3(1024), 0, (hipStream_t)stream, dout, W,
+                           const_cast<float*>(acts), dys, dx, R, L, n_layers);
+    else
+        hipLaunchKernelGGL((tower_chain_kernel<true, 8>), dim3((R + 7) / 8), dim3(1024), 0, (hipStream_t)stream, dout, W,
+                           const_cast<float*>(acts), dys, dx, R, L, n_layers);
     return launch_status("mpnn_tower_chain_bwd_f32");
 }
