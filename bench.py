@@ -1,24 +1,34 @@
 #!/usr/bin/env python3
 """Benchmark of the message-passing hot path (message + aggregate + update) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5] [--mode fwd|train]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5] [--mode fwd|train]
+                    [--scaling weak|strong]
 
-One process per GPU (N>1: launched by torch.distributed.run, RCCL backend).  A "step" is one pass
-of the hot path over one resident batch: T message-passing rounds of
-EdgeNetwork message -> AdjMsgAgg -> GRUUpdate through models.basic_model.BasicModel
-plus, in the default `--mode train`, the backward pass and the ONE RCCL all-reduce of the flat gradient
-bucket (the data-parallel step BASELINE.json's multi-GPU config describes); the forward-only rate of the
-same batch is measured in the same run and reported under "forward".  Inputs are resident
-in HBM before the timed region.  Molecules shard by graph: every rank holds its own 100k-molecule
-batch (weak scaling), no data-path collective.
+One process per GPU.  With --gpus N > 1 and no launcher environment (WORLD_SIZE unset) this script starts its own N
+ranks -- `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process, before anything here
+touches the GPU -- and relays the child's single JSON line; under the driver's launcher it is one of the ranks.
 
-Prints ONE JSON line (rank 0) with the whole-job edges/s, the aggregator's live-measured roofline
-figures and, at N=1, the CPU baseline (the oracle's dense restatement of the reference path) timed
-on this host's cores on a bounded sample of the same workload.
+A "step" is one pass of the hot path over the rank's resident molecules: T message-passing rounds of
+EdgeNetwork message -> AdjMsgAgg -> GRUUpdate through models.basic_model.BasicModel plus, in the default
+`--mode train`, the backward pass and the ONE RCCL all-reduce of the flat gradient bucket (the data-parallel step
+BASELINE.json's multi-GPU config describes); the forward-only rate of the same batch is measured in the same run and
+reported under "forward".  Inputs are resident in HBM before the timed region.  Molecules shard by graph, no
+data-path collective:
+
+  --scaling weak   (default) every rank holds its own batch of the workload's size (c2: 100k molecules per GPU);
+  --scaling strong ONE global set of 8 x <workload size> molecules (c4: 8 x 125k = 1 M, BASELINE configs[3]) partitioned
+                   over the ranks with parallel.shard_by_edges; a rank walks its share in micro-batches of at most the
+                   workload's size, accumulating gradients, then all-reduces once.
+
+Prints ONE JSON line (rank 0) with the whole-job edges/s, the aggregator's live-measured roofline figures and, at
+N=1, the CPU baseline (the oracle's dense restatement of the reference path) timed on this host's cores on a bounded
+sample of the same workload.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -40,8 +50,10 @@ WORKLOADS = {
                                  "one batch of the whole set per step, and the reference's batches of 16 beside it"),
     "tiny": (2_000, 64, 3, "drug", "2k mols (plumbing check)"),
 }
+STRONG_CHUNKS = 8           # --scaling strong: the global set is 8 chunks of the workload's size
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
-MFMA_F32_PEAK_TF = 157.3    # dense fp32 MFMA peak (MI355X_MICROARCH.md); the 1e-5 bar rules out plain bf16/xf32
+MFMA_F32_PEAK_TF = 157.3    # dense fp32 MFMA peak (MI355X_MICROARCH.md)
+MFMA_16BIT_PEAK_TF = 2500.0  # dense bf16 / fp16 MFMA peak (MI355X_MICROARCH.md)
 
 
 def parse():
@@ -53,25 +65,61 @@ def parse():
                     help="c2 = BASELINE.json configs[1] (the headline); c3/c4/c5 = configs[2..4] shapes")
     ap.add_argument("--mode", default="train", choices=["fwd", "train"],
                     help="train (default) = forward + backward + gradient all-reduce; fwd = inference pass only")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="strong = one global set of %d x the workload's molecules sharded over the ranks" % STRONG_CHUNKS)
+    ap.add_argument("--cpu-seconds", type=float, default=24.0, help="budget of the CPU baseline leg (2/3 training, 1/3 forward)")
     ap.add_argument("--no-cpu", action="store_true")
     return ap.parse_args()
 
 
-def pmc_traffic(workload):
-    """Per-launch HBM bytes of the aggregator from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
-    WRITE_SIZE in separate runs of this same command, corrected as MI355X_MICROARCH.md prescribes; see
-    tools/pmc_summary.py).  PMC collection needs the profiler, so it cannot happen inside this process; the
-    figure is a property of (kernel, workload) and is reported with its source, or None when no pass exists."""
-    path = os.path.join(REPO, "profiles", "r01_pmc_%s.json" % workload)
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        for k, v in d["kernels"].items():
-            if "segsum" in k and "bwd" not in k:
-                return v["hbm_bytes"], "profiles/" + os.path.basename(path)
-    except (OSError, ValueError, KeyError):
-        pass
+# ------------------------------------------------------------------------------------------------ self-launch
+def self_launch(args):
+    """--gpus N > 1 without a launcher: start N ranks as a child torch.distributed.run and relay its JSON line.
+    Nothing in this parent has touched the GPU (torch.cuda.device_count() does not initialise it on this image), and
+    the child is a child process, never an exec.  With fewer GPUs than ranks the ranks share devices over gloo
+    (a rehearsal of the N-rank code path, flagged in the JSON; its rate is not a scaling number)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if torch.cuda.device_count() < args.gpus and "MPNN_DIST_BACKEND" not in env:
+        env["MPNN_DIST_BACKEND"] = "gloo"
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    for ln in lines[-1:]:
+        print(ln, flush=True)
+    if r.returncode != 0 or not lines:
+        sys.stderr.write(r.stdout[-4000:])
+        sys.exit(r.returncode or 1)
+    sys.exit(0)
+
+
+# ------------------------------------------------------------------------------------------------ measurement helpers
+def pmc_traffic(workload, kernel_substr):
+    """Per-launch HBM bytes of one kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in
+    separate runs of this same command, corrected as MI355X_MICROARCH.md prescribes; tools/measure_all.sh +
+    tools/pmc_summary.py are the only writers).  PMC collection needs the profiler, so it cannot happen inside this
+    process; the figure is a property of (kernel, workload) and is reported with its source file, that file's hash and
+    the commit it was measured at, so a stale figure is visible.  (None, None) when no pass exists."""
+    for rnd in ("r02", "r01"):
+        path = os.path.join(REPO, "profiles", "%s_pmc_%s.json" % (rnd, workload))
+        try:
+            with open(path, "rb") as f:
+                raw = f.read()
+            d = json.loads(raw)
+            for k, v in d["kernels"].items():
+                if kernel_substr in k and "bwd" not in k:
+                    return v["hbm_bytes"], {"file": "profiles/" + os.path.basename(path),
+                                            "sha256_16": hashlib.sha256(raw).hexdigest()[:16],
+                                            "measured_at_commit": d.get("commit"), "kernel": k}
+        except (OSError, ValueError, KeyError):
+            continue
     return None, None
 
 
@@ -100,7 +148,7 @@ def usable_cores():
     return min(n, int(os.environ.get("MPNN_CPU_THREADS", "16")))   # the GPU box's CPU share per GPU is 16
 
 
-def cpu_baseline(mb, hidden, steps, mode, budget_s):
+def cpu_baseline_leg(mb, hidden, steps, mode, budget_s, first_batch=0):
     """The oracle's dense padded CPU path (== the reference's op sequence, validated against the
     reference's own outputs in tests/test_oracle_golden.py), batches of 16 molecules (the
     reference's batch size, test_lipo.py:150), all host cores, until `budget_s` is spent."""
@@ -116,6 +164,7 @@ def cpu_baseline(mb, hidden, steps, mode, budget_s):
     mfp, ufp = O.sub(params, "mf."), O.sub(params, "uf.")
     edges = 0
     nb = 0
+    nmol = 0
     # the dense path holds a (B, N, N, mf, nf) tensor (plus its gradient and the pair messages when training):
     # keep one batch under ~16 GB by dropping the largest molecules of a batch (C5: 200 atoms at H = 256 is 10.5 GB
     # per molecule), and say so in `sample`
@@ -123,7 +172,7 @@ def cpu_baseline(mb, hidden, steps, mode, budget_s):
     n_atoms = np.asarray(mb.n_atoms, dtype=np.int64)
     dropped = 0
     t0 = time.perf_counter()
-    for b0 in range(0, mb.num_mols - 16, 16):
+    for b0 in range(first_batch * 16, mb.num_mols - 16, 16):
         ids = np.arange(b0, b0 + 16)
         ids = ids[np.argsort(n_atoms[ids], kind="stable")]
         while len(ids) and len(ids) * float(n_atoms[ids].max()) ** 2 * hidden * hidden * 4 > budget_bytes:
@@ -147,13 +196,27 @@ def cpu_baseline(mb, hidden, steps, mode, budget_s):
                 h.sum().backward()
         edges += int(adj.sum().item()) * steps
         nb += 1
+        nmol += len(ids)
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    return {"value": edges / dt, "unit": "edges/s", "cores": cores, "kind": "port",
-            "sample": "%d batches of 16 molecules of the same synthetic set%s, dense padded torch-CPU path, "
-                      "%s, %.1f s" % (nb, " (%d molecules too large for the dense path left out)" % dropped if dropped else "",
-                                      "forward+backward" if mode == "train" else "forward", dt)}
+    return {"value": edges / dt, "unit": "edges/s", "cores": cores, "kind": "port", "sample_molecules": nmol,
+            "sample_seconds": dt,
+            "sample": "%d molecules (%d batches of 16, the reference's batch size) of the same synthetic set%s, dense "
+                      "padded torch-CPU path, %s, %.1f s -- a time-budgeted sample (SURVEY 8d's 2k-molecule subsample "
+                      "would take minutes of CPU)"
+                      % (nmol, nb, " (%d molecules too large for the dense path left out)" % dropped if dropped else "",
+                         "forward+backward" if mode == "train" else "forward", dt)}
+
+
+def cpu_baseline(mb, hidden, steps, mode, budget_s):
+    """Both legs in one record: the headline field follows `mode`; the other leg rides along under "forward"/"train"."""
+    fwd = cpu_baseline_leg(mb, hidden, steps, "fwd", budget_s / 3.0 if mode == "train" else budget_s)
+    if mode != "train":
+        return fwd
+    out = cpu_baseline_leg(mb, hidden, steps, "train", budget_s * 2.0 / 3.0)
+    out["forward"] = {k: fwd[k] for k in ("value", "unit", "sample_molecules", "sample_seconds")}
+    return out
 
 
 def stream_calibration(dev, nbytes):
@@ -175,17 +238,46 @@ def stream_calibration(dev, nbytes):
     return {"op": "torch.add, 2 reads : 1 write, same bytes", "GB/s": 12.0 * n / (ms * 1e-3) / 1e9, "ms": ms}
 
 
+def segsum_calibration(ops, graph, F, dev):
+    """The standalone segmented-sum aggregator (mpnn_segsum_f32: AdjMsgAgg on materialised message rows, the kernel the
+    weighted / attention aggregators run) on this batch, outside the timed region: BASELINE's 'aggregator' line."""
+    E, V = graph.num_edges, graph.num_nodes
+    msg = torch.empty(E, F, device=dev).normal_()
+    for _ in range(3):
+        ops.segsum_raw(msg, graph.row_ptr, None, V, label="calib")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        ops.segsum_raw(msg, graph.row_ptr, None, V, label="calib")
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    alg = 4.0 * F * (E + V) + 4.0 * (V + 1)
+    return {"kernel": "segsum_pair_kernel (mpnn_segsum_f32 on materialised (E, mf) message rows)", "bound": "hbm",
+            "algorithmic_bytes_per_launch": alg, "formula": "4*mf*(E+V) + 4*(V+1)", "avg_launch_ms": ms,
+            "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "timed": "10 launches after 3 warm-ups, outside the timed steps"}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                                   # never returns
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d; launch one rank per GPU (or run without a launcher: "
+                 "bench.py starts its own ranks)" % (args.gpus, world))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the hot path has no CPU fallback)")
-    local = local % max(torch.cuda.device_count(), 1)
+    ndev = max(torch.cuda.device_count(), 1)
+    rehearsal = world > ndev
+    local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
         backend = os.environ.get("MPNN_DIST_BACKEND", "nccl")      # "gloo": rehearsal with ranks sharing one GPU
@@ -193,19 +285,34 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
-    from mpnn_amd import ops, synth
+    from mpnn_amd import ops, parallel, synth
     from mpnn_amd.graph import MolGraph
     from mpnn_amd.models.basic_model import BasicModel
 
     mols, hidden, T, dist_name, desc = WORKLOADS[args.workload]
-    mb = synth.make_molecules(mols, hidden, seed=317 + rank, dist=dist_name, edge_features=4)
-    graph = MolGraph.from_molbatch(mb, dev)
-    afm = torch.from_numpy(mb.atom_feat).to(dev)
-    mask = torch.ones(mb.num_atoms, 1, device=dev)
-    V, E = graph.num_nodes, graph.num_edges
-    graph.order, graph.type_ptr                          # index arrays built once, outside the timed region
+    # ---- resident inputs: a list of micro-batches (afm, graph, mask); weak scaling has exactly one
+    shard_info = None
+    if args.scaling == "strong":
+        micro, shard_info = parallel.strong_scaling_shard(STRONG_CHUNKS, mols, rank, world, seed=317, dist_name=dist_name,
+                                                          micro_mols=mols)
+        batches = []
+        for mbi, keys in micro:
+            g = MolGraph.from_molbatch(mbi, dev)
+            a = synth.hashed_features(torch.from_numpy(keys).to(dev), hidden)
+            batches.append((a, g, torch.ones(mbi.num_atoms, 1, device=dev)))
+        mb = micro[0][0]
+        local_mols = shard_info["local_mols"]
+    else:
+        mb = synth.make_molecules(mols, hidden, seed=317 + rank, dist=dist_name, edge_features=4)
+        g = MolGraph.from_molbatch(mb, dev)
+        batches = [(torch.from_numpy(mb.atom_feat).to(dev), g, torch.ones(mb.num_atoms, 1, device=dev))]
+        local_mols = mols
+    for _, g, _ in batches:                              # index arrays built once, outside the timed region
+        g.prepare()
+    afm, graph, mask = batches[0]
+    V = sum(g.num_nodes for _, g, _ in batches)
+    E = sum(g.num_edges for _, g, _ in batches)
     torch.manual_seed(317)                               # same weights on every rank
     if args.workload in ("c3", "c3a"):
         from mpnn_amd.models.att_model import BasicModel as AttModel
@@ -218,26 +325,39 @@ def main():
     else:
         model = BasicModel(hidden, 4, hidden, 50, 8, message_opts={}, agg_opts={}, update_opts={}, readout_opts={},
                            message_steps=T).to(dev)
-    from mpnn_amd import parallel
     hot = [p for n, p in model.named_parameters() if not n.startswith("of.")]   # readout is off the hot path
-    graph.transpose, graph.edge_dst
     bucket = parallel.GradientBucket(hot)
-    total_mols = parallel.global_count(mols, dev)
+    total_mols = parallel.global_count(local_mols, dev)
 
     def step_fwd():
         with torch.no_grad():
-            state, _ = model.message_passing(afm, graph, graph, mask)
+            for a, g, mk in batches:
+                state, _ = model.message_passing(a, g, g, mk)
         return state
 
-    # d(loss)/d(state) of loss = sum(state) / total_mols (this shard's share of a global mean loss), built once: what
-    # a readout's backward would hand to the path; seeding with it skips a V x H reduce, expand and scale per step
-    seed = torch.full((V, hidden), 1.0 / float(total_mols), device=dev) if args.mode == "train" else None
+    # d(loss)/d(state) of loss = sum(state) / total_mols (this shard's share of a global mean loss, i.e. the loss is
+    # scaled by local_G / global_G), built once: what a readout's backward would hand to the path; seeding with it
+    # skips a V x H reduce, expand and scale per step
+    seeds = [torch.full((g.num_nodes, hidden), 1.0 / float(total_mols), device=dev) for _, g, _ in batches] \
+        if args.mode == "train" else None
+    ar_events = []
 
     def step_train():
         bucket.zero()
-        state, _ = model.message_passing(afm, graph, graph, mask)
-        state.backward(gradient=seed.view_as(state))
-        bucket.all_reduce()                              # ONE RCCL all-reduce of the flat gradient bucket
+        for (a, g, mk), sd in zip(batches, seeds):
+            state, _ = model.message_passing(a, g, g, mk)
+            state.backward(gradient=sd.view_as(state))
+        if ar_events is not None and dist is not None and backend == "nccl":
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            bucket.all_reduce()                          # ONE RCCL all-reduce of the flat gradient bucket
+            e1.record()
+            ar_events.append((e0, e1))
+        else:
+            t0 = time.perf_counter()
+            bucket.all_reduce()
+            if dist is not None:
+                ar_events.append(time.perf_counter() - t0)
         return state
 
     def fence():
@@ -251,6 +371,7 @@ def main():
         for _ in range(args.warmup):
             step()
         ops.set_kernel_timer(timer)
+        del ar_events[:]
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -263,17 +384,28 @@ def main():
             dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         return float(t_max.item())
 
-    edges = torch.tensor([float(E)], device=dev, dtype=torch.float64)
-    if dist is not None:
-        dist.all_reduce(edges)
-    total_edges = float(edges.item())
-    timer = ops.KernelTimer(["segsum", "edge_message", "gru_update"])
+    def gather_stat(x):
+        t = torch.zeros(world, device=dev, dtype=torch.float64)
+        t[rank] = float(x)
+        if dist is not None:
+            dist.all_reduce(t)
+        return t.tolist()
+
+    edges_per_rank = gather_stat(E)
+    mols_per_rank = gather_stat(local_mols)
+    total_edges = float(sum(edges_per_rank))
+    timer = ops.KernelTimer(["message_aggregate", "segsum", "edge_message", "gru_update", "gru_update_bwd",
+                             "message_aggregate_bwd"])
     if args.mode == "train":
         dt_fwd = timed(step_fwd, None)
         dt = timed(step_train, timer)
     else:
         dt_fwd = None
         dt = timed(step_fwd, timer)
+    ar_ms = None
+    if ar_events:
+        ar_ms = (sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events) if not isinstance(ar_events[0], float)
+                 else 1e3 * sum(ar_events) / len(ar_events))
 
     batch16 = None
     if args.workload == "c1" and world == 1:
@@ -283,7 +415,7 @@ def main():
         for b0 in range(0, mols, 16):
             sub = synth.select(mb, np.arange(b0, min(b0 + 16, mols)))
             gsub = MolGraph.from_molbatch(sub, dev)
-            gsub.order, gsub.type_ptr, gsub.transpose, gsub.edge_dst
+            gsub.prepare()
             a = torch.from_numpy(sub.atom_feat).to(dev)
             parts.append((a, gsub, torch.ones(a.shape[0], 1, device=dev)))
 
@@ -308,11 +440,28 @@ def main():
 
     if rank == 0:
         F = hidden
-        seg_ms = timer.mean_ms("segsum")
+        nb = len(batches)
+        # ---- the aggregator of the timed path.  Fused message+sum kernel when it ran, the standalone segmented sum
+        # otherwise; per-launch figures are per micro-batch (this rank's E and V over its `nb` launches per step).
+        Eb, Vb = E / nb, V / nb
         weighted = graph.agg_weight is not None
-        alg_bytes = 4.0 * F * (E + V) + 4.0 * (V + 1) + (4.0 * E if weighted else 0.0)   # msg rows + out rows + row_ptr (+ weights)
-        achieved = alg_bytes / (seg_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(args.workload)
+        fused_ms = timer.mean_ms("message_aggregate")
+        if fused_ms is not None:
+            # every h row read once (LDS-staged molecule tile), every out row written once, the tile plan's slot and
+            # row-tile words read once: the kernel's minimum traffic.  SURVEY 8(d)'s fused-gather formula counts the
+            # gathered row of every EDGE (4*nf*E) -- bytes this kernel serves from LDS instead -- and is given beside it.
+            plan_bytes = float(graph.plan_bytes())
+            alg_bytes = 4.0 * F * Vb + 4.0 * F * Vb + plan_bytes
+            survey_bytes = 4.0 * F * Eb + 4.0 * Eb + 4.0 * (Vb + 1) + 4.0 * F * Vb
+            agg_ms, kname, ksub = fused_ms, "message_sum_tile_kernel (fused typed message + neighbour sum, mpnn_message_aggregate_f32)", "message_sum_tile"
+            formula = "4*nf*V + 4*mf*V + tile-plan words (h rows and out rows once each; gathers served from the LDS tile)"
+        else:
+            alg_bytes = 4.0 * F * (Eb + Vb) + 4.0 * (Vb + 1) + (4.0 * Eb if weighted else 0.0)
+            survey_bytes = None
+            agg_ms, kname, ksub = timer.mean_ms("segsum"), "segsum_pair_kernel (aggregator, mpnn_segsum_f32)", "segsum"
+            formula = "4*mf*(E+V) + 4*(V+1) (+4*E weights)"
+        achieved = alg_bytes / (agg_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(args.workload, ksub)
         out = {
             "metric": "edges/sec (message+aggregate+update)",
             "value": total_edges * T * args.steps / dt,
@@ -322,37 +471,59 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "%s: %s" % (args.workload, desc), "mode": ("train: forward + backward + flat-gradient all-reduce" if args.mode == "train" else "forward only"), "mols_per_gpu": mols,
-                       "atoms_per_gpu": V, "edges_per_gpu": E, "hidden": hidden, "mp_steps": T,
+            "config": {"workload": "%s: %s" % (args.workload, desc), "mode": ("train: forward + backward + flat-gradient all-reduce" if args.mode == "train" else "forward only"),
+                       "mols_per_gpu": local_mols, "atoms_per_gpu": V, "edges_per_gpu": E, "micro_batches_per_step": nb,
+                       "hidden": hidden, "mp_steps": T,
                        "edge_features": 4, "edge_types": graph.num_types, "parallelism": "dp%d" % world,
                        "edges_counted": "directed edges x MP steps per pass",
-                       "math": ("fp32 matrix pipe (MPNN_GRU_MATH=fp32)" if os.environ.get("MPNN_GRU_MATH") == "fp32" else
-                                "fp32 data and accumulation; dense contractions as three-way bf16 operand splits "
-                                "(six bf16 MFMAs per fp32 product), parity 1e-5 as the fp32 kernels")},
-            "roofline": {"kernel": "segsum_pair_kernel (aggregator, mpnn_segsum_f32)", "bound": "hbm",
+                       "math": ops.math_description()},
+            "roofline": {"kernel": kname, "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": seg_ms, "algorithmic_bytes_per_launch": alg_bytes},
-            "kernels_ms": {k: timer.mean_ms(k) for k in ("edge_message", "segsum", "gru_update")},
+                         "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": agg_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes, "formula": formula},
+            "kernels_ms": {k: timer.mean_ms(k) for k in sorted(timer.names)},
         }
-        # the two dense contractions of the path against the fp32 matrix-core peak (fp32 MFMA 157.3 TF).
-        # They run as bf16x6 (three-way split operands, six bf16 MFMAs per fp32 product), so "achieved" is in
-        # fp32-EQUIVALENT flops: useful multiply-adds of the fp32 problem, not bf16 issue slots.
-        msg_ms, gru_ms = timer.mean_ms("edge_message"), timer.mean_ms("gru_update")
-        out["roofline_contractions"] = [
-            {"kernel": "typed edge message (mpnn_edge_message_f32)", "bound": "mfma", "unit": "TFLOP/s",
-             "peak": MFMA_F32_PEAK_TF, "achieved": 2.0 * F * F * E / (msg_ms * 1e-3) / 1e12,
-             "frac": 2.0 * F * F * E / (msg_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "avg_launch_ms": msg_ms,
-             "hbm_GBs_algorithmic": (4.0 * F * V + 4.0 * F * E + 8.0 * E) / (msg_ms * 1e-3) / 1e9},
-            {"kernel": "masked GRU update (mpnn_gru_update_f32)", "bound": "mfma", "unit": "TFLOP/s",
-             "peak": MFMA_F32_PEAK_TF, "achieved": 12.0 * F * F * V / (gru_ms * 1e-3) / 1e12,
-             "frac": 12.0 * F * F * V / (gru_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "avg_launch_ms": gru_ms},
-        ]
+        if survey_bytes is not None:
+            out["roofline"]["survey_8d_fused_gather"] = {
+                "formula": "4*nf*E + 4*E + 4*(V+1) + 4*mf*V", "bytes": survey_bytes,
+                "GB/s": survey_bytes / (agg_ms * 1e-3) / 1e9,
+                "note": "counts one gathered row per edge; above the HBM peak means the rows were NOT fetched per edge"}
+        if world > 1 or args.scaling == "strong":
+            out["sharding"] = {"global_mols": int(sum(mols_per_rank)), "global_edges": int(total_edges),
+                               "edges_per_rank_max": max(edges_per_rank), "edges_per_rank_min": min(edges_per_rank),
+                               "mols_per_rank_max": max(mols_per_rank), "mols_per_rank_min": min(mols_per_rank),
+                               "allreduce_ms": ar_ms, "allreduce_floats": int(bucket.flat.numel()),
+                               "backend": backend or "none",
+                               "partition": ("parallel.shard_by_edges over one global set" if args.scaling == "strong"
+                                             else "independent equal batches per rank")}
+        if rehearsal:
+            out["rehearsal"] = ("%d ranks share %d GPU(s) over %s: exercises the multi-rank code path only, the rate is "
+                                "not a scaling measurement" % (world, ndev, backend))
+        # ---- the dense contractions against the pipe they run on: 16-bit MFMA peak divided by the MFMAs issued per fp32
+        # product (6 for the three-way bf16 split, 3 for the two-way fp16 split); the fp32-MFMA-peak ratio is a side figure
+        per = ops.mfma_per_product()
+        peak_eq = MFMA_16BIT_PEAK_TF / per if per else MFMA_F32_PEAK_TF
+        rows = []
+        for key, name, flops in (("edge_message", "typed edge message (mpnn_edge_message_f32)", 2.0 * F * F * Eb),
+                                 ("gru_update", "masked GRU update forward (mpnn_gru_update_f32)", 12.0 * F * F * Vb),
+                                 ("gru_update_bwd", "masked GRU update backward (mpnn_gru_update_bwd_f32)", 24.0 * F * F * Vb)):
+            ms = timer.mean_ms(key)
+            if ms is None:
+                continue
+            tf = flops / (ms * 1e-3) / 1e12
+            rows.append({"kernel": name, "bound": "mfma", "unit": "TFLOP/s (fp32-equivalent)", "achieved": tf,
+                         "peak": peak_eq, "frac": tf / peak_eq, "avg_launch_ms": ms,
+                         "peak_note": "%.0f TF 16-bit dense MFMA peak / %d MFMAs per fp32 product" % (MFMA_16BIT_PEAK_TF, per) if per
+                                      else "fp32 MFMA peak",
+                         "side_figure_vs_fp32_mfma_peak": tf / MFMA_F32_PEAK_TF})
+        out["roofline_contractions"] = rows
         if world == 1:
             out["roofline"]["stream_calibration"] = stream_calibration(dev, alg_bytes)
+            out["aggregator_standalone"] = segsum_calibration(ops, graph, F, dev)
         if dt_fwd is not None:
             out["forward"] = {"value": total_edges * T * args.steps / dt_fwd, "unit": "edges/s",
                               "ms_per_step": dt_fwd / args.steps * 1e3,
@@ -370,7 +541,10 @@ def main():
                         "instead of once per MP step (their input is the constant afm, models/basic_model.py:57, so the "
                         "result is bit-identical); reported to show what the reference's own structure leaves on the table"}
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(mb, hidden, T, args.mode, args.cpu_seconds)
+            cmb = mb
+            if args.scaling == "strong":                  # the strong-scaling shard carries no host features
+                cmb = synth.make_molecules(min(mols, 4096), hidden, seed=317, dist=dist_name, edge_features=4)
+            out["cpu_baseline"] = cpu_baseline(cmb, hidden, T, args.mode, args.cpu_seconds)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if dist is not None:

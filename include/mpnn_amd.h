@@ -9,7 +9,12 @@
  * Conventions (every function):
  *   - all data pointers are DEVICE pointers owned by the caller; fp32 data, int32 indices;
  *   - `stream` is a hipStream_t passed as void*; work is enqueued, never synchronised;
- *   - no allocation, no host<->device copy, no global state except the last-error string;
+ *   - no allocation, no host<->device copy;
+ *   - process-wide state is exactly: the last-error string (one per calling thread), the environment switches
+ *     (alternate kernels for A/B runs, README "Switches"; read once by mpnn_init() or by the first call that needs
+ *     one), and one cached hipFuncSetAttribute result per kernel family that needs more than 64 KB of LDS (set on
+ *     that family's first launch; a failure is returned as MPNN_ELAUNCH by every launch of it).  All three are
+ *     initialised exactly once under C++11 static-initialisation guarantees, so concurrent first calls are safe;
  *   - re-entrant; returns 0 on success, a negative MPNN_E* code on a rejected call;
  *   - row-major, densely packed arrays; "V" = atoms (rows of node arrays), "E" = directed
  *     edges sorted by destination atom (CSR: row_ptr[V+1], col_idx[E] = source atom).
@@ -38,6 +43,9 @@ extern "C" {
 int mpnn_version(void);
 /* Message for the last non-zero return on the calling thread ("" if none). */
 const char* mpnn_last_error_string(void);
+/* Optional explicit initialisation: reads the environment switches now (otherwise the first call that consults one
+ * does).  Idempotent, thread-safe, touches no device. */
+int mpnn_init(void);
 
 /* ------------------------------------------------------------------ graph build ---- */
 /*
@@ -172,8 +180,11 @@ int mpnn_gru_update_f32(const float* m, const float* h, const float* mask,
                         float* out, float* saved, int64_t V, int H, void* stream);
 /*
  * Backward: given dout [V,H] and `saved`, writes dm [V,H], dh [V,H] and ACCUMULATES into
- * dW_ih, dW_hh [H,3H], db_ih, db_hh [3H] (caller zeroes them).  `workspace` holds the
- * pre-activation gradients [V,6H] (dgi | dgh); see mpnn_gru_bwd_workspace_bytes.
+ * dW_ih, dW_hh [H,3H], db_ih, db_hh [3H] (caller zeroes them).  `workspace`: mpnn_gru_bwd_workspace_bytes(V, H)
+ * bytes.  At H = 64 the backward is one kernel that keeps the gate gradients in LDS and needs NO workspace (the
+ * function returns a token 16 bytes); at H = 128 / 256 it holds the compact gate gradients
+ * [V,4H] = (d a_r | d a_z | d a_n | r * d a_n) that the dm/dh and dW kernels read; at other widths (and with
+ * MPNN_GRU_MATH=fp32) the pre-activation gradients [V,6H] = (dgi | dgh).
  */
 size_t mpnn_gru_bwd_workspace_bytes(int64_t V, int H);
 int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const float* h, const float* mask,

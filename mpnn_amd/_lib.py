@@ -23,6 +23,7 @@ usz = ctypes.c_size_t
 _SIGNATURES = {
     "mpnn_version": (ctypes.c_int, []),
     "mpnn_last_error_string": (ctypes.c_char_p, []),
+    "mpnn_init": (ctypes.c_int, []),
     "mpnn_csr_workspace_bytes": (usz, [i64]),
     "mpnn_csr_count": (ctypes.c_int, [c_f, c_f, i64, i32, i32, c_i, c_v, usz, c_v]),
     "mpnn_csr_fill": (ctypes.c_int, [c_f, c_f, i64, i32, i32, c_i, c_i, c_f, c_f, c_v]),

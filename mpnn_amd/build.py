@@ -32,24 +32,48 @@ def _stale():
     return any(os.path.getmtime(p) > t for p in deps)
 
 
+def _compile_one(job):
+    hipcc, src, obj, verbose = job
+    cmd = [hipcc] + [f for f in FLAGS if f != "-shared"] + ["-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    return src, r.returncode, r.stdout + r.stderr
+
+
 def build(force=False, verbose=False):
-    """Compile every HIP source into one shared object; returns its path."""
+    """Compile every HIP source to an object (only the stale ones, a few in parallel) and link them into one shared
+    object; returns its path."""
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libmpnn_amd.so (and there is no CPU fallback)")
     os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    headers = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "mpnn_amd.h")]
+    t_hdr = max(os.path.getmtime(p) for p in headers)
+    jobs, objs = [], []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), t_hdr):
+            jobs.append((hipcc, src, obj, verbose))
+    if jobs:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), int(os.environ.get("MPNN_BUILD_JOBS", "6")))) as ex:
+            for src, rc, log in ex.map(_compile_one, jobs):
+                if rc != 0:
+                    sys.stderr.write(log)
+                    raise RuntimeError("hipcc failed on %s" % src)
+                if verbose and log:
+                    sys.stderr.write(log)
     tmp = LIB + ".tmp"
-    cmd = [hipcc] + FLAGS + ["-o", tmp] + sources()
-    if verbose:
-        print(" ".join(cmd))
-    r = subprocess.run(cmd, capture_output=True, text=True)
+    r = subprocess.run([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", tmp] + objs, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError("hipcc failed building libmpnn_amd.so")
-    if verbose and r.stderr:
-        sys.stderr.write(r.stderr)
+        raise RuntimeError("hipcc failed linking libmpnn_amd.so")
     os.replace(tmp, LIB)
     return LIB
 

@@ -572,11 +572,11 @@ int launch_edge_da_split64(const float* Y, const float* h, const int32_t* src, c
                            const int32_t* order, const int32_t* type_ptr, const float* gate, float* dA, int64_t E,
                            int K, hipStream_t s);
 static bool da64_split() {     // default since the index pipeline; MPNN_DA64_DIRECT=1 selects the fp32 register-direct kernel
-    static const bool v = getenv("MPNN_DA64_DIRECT") == nullptr;
+    const bool v = !switches().da64_direct;
     return v;
 }
 static bool math_fp32_only() {
-    static const bool v = getenv("MPNN_GRU_MATH") && !strcmp(getenv("MPNN_GRU_MATH"), "fp32");
+    const bool v = switches().math_fp32;
     return v;
 }
 int launch_gru_bwd_dx_stream256(const float* ws, const float* W_ih, const float* W_hh, float* dm, float* dh, int64_t V,
@@ -660,7 +660,9 @@ extern "C" int mpnn_edge_message_bwd_f32(const float* h, const float* A, const i
 
 extern "C" size_t mpnn_gru_bwd_workspace_bytes(int64_t V, int H) {
     if (V < 0 || H <= 0) return 0;
-    return (size_t)V * 6 * H * sizeof(float);
+    if (H == 64) return 16;                                               // one kernel, gate gradients stay in LDS
+    if ((H == 128 || H == 256) && !switches().math_fp32) return (size_t)V * 4 * H * sizeof(float);   // compact layout
+    return (size_t)V * 6 * H * sizeof(float);                            // generic widths: (dgi | dgh)
 }
 
 extern "C" int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const float* h, const float* mask,
@@ -683,7 +685,7 @@ extern "C" int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const 
     float* ws = (float*)workspace;
     int64_t g = ceil_div(V * H, 256);
     if (g > 256 * 16) g = 256 * 16;
-    static const bool fp32_only = getenv("MPNN_GRU_MATH") && !strcmp(getenv("MPNN_GRU_MATH"), "fp32");
+    const bool fp32_only = switches().math_fp32;
     int rc;
     if ((H == 128 || H == 256) && !fp32_only) {
         hipLaunchKernelGGL(gru_gate_grad_kernel<true>, dim3((unsigned)g), dim3(256), 0, s, dout, h, mask, saved, ws, dh, V,
@@ -692,7 +694,7 @@ extern "C" int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const 
         if (rc) return rc;
         // hidden 128: the streamed kernel (2 output slices, 32 x 64 tile per wave) beats the resident-slice one
         // (4 slices) by ~1 ms on c4; MPNN_GRU128_SLICED_DX=1 selects the latter
-        static const bool sliced_dx = getenv("MPNN_GRU128_SLICED_DX") != nullptr;
+        const bool sliced_dx = switches().gru128_sliced_dx;
         if (H == 256) rc = launch_gru_bwd_dx_stream256(ws, W_ih, W_hh, dm, dh, V, s);
         else if (!sliced_dx) rc = launch_gru_bwd_dx_stream128(ws, W_ih, W_hh, dm, dh, V, s);
         else rc = launch_gru_bwd_dx128(ws, W_ih, W_hh, dm, dh, V, s);

@@ -22,6 +22,35 @@ inline int launch_status(const char* what) {
     return MPNN_OK;
 }
 
+// One-time opt-in of a kernel (family) to more than 64 KB of dynamic LDS.  Used as the initialiser of a function-local
+// `static const hipError_t` (C++11: initialised exactly once, thread-safely); every launch checks the cached result.
+struct LdsOptIn {
+    hipError_t err = hipSuccess;
+    void operator()(const void* kernel, hipFuncAttribute attr, int bytes) {
+        const hipError_t e = hipFuncSetAttribute(kernel, attr, bytes);
+        if (err == hipSuccess) err = e;
+    }
+};
+inline int lds_opt_in_failed(hipError_t e) {
+    set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(e));
+    return MPNN_ELAUNCH;
+}
+
+// Environment switches (A/B alternates of the default kernels; README "Switches"), read ONCE per process by
+// mpnn_init() or by the first call that needs one (thread-safe static initialisation in capi.hip).
+struct Switches {
+    bool math_fp32;          // MPNN_GRU_MATH=fp32: dense contractions on the fp32 matrix pipe
+    bool da64_direct;        // MPNN_DA64_DIRECT: fp32 register-direct dA kernel at width 64
+    bool gru128_sliced;      // MPNN_GRU128_SLICED: resident-slice GRU forward at width 128
+    bool gru128_sliced_dx;   // MPNN_GRU128_SLICED_DX: resident-slice dm/dh kernel at width 128
+    bool gru256_narrow;      // MPNN_GRU256_NARROW: 32-feature wave tiles in the streamed width-256 GRU
+    bool gru_bwd_uniform;    // MPNN_GRU_BWD_UNIFORM: all-waves-identical GRU backward at width 64
+    bool gru_bwd_fp32tile;   // MPNN_GRU_BWD_FP32TILE: fp32 LDS tile in the GRU backward at width 64
+    int segsum_variant;      // MPNN_SEGSUM_VARIANT: 1 = one atom per lane group, 2 = cached loads/stores, 3 = default
+    bool unfused_message;    // MPNN_UNFUSED_MESSAGE: message rows to HBM + segmented sum instead of the tile kernel
+};
+const Switches& switches();
+
 #define MPNN_REQUIRE(cond, ...)              \
     do {                                     \
         if (!(cond)) {                       \

@@ -178,12 +178,8 @@ static int launch_edge_da_split(const float* Y, const float* h, const int32_t* s
     if (gx > need) gx = need;
 #define MPNN_DA(D, W, G)                                                                                            \
     do {                                                                                                            \
-        static bool attr_done = false;                                                                              \
-        if (!attr_done) {                                                                                           \
-            (void)hipFuncSetAttribute((const void*)edge_da_split_kernel<F, D, W, G>,                                \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
-            attr_done = true;                                                                                       \
-        }                                                                                                           \
+        static const hipError_t attr_done = [&] { LdsOptIn opt_in_; opt_in_((const void*)edge_da_split_kernel<F, D, W, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); return opt_in_.err; }();  /* once, thread-safe */ \
+        if (attr_done != hipSuccess) return lds_opt_in_failed(attr_done);                                                                                                           \
         hipLaunchKernelGGL((edge_da_split_kernel<F, D, W, G>), dim3((unsigned)gx), dim3(F >= 128 ? 512 : 256), lds, s, Y, h, src, dst, \
                            w, order, type_ptr, gate, dA, K);                                                        \
     } while (0)

@@ -313,7 +313,7 @@ int launch_message_dx_split64(const float* dmsg, const float* A, const int32_t* 
                               float* dx, int64_t E, int K, hipStream_t s);
 
 static bool fp32_only() {
-    static const bool v = getenv("MPNN_GRU_MATH") && !strcmp(getenv("MPNN_GRU_MATH"), "fp32");
+    const bool v = switches().math_fp32;
     return v;
 }
 

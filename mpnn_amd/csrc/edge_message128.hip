@@ -188,14 +188,13 @@ static int launch_split(const float* h, const float* A, const int32_t* src, cons
     // F = 128: one 8-wave block per CU (96 KB of LDS).  F = 64: 24 KB images, 4-wave blocks, 4 per CU ungated (<= 128 VGPRs).
     constexpr int NW = F == 128 ? 8 : 4;
     const size_t lds = (size_t)3 * F * 2 * F;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)edge_message_split_kernel<F, NW, BWD, false>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)edge_message_split_kernel<F, NW, BWD, true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static const hipError_t attr_done = [&] {   // once per process, thread-safe (C++11 static initialisation)
+        LdsOptIn opt_in_;
+        opt_in_((const void*)edge_message_split_kernel<F, NW, BWD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        opt_in_((const void*)edge_message_split_kernel<F, NW, BWD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return opt_in_.err;
+    }();
+    if (attr_done != hipSuccess) return lds_opt_in_failed(attr_done);
     int64_t blocks = F == 128 ? 256 : (gate ? 512 : 1024);
     const int64_t need = ceil_div(ceil_div(E, 32) + K, NW);
     if (blocks > need) blocks = need;
@@ -223,12 +222,12 @@ static int launch_dgate(const float* dagg, const float* A, const int32_t* dst, c
                         hipStream_t s) {
     constexpr int NW = F == 128 ? 8 : 4;
     const size_t lds = (size_t)3 * F * 2 * F;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)edge_message_split_kernel<F, NW, true, false, true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static const hipError_t attr_done = [&] {   // once per process, thread-safe (C++11 static initialisation)
+        LdsOptIn opt_in_;
+        opt_in_((const void*)edge_message_split_kernel<F, NW, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return opt_in_.err;
+    }();
+    if (attr_done != hipSuccess) return lds_opt_in_failed(attr_done);
     int64_t blocks = F == 128 ? 256 : 1024;
     const int64_t need = ceil_div(ceil_div(E, 32) + K, NW);
     if (blocks > need) blocks = need;
@@ -410,14 +409,13 @@ __global__ void __launch_bounds__(512) edge_message_stream256_kernel(
 int launch_message_stream256(const float* h, const float* A, const int32_t* src, const int32_t* order,
                              const int32_t* type_ptr, const float* gate, float* msg, int64_t E, int K, hipStream_t s) {
     const size_t lds = (size_t)2 * 3 * 64 * 128;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)edge_message_stream256_kernel<false>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)edge_message_stream256_kernel<true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static const hipError_t attr_done = [&] {   // once per process, thread-safe (C++11 static initialisation)
+        LdsOptIn opt_in_;
+        opt_in_((const void*)edge_message_stream256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        opt_in_((const void*)edge_message_stream256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return opt_in_.err;
+    }();
+    if (attr_done != hipSuccess) return lds_opt_in_failed(attr_done);
     const dim3 grid(256), block(512);                       // 64 row groups x 4 slices = one block per CU
     if (gate)
         hipLaunchKernelGGL((edge_message_stream256_kernel<true>), grid, block, lds, s, h, A, src, order, type_ptr, gate,

@@ -304,14 +304,13 @@ static int launch_gru_resident(const float* m, const float* h, const float* mask
     constexpr int CS = 32 * NCS;
     constexpr int slices = H / CS;
     const size_t lds = (size_t)2 * H * 3 * CS * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gru_update_resident_kernel<H, NCS, NW, true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)gru_update_resident_kernel<H, NCS, NW, false>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static const hipError_t attr_done = [&] {   // once per process, thread-safe (C++11 static initialisation)
+        LdsOptIn opt_in_;
+        opt_in_((const void*)gru_update_resident_kernel<H, NCS, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        opt_in_((const void*)gru_update_resident_kernel<H, NCS, NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return opt_in_.err;
+    }();
+    if (attr_done != hipSuccess) return lds_opt_in_failed(attr_done);
     const int64_t tiles = (V + 31) / 32;
     int64_t pblocks = (256 + slices - 1) / slices;        // one block per CU (LDS-bound residency)
     if (pblocks * NW > tiles) pblocks = (tiles + NW - 1) / NW;
@@ -348,7 +347,7 @@ extern "C" int mpnn_gru_update_f32(const float* m, const float* h, const float* 
     hipStream_t st = (hipStream_t)stream;
     // MPNN_GRU_MATH=fp32 keeps the GEMMs on v_mfma_f32_32x32x2_f32; default: bf16 pipe with 3-way operand
     // splitting (fp32-equivalent accuracy, see gru_split.hip)
-    static const bool fp32_only = getenv("MPNN_GRU_MATH") && !strcmp(getenv("MPNN_GRU_MATH"), "fp32");
+    const bool fp32_only = switches().math_fp32;
     if (!fp32_only) {
         const int rc = launch_gru_split(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, H, st);
         if (rc != 1) return rc;

@@ -670,27 +670,25 @@ int launch_gru_bwd_fused64(const float* dout, const float* m, const float* h, co
     constexpr int H = 64;
     const int64_t tiles = (V + 31) / 32;
     const size_t lds = (size_t)2 * 32 * (5 * H + 4 + 2 * H) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gru_bwd_fused_kernel<H, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        (void)hipFuncSetAttribute((const void*)gru_bwd_fused_kernel<H, false>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static const hipError_t attr_done = [&] {   // once per process, thread-safe (C++11 static initialisation)
+        LdsOptIn opt_in_;
+        opt_in_((const void*)gru_bwd_fused_kernel<H, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        opt_in_((const void*)gru_bwd_fused_kernel<H, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return opt_in_.err;
+    }();
+    if (attr_done != hipSuccess) return lds_opt_in_failed(attr_done);
     int64_t blocks = 256;                                  // one 8-wave block per CU (116 KB of LDS)
     if (blocks > tiles) blocks = tiles;
-    static const bool fp32_only = getenv("MPNN_GRU_MATH") && !strcmp(getenv("MPNN_GRU_MATH"), "fp32");
-    static const bool uniform = getenv("MPNN_GRU_BWD_UNIFORM") != nullptr;  // A/B: all-waves-identical arrangement
+    const bool fp32_only = switches().math_fp32;
+    const bool uniform = switches().gru_bwd_uniform;  // A/B: all-waves-identical arrangement
     if (!fp32_only && uniform) {
-        static bool attr3 = false;
-        if (!attr3) {
-            (void)hipFuncSetAttribute((const void*)gru_bwd_uniform_kernel<H, true>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute((const void*)gru_bwd_uniform_kernel<H, false>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr3 = true;
-        }
+        static const hipError_t attr3 = [&] {   // once per process, thread-safe (C++11 static initialisation)
+        LdsOptIn opt_in_;
+        opt_in_((const void*)gru_bwd_uniform_kernel<H, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        opt_in_((const void*)gru_bwd_uniform_kernel<H, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return opt_in_.err;
+    }();
+    if (attr3 != hipSuccess) return lds_opt_in_failed(attr3);
         if (mask)
             hipLaunchKernelGGL((gru_bwd_uniform_kernel<H, true>), dim3((unsigned)blocks), dim3(512), lds, s, dout, m, h,
                                mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, V);
@@ -701,18 +699,17 @@ int launch_gru_bwd_fused64(const float* dout, const float* m, const float* h, co
     }
     // default: gate gradients split once at staging (gru_bwd_presplit.hip); MPNN_GRU_BWD_FP32TILE=1 keeps the fp32
     // tile whose consumers split what they read
-    static const bool fp32_tile = getenv("MPNN_GRU_BWD_FP32TILE") != nullptr;
+    const bool fp32_tile = switches().gru_bwd_fp32tile;
     if (!fp32_only && !fp32_tile)
         return launch_gru_bwd_presplit64(dout, m, h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, V, s);
     if (!fp32_only) {
-        static bool attr2 = false;
-        if (!attr2) {
-            (void)hipFuncSetAttribute((const void*)gru_bwd_fused_split_kernel<H, true>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute((const void*)gru_bwd_fused_split_kernel<H, false>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr2 = true;
-        }
+        static const hipError_t attr2 = [&] {   // once per process, thread-safe (C++11 static initialisation)
+        LdsOptIn opt_in_;
+        opt_in_((const void*)gru_bwd_fused_split_kernel<H, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        opt_in_((const void*)gru_bwd_fused_split_kernel<H, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return opt_in_.err;
+    }();
+    if (attr2 != hipSuccess) return lds_opt_in_failed(attr2);
         if (mask)
             hipLaunchKernelGGL((gru_bwd_fused_split_kernel<H, true>), dim3((unsigned)blocks), dim3(512), lds, s, dout, m,
                                h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, V);

@@ -120,11 +120,12 @@ __global__ void __launch_bounds__(512) gru_bwd_dx128_kernel(const float* __restr
 int launch_gru_bwd_dx128(const float* ws, const float* W_ih, const float* W_hh, float* dm, float* dh, int64_t V,
                          hipStream_t s) {
     const size_t lds = (size_t)2 * 3 * 32 * (2 * 3 * 128);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gru_bwd_dx128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static const hipError_t attr_done = [&] {   // once per process, thread-safe (C++11 static initialisation)
+        LdsOptIn opt_in_;
+        opt_in_((const void*)gru_bwd_dx128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return opt_in_.err;
+    }();
+    if (attr_done != hipSuccess) return lds_opt_in_failed(attr_done);
     const int64_t tiles = (V + 31) / 32;
     int64_t pblocks = 64;                                   // x 4 slices = one block per CU
     if (pblocks * 8 > tiles) pblocks = (tiles + 7) / 8;
@@ -254,11 +255,12 @@ __global__ void __launch_bounds__(512) gru_bwd_dw128_kernel(const float* __restr
 int launch_gru_bwd_dw128(const float* m, const float* h, const float* ws, float* dW_ih, float* dW_hh, float* db_ih,
                          float* db_hh, int64_t V, hipStream_t s) {
     const size_t lds = (size_t)2 * 3 * 2 * 512 * 16;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gru_bwd_dw128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static const hipError_t attr_done = [&] {   // once per process, thread-safe (C++11 static initialisation)
+        LdsOptIn opt_in_;
+        opt_in_((const void*)gru_bwd_dw128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return opt_in_.err;
+    }();
+    if (attr_done != hipSuccess) return lds_opt_in_failed(attr_done);
     const int64_t steps = (V + 15) / 16;
     int64_t gx = 128;                                       // x 2 matrices = one block per CU (96 KB of LDS)
     if (gx > steps) gx = steps;
@@ -380,11 +382,12 @@ __global__ void __launch_bounds__(512) gru_bwd_dw256_kernel(const float* __restr
 int launch_gru_bwd_dw256(const float* m, const float* h, const float* ws, float* dW_ih, float* dW_hh, float* db_ih,
                          float* db_hh, int64_t V, hipStream_t s) {
     const size_t lds = (size_t)2 * 3 * 2 * 512 * 16;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gru_bwd_dw256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static const hipError_t attr_done = [&] {   // once per process, thread-safe (C++11 static initialisation)
+        LdsOptIn opt_in_;
+        opt_in_((const void*)gru_bwd_dw256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return opt_in_.err;
+    }();
+    if (attr_done != hipSuccess) return lds_opt_in_failed(attr_done);
     const int64_t steps = (V + 15) / 16;
     int64_t gx = 42;                                        // x 6 (matrix, gate) jobs = 252 blocks: one per CU, ONE wave of blocks (43 x 6 = 258 left two blocks for a second pass and doubled the kernel time)
     if (gx > steps) gx = steps;
@@ -545,12 +548,12 @@ static int launch_dx_stream(const float* ws, const float* W_ih, const float* W_h
                             hipStream_t s) {
     constexpr int NS = H / 64;
     const size_t lds = (size_t)2 * 6 * 64 * 128;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gru_bwd_dx_stream_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        attr_done = true;
-    }
+    static const hipError_t attr_done = [&] {   // once per process, thread-safe (C++11 static initialisation)
+        LdsOptIn opt_in_;
+        opt_in_((const void*)gru_bwd_dx_stream_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return opt_in_.err;
+    }();
+    if (attr_done != hipSuccess) return lds_opt_in_failed(attr_done);
     const int64_t rounds = (V + 255) / 256;
     int64_t pblocks = 256 / NS;
     if (pblocks > rounds) pblocks = rounds;

@@ -331,14 +331,13 @@ int launch_gru_bwd_presplit64(const float* dout, const float* m, const float* h,
                               float* db_ih, float* db_hh, int64_t V, hipStream_t s) {
     const int64_t tiles = (V + 31) / 32;
     const size_t lds = (size_t)2 * PS_TILE;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gru_bwd_presplit64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        (void)hipFuncSetAttribute((const void*)gru_bwd_presplit64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        attr_done = true;
-    }
+    static const hipError_t attr_done = [&] {   // once per process, thread-safe (C++11 static initialisation)
+        LdsOptIn opt_in_;
+        opt_in_((const void*)gru_bwd_presplit64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        opt_in_((const void*)gru_bwd_presplit64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return opt_in_.err;
+    }();
+    if (attr_done != hipSuccess) return lds_opt_in_failed(attr_done);
     int64_t blocks = 256;                                  // one 8-wave block per CU (145 KB of LDS)
     if (blocks > tiles) blocks = tiles;
     if (mask)

@@ -258,15 +258,16 @@ static int launch_split(const float* m, const float* h, const float* mask, const
     constexpr int CS = 32 * NCS;
     constexpr int slices = H / CS;
     const size_t lds = (size_t)2 * 3 * (3 * CS) * (2 * H) + 16 * CS;    // weight images + gate biases
-    static bool attr_done = false;
-    if (!attr_done) {
+    static const hipError_t attr_done = [&] {   // once per process, thread-safe (C++11 static initialisation)
+        LdsOptIn opt_in_;
         const int n = (int)lds;
-        (void)hipFuncSetAttribute((const void*)gru_update_split_kernel<H, NCS, NW, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
-        (void)hipFuncSetAttribute((const void*)gru_update_split_kernel<H, NCS, NW, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
-        (void)hipFuncSetAttribute((const void*)gru_update_split_kernel<H, NCS, NW, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
-        (void)hipFuncSetAttribute((const void*)gru_update_split_kernel<H, NCS, NW, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
-        attr_done = true;
-    }
+        opt_in_((const void*)gru_update_split_kernel<H, NCS, NW, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
+        opt_in_((const void*)gru_update_split_kernel<H, NCS, NW, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
+        opt_in_((const void*)gru_update_split_kernel<H, NCS, NW, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
+        opt_in_((const void*)gru_update_split_kernel<H, NCS, NW, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
+        return opt_in_.err;
+    }();
+    if (attr_done != hipSuccess) return lds_opt_in_failed(attr_done);
     const int64_t tiles = (V + 31) / 32;
     int64_t pblocks = (256 + slices - 1) / slices;        // one block per CU (144 KB of LDS)
     if (pblocks * NW > tiles) pblocks = (tiles + NW - 1) / NW;
@@ -420,14 +421,13 @@ __global__ void __launch_bounds__(512) gru_update_split128_kernel(
 static int launch_split128(const float* m, const float* h, const float* mask, const float* W_ih, const float* W_hh,
                            const float* b_ih, const float* b_hh, float* out, float* saved, int64_t V, hipStream_t s) {
     const size_t lds = (size_t)2 * 3 * 96 * 256;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gru_update_split128_kernel<true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)gru_update_split128_kernel<false>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static const hipError_t attr_done = [&] {   // once per process, thread-safe (C++11 static initialisation)
+        LdsOptIn opt_in_;
+        opt_in_((const void*)gru_update_split128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        opt_in_((const void*)gru_update_split128_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return opt_in_.err;
+    }();
+    if (attr_done != hipSuccess) return lds_opt_in_failed(attr_done);
     const int64_t tiles = (V + 31) / 32;
     int64_t pblocks = 64;                                   // x 4 slices = one block per CU
     if (pblocks * 8 > tiles) pblocks = (tiles + 7) / 8;
@@ -805,14 +805,13 @@ static int launch_stream(const float* m, const float* h, const float* mask, cons
                          const float* b_ih, const float* b_hh, float* out, float* saved, int64_t V, hipStream_t s) {
     constexpr int NS = H / 64;
     const size_t lds = (size_t)2 * 6 * 192 * 64;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gru_update_stream_kernel<H, true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)gru_update_stream_kernel<H, false>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static const hipError_t attr_done = [&] {   // once per process, thread-safe (C++11 static initialisation)
+        LdsOptIn opt_in_;
+        opt_in_((const void*)gru_update_stream_kernel<H, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        opt_in_((const void*)gru_update_stream_kernel<H, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return opt_in_.err;
+    }();
+    if (attr_done != hipSuccess) return lds_opt_in_failed(attr_done);
     const int64_t rounds = (V + 127) / 128;
     int64_t pblocks = 256 / NS;                             // x NS slices = one block per CU (144 KB of LDS)
     if (pblocks > rounds) pblocks = rounds;
@@ -832,15 +831,16 @@ static int launch_stream_wide(const float* m, const float* h, const float* mask,
                          const float* b_ih, const float* b_hh, float* out, float* saved, int64_t V, hipStream_t s) {
     constexpr int NS = H / 64;
     const size_t lds = (size_t)2 * 6 * 192 * 64;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static const hipError_t attr_done = [&] {   // once per process, thread-safe (C++11 static initialisation)
+        LdsOptIn opt_in_;
         const int n = (int)lds;
-        (void)hipFuncSetAttribute((const void*)gru_update_stream_wide_kernel<H, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
-        (void)hipFuncSetAttribute((const void*)gru_update_stream_wide_kernel<H, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
-        (void)hipFuncSetAttribute((const void*)gru_update_stream_wide_kernel<H, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
-        (void)hipFuncSetAttribute((const void*)gru_update_stream_wide_kernel<H, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
-        attr_done = true;
-    }
+        opt_in_((const void*)gru_update_stream_wide_kernel<H, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
+        opt_in_((const void*)gru_update_stream_wide_kernel<H, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
+        opt_in_((const void*)gru_update_stream_wide_kernel<H, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
+        opt_in_((const void*)gru_update_stream_wide_kernel<H, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
+        return opt_in_.err;
+    }();
+    if (attr_done != hipSuccess) return lds_opt_in_failed(attr_done);
     const int64_t rounds = (V + 255) / 256;
     int64_t pblocks = 256 / NS;                             // x NS slices = one block per CU (144 KB of LDS)
     if (pblocks > rounds) pblocks = rounds;
@@ -863,10 +863,10 @@ int launch_gru_split(const float* m, const float* h, const float* mask, const fl
     if (H == 64) return launch_split<64, 2, 8>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, s);
     // hidden 128: streamed weights with the wide tile (2 output slices) is ~1.5 % ahead of the resident-slice kernel
     // (4 slices) on c4; MPNN_GRU128_SLICED=1 selects the latter
-    static const bool stream128 = getenv("MPNN_GRU128_SLICED") == nullptr;
+    const bool stream128 = !switches().gru128_sliced;
     if (H == 128 && stream128) return launch_stream_wide<128>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, s);
     if (H == 128) return launch_split128(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, s);
-    static const bool narrow256 = getenv("MPNN_GRU256_NARROW") != nullptr;
+    const bool narrow256 = switches().gru256_narrow;
     if (H == 256 && !narrow256) return launch_stream_wide<256>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, s);
     if (H == 256) return launch_stream<256>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, s);
     return 1;

@@ -211,7 +211,7 @@ static int launch_segsum(const float* msg, const int32_t* row_ptr, const int32_t
     const bool v4 = (F % 4 == 0) && ((reinterpret_cast<uintptr_t>(msg) | reinterpret_cast<uintptr_t>(out)) % 16 == 0);
     const int lpr = pick_lpr(F, v4 ? 4 : 1);
     const dim3 grid(grid_for(V, lpr)), block(256);
-    static const int variant = getenv("MPNN_SEGSUM_VARIANT") ? atoi(getenv("MPNN_SEGSUM_VARIANT")) : 3;   // 1 = one atom per lane group, 2 = pair kernel with cached loads/stores (A/B)
+    const int variant = switches().segsum_variant;   // 1 = one atom per lane group, 2 = pair kernel with cached loads/stores (A/B)
     if (!GATHER && (variant == 2 || variant == 3) && v4 && lpr * 4 >= F) {
         const dim3 g2(grid_for((V + 1) / 2, lpr));
 #define MPNN_PAIR(LPR)                                                                                              \

@@ -58,6 +58,16 @@ class MolGraph:
         g.edge_feat = None
         return g
 
+    def prepare(self):
+        """Build every derived index array now (type order, transposed graph, destination list, tile plan), so
+        that none of it lands inside a timed or captured region."""
+        self.order, self.type_ptr, self.transpose, self.edge_dst, self.agg_weight
+        return self
+
+    def plan_bytes(self):
+        """Bytes of index data the fused message+sum kernel reads per launch (0 without a tile plan)."""
+        return 0
+
     # ------------------------------------------------------------------ derived index arrays
     @property
     def order(self):

@@ -58,6 +58,23 @@ def _timed(name, fn):
     return fn() if _timer is None else _timer.launch(name, fn)
 
 
+def math_mode():
+    """"fp32" (MPNN_GRU_MATH=fp32: contractions on the fp32 matrix pipe) or "bf16x6" (default: three-way bf16 operand
+    splits, six bf16 MFMAs per fp32 product)."""
+    return "fp32" if os.environ.get("MPNN_GRU_MATH") == "fp32" else "bf16x6"
+
+
+def mfma_per_product():
+    """16-bit MFMAs issued per fp32 product by the dense contractions (0 = the fp32 matrix pipe itself)."""
+    return {"fp32": 0, "bf16x6": 6}[math_mode()]
+
+
+def math_description():
+    return {"fp32": "fp32 matrix pipe (MPNN_GRU_MATH=fp32)",
+            "bf16x6": "fp32 data and accumulation; dense contractions as three-way bf16 operand splits "
+                      "(six bf16 MFMAs per fp32 product), parity 1e-5 as the fp32 kernels"}[math_mode()]
+
+
 # --------------------------------------------------------------------------- raw launches
 def segsum_raw(msg, row_ptr, w, num_rows, label="segsum"):
     """`label` names the launch for ops.KernelTimer: "segsum" is reserved for the aggregator proper (message rows
@@ -145,11 +162,10 @@ def gru_update_bwd_raw(dout, m, h, mask, W_ih, W_hh, saved):
     db_hh = torch.zeros(3 * H, dtype=torch.float32, device=h.device)
     ws_bytes = lib.mpnn_gru_bwd_workspace_bytes(V, H)
     ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=h.device)
-    _lib.check(lib.mpnn_gru_update_bwd_f32(_lib.fptr(dout), _lib.fptr(m), _lib.fptr(h), _lib.fptr(mask),
-                                           _lib.fptr(W_ih), _lib.fptr(W_hh), _lib.fptr(saved),
-                                           _lib.fptr(dm), _lib.fptr(dh), _lib.fptr(dW_ih), _lib.fptr(dW_hh),
-                                           _lib.fptr(db_ih), _lib.fptr(db_hh), _lib.ptr(ws), ws_bytes,
-                                           V, H, _lib.stream()), "mpnn_gru_update_bwd_f32")
+    _lib.check(_timed("gru_update_bwd", lambda: lib.mpnn_gru_update_bwd_f32(
+        _lib.fptr(dout), _lib.fptr(m), _lib.fptr(h), _lib.fptr(mask), _lib.fptr(W_ih), _lib.fptr(W_hh),
+        _lib.fptr(saved), _lib.fptr(dm), _lib.fptr(dh), _lib.fptr(dW_ih), _lib.fptr(dW_hh), _lib.fptr(db_ih),
+        _lib.fptr(db_hh), _lib.ptr(ws), ws_bytes, V, H, _lib.stream())), "mpnn_gru_update_bwd_f32")
     return dm, dh, dW_ih, dW_hh, db_ih, db_hh
 
 
@@ -253,10 +269,10 @@ class MessageAggregate(torch.autograd.Function):
             lib = _lib.load()
             dA = torch.zeros_like(A)
             if g.num_edges:
-                _lib.check(lib.mpnn_edge_message_agg_bwd_da_f32(
+                _lib.check(_timed("message_aggregate_bwd", lambda: lib.mpnn_edge_message_agg_bwd_da_f32(
                     _lib.fptr(dout), _lib.fptr(h), _lib.iptr(g.col_idx), _lib.iptr(g.edge_dst), _lib.fptr(w),
                     _lib.iptr(g.order), _lib.iptr(g.type_ptr), _lib.fptr(gate), _lib.fptr(dA), g.num_nodes,
-                    g.num_edges, K, nf, mf, _lib.stream()), "mpnn_edge_message_agg_bwd_da_f32")
+                    g.num_edges, K, nf, mf, _lib.stream())), "mpnn_edge_message_agg_bwd_da_f32")
             return None, dA, None, None, None
         if (gate is not None and ctx.needs_input_grad[2] and not ctx.needs_input_grad[0] and mf == nf
                 and mf in (64, 128) and K <= 64 and os.environ.get("MPNN_GRU_MATH") != "fp32"):

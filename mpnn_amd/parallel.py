@@ -105,3 +105,43 @@ def synced_masked_batch_norm(x, mask, weight=None, bias=None, eps=1e-5, masked_m
     else:                                # MaskBatchNorm: mask inside, no parameters
         out = c / scale
     return out.view(x.shape), mean, var
+
+
+def strong_scaling_shard(num_chunks, chunk_mols, rank, world, seed=317, dist_name="drug", edge_features=4,
+                         micro_mols=None):
+    """This rank's share of ONE fixed global set of num_chunks * chunk_mols synthetic molecules (BASELINE configs[3]:
+    8 x 125k = 1 M), for strong-scaling runs: the same molecules at every world size, partitioned by graph.
+
+    The set is generated chunk by chunk (chunk c = synth.make_molecules(chunk_mols, seed=seed + c), topology only) so
+    no rank ever holds 1 M molecules' features; `shard_by_edges` over ALL molecules' edge counts gives every rank a
+    balanced list of global molecule ids; the rank's molecules are gathered chunk by chunk and cut into micro-batches
+    of at most `micro_mols` molecules (default chunk_mols: what one GPU holds resident for one forward + backward).
+
+    Returns (micro_batches, info): micro_batches = [(MolBatch without features, atom keys int64 for
+    synth.hashed_features)], info = dict(global_mols, global_edges, local_mols, local_edges)."""
+    from . import synth
+    micro_mols = int(micro_mols or chunk_mols)
+    chunks = [synth.make_molecules(chunk_mols, 0, seed=seed + c, dist=dist_name, edge_features=edge_features)
+              for c in range(num_chunks)]
+    per_mol = np.concatenate([np.add.reduceat(np.diff(c.row_ptr).astype(np.int64), c.atom_ptr[:-1].astype(np.int64))
+                              for c in chunks])
+    mine = shard_by_edges(per_mol, world)[rank]                       # global ids, ascending
+    parts, gids = [], []
+    for c, chunk in enumerate(chunks):
+        lo, hi = c * chunk_mols, (c + 1) * chunk_mols
+        sel = mine[(mine >= lo) & (mine < hi)]
+        if sel.size:
+            parts.append(synth.select(chunk, sel - lo) if sel.size < chunk_mols else chunk)
+            gids.append(sel)
+    local = synth.concat(parts)
+    gids = np.concatenate(gids)
+    nmb = max(1, -(-local.num_mols // micro_mols))
+    bounds = np.linspace(0, local.num_mols, nmb + 1).astype(np.int64)
+    micro = []
+    for i in range(nmb):
+        ids = np.arange(bounds[i], bounds[i + 1])
+        mb = local if nmb == 1 else synth.select(local, ids)
+        micro.append((mb, synth.hashed_atom_keys(gids[ids], mb.n_atoms)))
+    info = {"global_mols": int(per_mol.shape[0]), "global_edges": int(per_mol.sum()),
+            "local_mols": int(local.num_mols), "local_edges": int(local.num_edges)}
+    return micro, info

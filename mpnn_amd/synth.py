@@ -276,3 +276,50 @@ def to_dense(batch, numeric_tail=0):
         out["afm"] = afm[..., : nf - numeric_tail].copy()
         out["nafm"] = afm[..., nf - numeric_tail:].copy()
     return out
+
+
+def concat(batches):
+    """One MolBatch holding the molecules of `batches` in order (discrete bond types only: the batches must share
+    their `type_feat` table)."""
+    if len(batches) == 1:
+        return batches[0]
+    if any(b.edge_feat is not None for b in batches):
+        raise ValueError("concat: continuous bond features are not supported")
+    n = np.concatenate([b.n_atoms for b in batches]).astype(np.int64)
+    atom_ptr = np.zeros(n.shape[0] + 1, dtype=np.int64)
+    np.cumsum(n, out=atom_ptr[1:])
+    a_off = np.cumsum([0] + [b.num_atoms for b in batches])
+    e_off = np.cumsum([0] + [b.num_edges for b in batches])
+    row_ptr = np.concatenate([batches[0].row_ptr[:1].astype(np.int64)] +
+                             [b.row_ptr[1:].astype(np.int64) + e_off[i] for i, b in enumerate(batches)])
+    col = np.concatenate([b.col_idx.astype(np.int64) + a_off[i] for i, b in enumerate(batches)])
+    return MolBatch(n_atoms=n.astype(np.int32), atom_ptr=atom_ptr.astype(np.int32), row_ptr=row_ptr.astype(np.int32),
+                    col_idx=col.astype(np.int32), bond_type=np.concatenate([b.bond_type for b in batches]),
+                    type_feat=batches[0].type_feat, edge_feat=None,
+                    atom_feat=np.concatenate([b.atom_feat for b in batches], axis=0))
+
+
+def hashed_atom_keys(mol_gid, n_atoms):
+    """int64 key of every atom of a batch = (global molecule id, index inside the molecule): a feature generator keyed
+    on it gives a molecule the same features whichever rank / micro-batch it lands in."""
+    mol_gid = np.asarray(mol_gid, dtype=np.int64)
+    n = np.asarray(n_atoms, dtype=np.int64)
+    ptr = np.zeros(n.shape[0] + 1, dtype=np.int64)
+    np.cumsum(n, out=ptr[1:])
+    rep = np.repeat(np.arange(n.shape[0]), n)
+    return mol_gid[rep] * 256 + (np.arange(int(ptr[-1])) - ptr[rep])
+
+
+def hashed_features(keys, node_features, device=None):
+    """(V, nf) uniform(-1, 1) fp32 features as a pure function of (atom key, column), computed with torch integer ops
+    on `device` (a 32-bit mix of key * nf + column): 1 M molecules x 128 features never exist on the host."""
+    import torch
+    k = torch.as_tensor(keys, dtype=torch.int64, device=device)
+    x = (k.unsqueeze(1) * int(node_features) + torch.arange(int(node_features), device=k.device, dtype=torch.int64))
+    m = 0xFFFFFFFF
+    x = (x ^ (x >> 16)) & m
+    x = (x * 0x45D9F3B) & m
+    x = (x ^ (x >> 16)) & m
+    x = (x * 0x45D9F3B) & m
+    x = (x ^ (x >> 16)) & m
+    return (x.to(torch.float32) * (2.0 / 4294967296.0) - 1.0).contiguous()

@@ -253,3 +253,155 @@ def test_h128_fused_message_aggregate_weight_gradient_full_size(dev, c4s, weight
             val = val * w.double()[idx].unsqueeze(1)
         fwd = fwd.index_add(0, dst[idx], val)
     assert max_err(agg.detach(), fwd) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------ hidden 64 at the TIMED size
+# bench.py's c2 launches put ~366 32-atom tiles on every persistent block of the H = 64 GRU backward kernel (double-
+# buffered tile loop, clamped duplicate tile, one atomic flush per block) and thousands of tiles on the weight-gradient
+# kernel of message+sum; the small fixtures run one tile per block.  These run the real c2 graph (V ~ 3.0 M atoms,
+# E ~ 6.0 M edges) with random weights and a partial mask against float64 autograd on the device.
+def test_h64_gru_forward_backward_full_size(dev, c2):
+    from mpnn_amd import ops
+    mb, g, h = c2
+    V, H = h.shape
+    assert V > 2_900_000 and H == 64
+    gen = torch.Generator(device=dev).manual_seed(17)
+    m = torch.randn(V, H, device=dev, generator=gen)
+    mask = (torch.rand(V, 1, device=dev, generator=gen) > 0.1).float()
+    bound = (6.0 / (H + 3 * H)) ** 0.5
+    W_ih = (torch.rand(H, 3 * H, device=dev, generator=gen) * 2 - 1) * bound
+    W_hh = (torch.rand(H, 3 * H, device=dev, generator=gen) * 2 - 1) * bound
+    b_ih = torch.rand(3 * H, device=dev, generator=gen) * 0.2 - 0.1
+    b_hh = torch.rand(3 * H, device=dev, generator=gen) * 0.2 - 0.1
+    dout = torch.randn(V, H, device=dev, generator=gen)
+    leaves = [t.clone().requires_grad_(True) for t in (m, h, W_ih, W_hh, b_ih, b_hh)]
+    out = ops.gru_update(leaves[0], leaves[1], mask, *leaves[2:])
+    out.backward(dout)
+    with torch.no_grad():                                     # the inference instantiation (no gate dump) as well
+        out_inf = ops.gru_update(m, h, mask, W_ih, W_hh, b_ih, b_hh)
+    ref_leaves = [t.double().requires_grad_(True) for t in (m, h, W_ih, W_hh, b_ih, b_hh)]
+    ref = _gru_ref64(ref_leaves[0], ref_leaves[1], mask.double(), *ref_leaves[2:])
+    ref.backward(dout.double())
+    assert max_err(out.detach(), ref.detach()) < 1e-5
+    assert max_err(out_inf, ref.detach()) < 1e-5
+    assert float((out.detach() * (1 - mask)).abs().max()) == 0.0          # masked atoms exactly zero
+    for got, want, name in zip(leaves, ref_leaves, ("dm", "dh", "dW_ih", "dW_hh", "db_ih", "db_hh")):
+        scale = max(1.0, float(want.grad.abs().max()))
+        tol = 1e-5 if name in ("dm", "dh") else 2e-5            # weight gradients sum 3 M terms
+        assert max_err(got.grad, want.grad) / scale < tol, name
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_h64_fused_message_aggregate_full_size(dev, c2, weighted):
+    """Message + adjacency-weighted sum as one node at hidden 64 on the c2 graph: forward rows and the weight gradient
+    dA (the no-dmsg path the training step takes) against float64."""
+    from mpnn_amd import ops
+    mb, g, h = c2
+    E, V, F, K = g.num_edges, g.num_nodes, 64, int(g.type_feat.shape[0])
+    gen = torch.Generator(device=dev).manual_seed(18)
+    A = torch.randn(K, F, F, device=dev, generator=gen) * (1.0 / F ** 0.5)
+    w = (torch.rand(E, device=dev, generator=gen) + 0.5) if weighted else None
+    dagg = torch.randn(V, F, device=dev, generator=gen)
+    Al = A.clone().requires_grad_(True)
+    agg = ops.message_aggregate(h, Al, g, w)
+    agg.backward(dagg)
+    src, dst, typ = g.col_idx.long(), g.edge_dst.long(), g.edge_type.long()
+    fwd = torch.zeros(V, F, dtype=torch.float64, device=dev)
+    ref = []
+    for k in range(K):
+        idx = (typ == k).nonzero().squeeze(1)
+        x = h.double()[src[idx]]
+        y = dagg.double()[dst[idx]]
+        if weighted:
+            y = y * w.double()[idx].unsqueeze(1)
+        ref.append(y.t() @ x)
+        val = x @ A.double()[k].t()
+        if weighted:
+            val = val * w.double()[idx].unsqueeze(1)
+        fwd = fwd.index_add(0, dst[idx], val)
+    ref = torch.stack(ref)
+    assert max_err(agg.detach(), fwd) < 1e-5
+    assert max_err(Al.grad, ref) / max(1.0, float(ref.abs().max())) < 2e-5
+    # with gradients wanted for the node features too (the generic backward: d(msg), dx, transposed scatter)
+    hl = h.clone().requires_grad_(True)
+    agg2 = ops.message_aggregate(hl, A, g, w)
+    agg2.backward(dagg)
+    dh = torch.zeros(V, F, dtype=torch.float64, device=dev)
+    for k in range(K):
+        idx = (typ == k).nonzero().squeeze(1)
+        y = dagg.double()[dst[idx]]
+        if weighted:
+            y = y * w.double()[idx].unsqueeze(1)
+        dh = dh.index_add(0, src[idx], y @ A.double()[k])
+    assert max_err(hl.grad, dh) / max(1.0, float(dh.abs().max())) < 1e-5
+
+
+def test_c2_basic_model_training_step_against_float64(dev, c2):
+    """The whole timed step on the c2 batch -- 3 rounds of message -> sum -> GRU with random (non-zero-bias) weights,
+    backward from a random cotangent -- against a float64 restatement on the device: final node state and the gradients
+    of every hot-path parameter."""
+    from mpnn_amd.models.basic_model import BasicModel
+    mb, g, h = c2
+    V, H, T = g.num_nodes, 64, 3
+    torch.manual_seed(5)
+    model = BasicModel(H, 4, H, 50, 8, message_opts={}, agg_opts={}, update_opts={}, readout_opts={},
+                       message_steps=T).to(dev)
+    with torch.no_grad():
+        # a tower that carries signal through its 50 aliased layers (kaiming, as test_lipo.py:132 initialises it),
+        # non-zero biases everywhere (so A0 != 0), and a last layer scaled to put the bond matrices at O(1/4)
+        for mod in model.mf.edge_map.modules():
+            if isinstance(mod, torch.nn.Linear):
+                torch.nn.init.kaiming_uniform_(mod.weight, nonlinearity="relu")
+        for n, p in model.named_parameters():
+            if n.endswith("bias") or "bias_" in n:
+                p.uniform_(-0.05, 0.05)
+        A_now, _ = model.mf._edge_matrices(g)
+        last = model.mf.edge_map[-1]
+        sc = 0.25 / float(A_now.abs().max())
+        last.weight.mul_(sc)
+        last.bias.mul_(sc)
+    mask = torch.ones(V, 1, device=dev)
+    cot = torch.randn(V, H, device=dev) / V ** 0.5
+    state, _ = model.message_passing(h, g, g, mask)
+    state.backward(cot)
+    # float64 restatement: tower on the K+1 bond rows, per-type dense products, index_add neighbour sum, GRU
+    p64 = {n: p.detach().double().requires_grad_(True) for n, p in model.named_parameters() if not n.startswith("of.")}
+    rows = torch.cat([g.type_feat.new_zeros(1, 4), g.type_feat]).double()
+    x = rows
+    mods = list(model.mf.edge_map)
+    i = 0
+    while i < len(mods):
+        mod = mods[i]
+        if isinstance(mod, torch.nn.Linear):
+            x = x @ p64["mf.edge_map.%d.weight" % i].t() + p64["mf.edge_map.%d.bias" % i]
+        elif isinstance(mod, torch.nn.Sequential):
+            first = next(j for j, mm in enumerate(mods) if mm is mod)        # the 50 aliases share one tensor
+            x = torch.relu(x @ p64["mf.edge_map.%d.0.weight" % first].t())
+        else:
+            x = torch.relu(x)
+        i += 1
+    A = x.view(-1, H, H)[1:]
+    src, dst, typ = g.col_idx.long(), g.edge_dst.long(), g.edge_type.long()
+    h64 = h.double()
+    agg = torch.zeros(V, H, dtype=torch.float64, device=dev)
+    for k in range(A.shape[0]):
+        idx = (typ == k).nonzero().squeeze(1)
+        agg = agg.index_add(0, dst[idx], h64[src[idx]] @ A[k].t())
+    st = h64
+    for _ in range(T):
+        st = _gru_ref64(agg, st, mask.double(), p64["uf.gru_cell.weight_ih"], p64["uf.gru_cell.weight_hh"],
+                        p64["uf.gru_cell.bias_ih"], p64["uf.gru_cell.bias_hh"])
+    st.backward(cot.double())
+    assert max_err(state.detach(), st.detach()) < 2e-5
+    seen = set()
+    for n, p in model.named_parameters():
+        if n.startswith("of.") or p.data_ptr() in seen or n == "mf.message_bias":
+            continue
+        seen.add(p.data_ptr())
+        first = n
+        want = p64[first].grad
+        if want is None:
+            continue
+        # aliased tower layers: the float64 graph accumulated every alias into the first name
+        scale = max(1e-3, float(want.abs().max()))
+        assert max_err(p.grad, want) / scale < 5e-4, n

@@ -133,3 +133,31 @@ def test_synced_masked_batch_norm_matches_single_process():
     assert np.abs(gx1 - xr2.grad.numpy()).max() < 2e-5
     assert np.abs(got[0]["bn1d"][4] + got[1]["bn1d"][4] - params["weight"].grad.numpy()).max() < 2e-5
     assert np.abs(got[0]["bn1d"][2] - got[1]["bn1d"][2]).max() == 0          # both ranks hold the same moments
+
+
+def test_strong_scaling_shard_is_a_partition_of_one_global_set():
+    """parallel.strong_scaling_shard: whatever the world size, the ranks' micro-batches hold every molecule of the
+    SAME global set exactly once, balanced by edge count, with features keyed on the global molecule id."""
+    ref_keys = None
+    for world in (1, 2, 4):
+        keys, edges, loads = [], 0, []
+        for r in range(world):
+            micro, info = parallel.strong_scaling_shard(4, 300, r, world, micro_mols=250)
+            assert info["global_mols"] == 1200
+            assert all(m.num_mols <= 250 for m, _ in micro)
+            assert sum(m.num_mols for m, _ in micro) == info["local_mols"]
+            for m, k in micro:
+                assert k.shape[0] == m.num_atoms and m.atom_feat.shape == (m.num_atoms, 0)
+                assert int(m.col_idx.max()) < m.num_atoms and m.row_ptr[-1] == m.num_edges
+            keys.append(np.concatenate([k for _, k in micro]))
+            loads.append(info["local_edges"])
+            edges += info["local_edges"]
+        allk = np.sort(np.concatenate(keys))
+        assert np.unique(allk).shape[0] == allk.shape[0] and edges == info["global_edges"]
+        assert max(loads) - min(loads) <= 120
+        if ref_keys is None:
+            ref_keys = allk
+        assert np.array_equal(allk, ref_keys)
+    f = synth.hashed_features(ref_keys[:500], 16)
+    assert f.shape == (500, 16) and float(f.abs().max()) <= 1.0 and abs(float(f.mean())) < 0.05
+    assert torch.equal(f[:7], synth.hashed_features(ref_keys[:7], 16))

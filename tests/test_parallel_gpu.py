@@ -1,0 +1,128 @@
+"""Data parallelism on the HIP path itself: 2 ranks (gloo, both on cuda:0) run BasicModel on their molecule shards,
+sum gradients through parallel.GradientBucket, and must reproduce the single-process gradient of the whole batch."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+H, T, G = 64, 3, 600
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model(dev):
+    from mpnn_amd.models.basic_model import BasicModel
+    torch.manual_seed(23)
+    model = BasicModel(H, 4, H, 50, 8, message_opts={}, agg_opts={}, update_opts={}, readout_opts={},
+                       message_steps=T).to(dev)
+    with torch.no_grad():
+        for mod in model.mf.edge_map.modules():
+            if isinstance(mod, torch.nn.Linear):
+                torch.nn.init.kaiming_uniform_(mod.weight, nonlinearity="relu")
+        last = model.mf.edge_map[-1]
+        last.weight.mul_(1e-3)
+    return model
+
+
+def _loss_grad(model, mb, dev, total_mols):
+    """Gradient of (1/total_mols) * sum over this batch's molecules of sum(node_state^2) into a GradientBucket."""
+    from mpnn_amd import parallel
+    from mpnn_amd.graph import MolGraph
+    hot = [p for n, p in model.named_parameters() if not n.startswith("of.")]
+    bucket = parallel.GradientBucket(hot)
+    bucket.zero()
+    g = MolGraph.from_molbatch(mb, dev)
+    afm = torch.from_numpy(mb.atom_feat).to(dev)
+    state, _ = model.message_passing(afm, g, g, torch.ones(mb.num_atoms, 1, device=dev))
+    ((state * state).sum() / total_mols).backward()
+    return bucket
+
+
+def _worker(rank, world, port, out):
+    import torch.distributed as dist
+    from mpnn_amd import parallel, synth
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    mb = synth.make_molecules(G, H, seed=41)
+    per_mol = np.add.reduceat(np.diff(mb.row_ptr), mb.atom_ptr[:-1])
+    ids = parallel.shard_by_edges(per_mol, world)[rank]
+    total = parallel.global_count(len(ids), dev)
+    bucket = _loss_grad(_model(dev), synth.select(mb, ids), dev, total)
+    flat = bucket.all_reduce().detach().cpu().numpy()
+    if rank == 0:
+        out.put((flat, total))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_hip_gradient_equals_single_process():
+    from mpnn_amd import synth
+    dev = torch.device("cuda:0")
+    mb = synth.make_molecules(G, H, seed=41)
+    ref = _loss_grad(_model(dev), mb, dev, float(G)).flat.detach().cpu().numpy()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, total = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert total == G
+    scale = max(1e-6, float(np.abs(ref).max()))
+    assert np.abs(got - ref).max() / scale < 2e-5        # same terms, summed in two parts
+
+
+def _run_bench(extra):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--workload", "tiny", "--steps", "2", "--warmup", "1",
+                        "--no-cpu"] + extra, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_bench_launches_its_own_ranks():
+    """`bench.py --gpus 2` without a launcher must report n_gpus 2 (it starts its ranks as a child torchrun; on this
+    one-GPU box they share the device over gloo and the line says so)."""
+    d = _run_bench(["--gpus", "2"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["parallelism"] == "dp2"
+    sh = d["sharding"]
+    assert sh["global_mols"] == 4000 and sh["allreduce_ms"] is not None
+    if torch.cuda.device_count() < 2:
+        assert "rehearsal" in d
+
+
+def test_bench_strong_scaling_partitions_one_global_set():
+    one = _run_bench(["--scaling", "strong"])
+    two = _run_bench(["--scaling", "strong", "--gpus", "2"])
+    assert one["scaling"] == two["scaling"] == "strong"
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert one["sharding"]["global_mols"] == two["sharding"]["global_mols"] == 16000
+    assert one["sharding"]["global_edges"] == two["sharding"]["global_edges"]            # the same molecules
+    assert two["sharding"]["edges_per_rank_max"] - two["sharding"]["edges_per_rank_min"] <= 200
+    assert one["config"]["micro_batches_per_step"] == 8 and two["config"]["micro_batches_per_step"] == 4
