@@ -28,7 +28,6 @@ const Switches& switches() {
         s.gru_bwd_fp32tile = getenv("MPNN_GRU_BWD_FP32TILE") != nullptr;
         const char* v = getenv("MPNN_SEGSUM_VARIANT");
         s.segsum_variant = v ? atoi(v) : 3;
-        s.unfused_message = getenv("MPNN_UNFUSED_MESSAGE") != nullptr;
         return s;
     }();
     return sw;

@@ -47,7 +47,6 @@ struct Switches {
     bool gru_bwd_uniform;    // MPNN_GRU_BWD_UNIFORM: all-waves-identical GRU backward at width 64
     bool gru_bwd_fp32tile;   // MPNN_GRU_BWD_FP32TILE: fp32 LDS tile in the GRU backward at width 64
     int segsum_variant;      // MPNN_SEGSUM_VARIANT: 1 = one atom per lane group, 2 = cached loads/stores, 3 = default
-    bool unfused_message;    // MPNN_UNFUSED_MESSAGE: message rows to HBM + segmented sum instead of the tile kernel
 };
 const Switches& switches();
 

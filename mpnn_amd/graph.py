@@ -25,6 +25,78 @@ def _i32(t):
     return t.to(torch.int32).contiguous()
 
 
+class TilePlan:
+    """Work list of the fused message+sum kernels (csrc/message_tile.hip).
+
+    Atoms are cut into molecule-aligned TILES of at most `tile_atoms` atoms (tile_ptr), a tile into four SUB-TILES of
+    ceil(n/4) consecutive atoms (one per wave).  The edges whose destination lies in a sub-tile are grouped by bond
+    type -- edge order kept inside a type -- and each group is padded to whole ROW-TILES of 16 slots:
+
+        rt_ptr[4*T+1]   row-tiles of sub-tile s are [rt_ptr[s], rt_ptr[s+1])
+        rt_type[R]      bond type of each row-tile
+        slots[16*R]     (source atom - tile start) | (destination atom - sub-tile start) << 8; padding = sink row 32
+        slot_eid[16*R]  edge id of the slot (-1 = padding): per-edge weights / gates are fetched through it
+    """
+
+    def __init__(self, tile_ptr, rt_ptr, rt_type, slots, slot_eid, tile_atoms):
+        self.tile_ptr, self.rt_ptr, self.rt_type, self.slots, self.slot_eid = tile_ptr, rt_ptr, rt_type, slots, slot_eid
+        self.num_tiles = int(tile_ptr.shape[0]) - 1
+        self.num_row_tiles = int(rt_type.shape[0])
+        self.tile_atoms = tile_atoms
+        # what one launch reads: tile and row-tile words once, every slot word twice (gather lane + accumulator lane)
+        self.nbytes = 4 * (self.num_tiles + 1 + 4 * self.num_tiles + 1 + self.num_row_tiles + 2 * 16 * self.num_row_tiles)
+
+    @classmethod
+    def build(cls, g):
+        lib = _lib.load()
+        tv, kmax = lib.mpnn_message_aggregate_tile_atoms(), lib.mpnn_message_aggregate_max_types()
+        if g.num_types > kmax or g.num_nodes == 0 or g.num_graphs == 0:
+            return None
+        import ctypes
+        gp = g.graph_ptr.to("cpu", torch.int32).contiguous()
+        tp = torch.empty(g.num_graphs + 2, dtype=torch.int32)
+        nt = lib.mpnn_plan_tiles_host(ctypes.c_void_p(gp.data_ptr()), g.num_graphs, tv, ctypes.c_void_p(tp.data_ptr()))
+        if nt <= 0:
+            return None                                   # a molecule larger than a tile
+        dev = g.device
+        tile_ptr = tp[:nt + 1].to(dev)
+        tp64 = tile_ptr.to(torch.int64)
+        n_t = tp64[1:] - tp64[:-1]
+        ss_t = torch.clamp((n_t + 3) // 4, min=1)
+        tile_of_atom = torch.repeat_interleave(torch.arange(nt, device=dev), n_t, output_size=g.num_nodes)
+        local = torch.arange(g.num_nodes, device=dev) - tp64[tile_of_atom]
+        sub = local // ss_t[tile_of_atom]
+        dst = g.edge_dst.to(torch.int64)
+        src = g.col_idx.to(torch.int64)
+        et = g.edge_type.to(torch.int64)
+        K = g.num_types
+        E = g.num_edges
+        sid = tile_of_atom[dst] * 4 + sub[dst]                                  # sub-tile of every edge (non-decreasing)
+        src_local = src - tp64[tile_of_atom[dst]]
+        if E and (int(src_local.min()) < 0 or int(src_local.max()) >= tv):
+            return None                                   # an edge leaves its tile: not a batch of separate molecules
+        key = sid * K + et
+        order = torch.sort(key, stable=True).indices                           # edge order kept inside (sub-tile, type)
+        cnt = torch.bincount(key, minlength=4 * nt * K)
+        rts = (cnt + 15) // 16
+        rt_start = torch.zeros(4 * nt * K + 1, dtype=torch.int64, device=dev)
+        rt_start[1:] = torch.cumsum(rts, 0)
+        grp_start = torch.zeros(4 * nt * K + 1, dtype=torch.int64, device=dev)
+        grp_start[1:] = torch.cumsum(cnt, 0)
+        R = int(rt_start[-1].item())
+        rt_ptr = _i32(rt_start[::K])
+        rt_type = _i32(torch.repeat_interleave(torch.arange(4 * nt * K, device=dev) % K, rts, output_size=R))
+        skey = key[order]
+        pos = rt_start[skey] * 16 + (torch.arange(E, device=dev) - grp_start[skey])
+        dst_sub = local[dst] - sub[dst] * ss_t[tile_of_atom[dst]]
+        word = (src_local | (dst_sub << 8))[order]
+        slots = torch.full((16 * R,), 32 << 8, dtype=torch.int64, device=dev)
+        slots[pos] = word
+        slot_eid = torch.full((16 * R,), -1, dtype=torch.int64, device=dev)
+        slot_eid[pos] = order
+        return cls(tile_ptr, rt_ptr, rt_type, _i32(slots), _i32(slot_eid), tv)
+
+
 class MolGraph:
     def __init__(self, row_ptr, col_idx, edge_weight, edge_type, type_feat, graph_ptr, dense_shape=None,
                  edge_feat=None):
@@ -49,6 +121,7 @@ class MolGraph:
         self._pad_size = None
         self._unit_weights = None
         self._adj_ptr = None
+        self._tile_plan = None
 
     def with_type_feat(self, type_feat):
         """The same graph with another (K, ef) table of bond-feature rows (index arrays and their caches shared)."""
@@ -61,12 +134,21 @@ class MolGraph:
     def prepare(self):
         """Build every derived index array now (type order, transposed graph, destination list, tile plan), so
         that none of it lands inside a timed or captured region."""
-        self.order, self.type_ptr, self.transpose, self.edge_dst, self.agg_weight
+        self.order, self.type_ptr, self.transpose, self.edge_dst, self.agg_weight, self.tile_plan
         return self
 
     def plan_bytes(self):
         """Bytes of index data the fused message+sum kernel reads per launch (0 without a tile plan)."""
-        return 0
+        p = self.tile_plan
+        return 0 if p is None else p.nbytes
+
+    @property
+    def tile_plan(self):
+        """TilePlan for the fused message+sum kernels, or None when the batch does not fit them (a molecule larger than a
+        tile, too many bond types).  Built once per batch, like the CSR."""
+        if self._tile_plan is None:
+            self._tile_plan = TilePlan.build(self) or False
+        return self._tile_plan or None
 
     # ------------------------------------------------------------------ derived index arrays
     @property

@@ -65,7 +65,8 @@ def math_mode():
 
 
 def mfma_per_product():
-    """16-bit MFMAs issued per fp32 product by the dense contractions (0 = the fp32 matrix pipe itself)."""
+    """16-bit MFMAs issued per fp32 product by the GRU / per-edge message contractions (0 = the fp32 matrix pipe
+    itself).  The fused message+sum tile kernel uses a two-way fp16 split (3 MFMAs per product) in the default mode."""
     return {"fp32": 0, "bf16x6": 6}[math_mode()]
 
 
@@ -124,6 +125,32 @@ def edge_message_raw(h, A, graph, gate=None):
         _lib.fptr(gate), _lib.fptr(msg), graph.num_nodes, E, K, nf, mf, _lib.stream())),
         "mpnn_edge_message_f32")
     return msg
+
+
+def tile_kernel_applies(A, gate, graph):
+    """The fused message+sum tile kernel covers: no gate, nf = mf = 64, a batch of separate molecules of at most one
+    tile each with few bond types (graph.tile_plan), default math.  MPNN_UNFUSED_MESSAGE=1 keeps the two-kernel path
+    (message rows to HBM, then the segmented-sum aggregator) for A/B runs."""
+    K, mf, nf = (int(s) for s in A.shape)
+    if gate is not None or mf != 64 or nf != 64 or math_mode() == "fp32" or os.environ.get("MPNN_UNFUSED_MESSAGE"):
+        return False
+    plan = graph.tile_plan
+    return plan is not None and K == graph.num_types
+
+
+def message_aggregate_tile_raw(h, A, w, graph):
+    lib = _lib.load()
+    K, mf, nf = (int(s) for s in A.shape)
+    V = graph.num_nodes
+    plan = graph.tile_plan
+    out = _empty((V, mf), h)
+    if V == 0:
+        return out
+    _lib.check(_timed("message_aggregate", lambda: lib.mpnn_message_aggregate_f32(
+        _lib.fptr(h), _lib.fptr(A), _lib.fptr(w), _lib.iptr(plan.tile_ptr), _lib.iptr(plan.rt_ptr),
+        _lib.iptr(plan.rt_type), _lib.iptr(plan.slots), _lib.iptr(plan.slot_eid), _lib.fptr(out), V, plan.num_tiles,
+        K, nf, mf, _lib.stream())), "mpnn_message_aggregate_f32")
+    return out
 
 
 def edge_message_bwd_raw(h, A, graph, gate, dmsg, need_dx=True, need_dA=True):
@@ -252,6 +279,8 @@ class MessageAggregate(torch.autograd.Function):
         gate = gate.contiguous() if gate is not None else None
         ctx.graph = graph
         ctx.save_for_backward(h, A, gate, w)
+        if tile_kernel_applies(A, gate, graph):
+            return message_aggregate_tile_raw(h, A, w, graph)
         msg = edge_message_raw(h, A, graph, gate)
         return segsum_raw(msg, graph.row_ptr, w, graph.num_nodes)
 
