@@ -132,25 +132,30 @@ int mpnn_edge_message_agg_bwd_dgate_f32(const float* dagg, const float* A, const
 
 /*
  * Typed edge message FUSED with the neighbour sum, no (E, mf) message tensor in HBM:
- *   out[i, :] = sum_{e in row i} w[e] * A[type[e]] . h[src[e], :]          (w == NULL: plain sum)
+ *   out[i, :] = sum_{e in row i} A[type[e]] . h[src[e], :]
  * replaces: mpnn_functions/message/edge_network.py:50-51 (edge_embed.bmm(...): message and sum as one product),
  *           i.e. edge_network.py:40,52 composed with message_aggregators/adjacent_message_agg.py:18;
  *           also ggnn_msg_pass.py:30-31 (A = the bond-type table).
  * The edges arrive as a TILE PLAN (built once per batch from graph_ptr / row_ptr / src / type; layout in
  * mpnn_amd/graph.py::TilePlan): molecule-aligned tiles of at most mpnn_message_aggregate_tile_atoms() atoms whose h rows
- * are staged in LDS once, four sub-tiles per tile, each sub-tile's edges grouped by type into row-tiles of 16 slots.
- *   tile_ptr[T+1], rt_ptr[4T+1], rt_type[R], slots[16R], slot_eid[16R] (only read when w != NULL)
- * nf = mf = 64 and K <= mpnn_message_aggregate_max_types() only (MPNN_EINVAL otherwise: callers run mpnn_edge_message_f32
- * + mpnn_segsum_f32).  Sum order inside a row: types ascending, edge order within a type (deterministic).
+ * are staged in LDS once; the tile's atoms sorted by per-type in-degree and dealt in blocks of 16 (block B: sub-tile
+ * B % 4, destination block B / 4); a row-tile = the rank-th incoming type-k edge of each atom of one block.
+ *   tile_rec[T][16]   first atom, atoms, first row-tile of sub-tile 0, 1, 2, 3, end of sub-tile 3, zeros
+ *   tile_atom[T][128] atom id at every sorted position of the tile, -1 = none
+ *   slots[16R]        (source atom - first atom) | valid << 14 | bond type << 16 | destination block << 20; an empty
+ *                     slot names source row 128 (zeros); row-tiles in (tile, sub-tile, type, block, rank) order
+ * nf = mf = 64, K <= mpnn_message_aggregate_max_types(), at most mpnn_message_aggregate_max_row_tiles() row-tiles per
+ * sub-tile, unit edge weights only (callers run mpnn_edge_message_f32 + mpnn_segsum_f32 otherwise).  Sum order inside
+ * a row: types ascending, edge order within a type (deterministic).
  * mpnn_plan_tiles_host is a HOST helper (host pointers, no device work): greedy packing of whole molecules into
  * tiles; writes tile_ptr (capacity G+2) and returns the tile count, or -1 if a molecule exceeds max_atoms.
  */
 int64_t mpnn_plan_tiles_host(const int32_t* graph_ptr_host, int64_t G, int max_atoms, int32_t* tile_ptr_host);
 int mpnn_message_aggregate_tile_atoms(void);
 int mpnn_message_aggregate_max_types(void);
-int mpnn_message_aggregate_f32(const float* h, const float* A, const float* w /* [E] or NULL */,
-                               const int32_t* tile_ptr, const int32_t* rt_ptr, const int32_t* rt_type,
-                               const int32_t* slots, const int32_t* slot_eid, float* out,
+int mpnn_message_aggregate_max_row_tiles(void);
+int mpnn_message_aggregate_f32(const float* h, const float* A, const int32_t* tile_rec, const int32_t* tile_atom,
+                               const int32_t* slots, float* out,
                                int64_t V, int64_t num_tiles, int K, int nf, int mf, void* stream);
 
 /* ------------------------------------------------------------------ edge tower ----- */

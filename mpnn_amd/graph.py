@@ -26,31 +26,46 @@ def _i32(t):
 
 
 class TilePlan:
-    """Work list of the fused message+sum kernels (csrc/message_tile.hip).
+    """Work list of the fused message+sum kernel (csrc/message_tile.hip).
 
-    Atoms are cut into molecule-aligned TILES of at most `tile_atoms` atoms (tile_ptr), a tile into four SUB-TILES of
-    ceil(n/4) consecutive atoms (one per wave).  The edges whose destination lies in a sub-tile are grouped by bond
-    type -- edge order kept inside a type -- and each group is padded to whole ROW-TILES of 16 slots:
+    Atoms are cut into molecule-aligned TILES of at most `tile_atoms` atoms (greedy, whole molecules).  Inside a tile
+    the atoms are SORTED by their per-type in-degree pattern and dealt in BLOCKS of 16 consecutive sorted atoms; block
+    B belongs to sub-tile B % 4 (one wave pair each) as its destination block B // 4.  A ROW-TILE is then
+    "the rank-th incoming edge of type k of each of the block's 16 atoms": row m of the contraction IS destination atom
+    m of the block, so the contraction's accumulator rows are output rows and nothing has to be summed afterwards.  A
+    block needs max-over-its-atoms(count of type-k edges) row-tiles for type k; sorting atoms by pattern keeps that
+    close to what each atom really has (the slot fill).
 
-        rt_ptr[4*T+1]   row-tiles of sub-tile s are [rt_ptr[s], rt_ptr[s+1])
-        rt_type[R]      bond type of each row-tile
-        slots[16*R]     (source atom - tile start) | (destination atom - sub-tile start) << 8; padding = sink row 32
-        slot_eid[16*R]  edge id of the slot (-1 = padding): per-edge weights / gates are fetched through it
+        tile_rec[T,16]  first atom, atoms, first row-tile of sub-tile 0..3, end of sub-tile 3, 0, 8 x 0
+        tile_atom[T,128] atom id of every sorted position of the tile (block B = position // 16), -1 = none
+        slots[16*R]     row-tiles in (tile, sub-tile, type, destination block, rank) order, 16 words each:
+                        (source atom - tile start) | valid << 14 | bond type << 16 | destination block << 20;
+                        an empty slot reads source row `tile_atoms` (a row of zeros in the kernel's LDS image)
+        slot_eid[16*R]  edge id of the slot (-1 = empty); tests and the backward use it
     """
 
-    def __init__(self, tile_ptr, rt_ptr, rt_type, slots, slot_eid, tile_atoms):
-        self.tile_ptr, self.rt_ptr, self.rt_type, self.slots, self.slot_eid = tile_ptr, rt_ptr, rt_type, slots, slot_eid
+    def __init__(self, tile_ptr, tile_atom, rt_ptr, slots, slot_eid, tile_atoms):
+        self.tile_ptr, self.tile_atom, self.rt_ptr, self.slots, self.slot_eid = tile_ptr, tile_atom, rt_ptr, slots, slot_eid
         self.num_tiles = int(tile_ptr.shape[0]) - 1
-        self.num_row_tiles = int(rt_type.shape[0])
+        self.num_row_tiles = int(slots.shape[0]) // 16
         self.tile_atoms = tile_atoms
-        # what one launch reads: tile and row-tile words once, every slot word twice (gather lane + accumulator lane)
-        self.nbytes = 4 * (self.num_tiles + 1 + 4 * self.num_tiles + 1 + self.num_row_tiles + 2 * 16 * self.num_row_tiles)
+        T = self.num_tiles
+        rec = torch.zeros(T, 16, dtype=torch.int32, device=tile_ptr.device)
+        rec[:, 0] = tile_ptr[:-1]
+        rec[:, 1] = tile_ptr[1:] - tile_ptr[:-1]
+        rec[:, 2:6] = rt_ptr[:4 * T].view(T, 4)
+        rec[:, 6] = rt_ptr[4::4]
+        self.tile_rec = rec.contiguous()
+        # what one launch reads: a record and the sorted-atom list per tile, every slot word once
+        self.nbytes = 4 * (16 * T + tile_atoms * T + 16 * self.num_row_tiles)
 
     @classmethod
     def build(cls, g):
         lib = _lib.load()
         tv, kmax = lib.mpnn_message_aggregate_tile_atoms(), lib.mpnn_message_aggregate_max_types()
-        if g.num_types > kmax or g.num_nodes == 0 or g.num_graphs == 0:
+        rtmax = lib.mpnn_message_aggregate_max_row_tiles()
+        K, E, V = g.num_types, g.num_edges, g.num_nodes
+        if K > kmax or V == 0 or g.num_graphs == 0:
             return None
         import ctypes
         gp = g.graph_ptr.to("cpu", torch.int32).contiguous()
@@ -62,39 +77,62 @@ class TilePlan:
         tile_ptr = tp[:nt + 1].to(dev)
         tp64 = tile_ptr.to(torch.int64)
         n_t = tp64[1:] - tp64[:-1]
-        ss_t = torch.clamp((n_t + 3) // 4, min=1)
-        tile_of_atom = torch.repeat_interleave(torch.arange(nt, device=dev), n_t, output_size=g.num_nodes)
-        local = torch.arange(g.num_nodes, device=dev) - tp64[tile_of_atom]
-        sub = local // ss_t[tile_of_atom]
+        tile_of_atom = torch.repeat_interleave(torch.arange(nt, device=dev), n_t, output_size=V)
         dst = g.edge_dst.to(torch.int64)
         src = g.col_idx.to(torch.int64)
         et = g.edge_type.to(torch.int64)
-        K = g.num_types
-        E = g.num_edges
-        sid = tile_of_atom[dst] * 4 + sub[dst]                                  # sub-tile of every edge (non-decreasing)
         src_local = src - tp64[tile_of_atom[dst]]
         if E and (int(src_local.min()) < 0 or int(src_local.max()) >= tv):
             return None                                   # an edge leaves its tile: not a batch of separate molecules
-        key = sid * K + et
-        order = torch.sort(key, stable=True).indices                           # edge order kept inside (sub-tile, type)
-        cnt = torch.bincount(key, minlength=4 * nt * K)
-        rts = (cnt + 15) // 16
-        rt_start = torch.zeros(4 * nt * K + 1, dtype=torch.int64, device=dev)
-        rt_start[1:] = torch.cumsum(rts, 0)
-        grp_start = torch.zeros(4 * nt * K + 1, dtype=torch.int64, device=dev)
-        grp_start[1:] = torch.cumsum(cnt, 0)
+        # ---- per-atom in-degree by type, and the sort of every tile's atoms by that pattern (high counts first)
+        cnt = torch.bincount(dst * K + et, minlength=V * K).view(V, K)
+        if int(cnt.max()) > rtmax:
+            return None
+        code = torch.zeros(V, dtype=torch.int64, device=dev)
+        for k in reversed(range(K)):                     # rare types (high ids) first: measured best fill on c2
+            code = code * 256 + (255 - cnt[:, k].clamp(max=255))
+        perm = torch.sort(tile_of_atom * (256 ** K) + code, stable=True).indices     # sorted position -> atom
+        pos_in_tile = torch.empty(V, dtype=torch.int64, device=dev)
+        pos_in_tile[perm] = torch.arange(V, device=dev) - tp64[tile_of_atom[perm]]
+        nblk = tv // 16
+        tile_atom = torch.full((nt * tv,), -1, dtype=torch.int64, device=dev)
+        tile_atom[tile_of_atom * tv + pos_in_tile] = torch.arange(V, device=dev)
+        blk_of_atom = tile_of_atom * nblk + pos_in_tile // 16                         # global block id
+        row_of_atom = pos_in_tile % 16
+        # ---- row-tiles: block (t, B) needs max_count(type k) of them for type k; memory order (t, q = B % 4, k, B // 4, rank)
+        # (type-major inside a sub-tile: the kernel keeps one type's matrix fragments in registers at a time)
+        need = torch.zeros(nt * nblk * K, dtype=torch.int64, device=dev)
+        need.scatter_reduce_(0, (blk_of_atom.unsqueeze(1) * K + torch.arange(K, device=dev)).reshape(-1), cnt.reshape(-1),
+                             reduce="amax")
+        need = need.view(nt, nblk // 4, 4, K).permute(0, 2, 3, 1).contiguous()       # [t][q][k][B // 4]
+        rt_start = torch.zeros(need.numel() + 1, dtype=torch.int64, device=dev)
+        rt_start[1:] = torch.cumsum(need.reshape(-1), 0)
         R = int(rt_start[-1].item())
-        rt_ptr = _i32(rt_start[::K])
-        rt_type = _i32(torch.repeat_interleave(torch.arange(4 * nt * K, device=dev) % K, rts, output_size=R))
-        skey = key[order]
-        pos = rt_start[skey] * 16 + (torch.arange(E, device=dev) - grp_start[skey])
-        dst_sub = local[dst] - sub[dst] * ss_t[tile_of_atom[dst]]
-        word = (src_local | (dst_sub << 8))[order]
-        slots = torch.full((16 * R,), 32 << 8, dtype=torch.int64, device=dev)
-        slots[pos] = word
+        per_sub = (nblk // 4) * K
+        rt_ptr64 = rt_start[::per_sub]
+        if R and int((rt_ptr64[1:] - rt_ptr64[:-1]).max()) > rtmax:
+            return None                                   # a sub-tile with more row-tiles than the kernel parks in LDS
+        grp = torch.arange(need.numel(), device=dev)
+        g_hi = grp % (nblk // 4)
+        g_k = (grp // (nblk // 4)) % K
+        rt_grp = torch.repeat_interleave(grp, need.reshape(-1), output_size=R)
+        slots = (tv | (g_k[rt_grp] << 16) | (g_hi[rt_grp] << 20)).repeat_interleave(16)   # empty: the zero row
         slot_eid = torch.full((16 * R,), -1, dtype=torch.int64, device=dev)
-        slot_eid[pos] = order
-        return cls(tile_ptr, rt_ptr, rt_type, _i32(slots), _i32(slot_eid), tv)
+        if E:
+            # rank of an edge among the edges of its (destination, type), in edge order
+            key = dst * K + et
+            order = torch.sort(key, stable=True).indices
+            skey = key[order]
+            first = torch.zeros(V * K + 1, dtype=torch.int64, device=dev)
+            first[1:] = torch.cumsum(cnt.reshape(-1), 0)
+            rank = torch.empty(E, dtype=torch.int64, device=dev)
+            rank[order] = torch.arange(E, device=dev) - first[skey]
+            t_e, b_e = tile_of_atom[dst], pos_in_tile[dst] // 16
+            gid = ((t_e * 4 + b_e % 4) * K + et) * (nblk // 4) + b_e // 4
+            pos = (rt_start[gid] + rank) * 16 + row_of_atom[dst]
+            slots[pos] = src_local | (1 << 14) | (et << 16) | ((b_e // 4) << 20)
+            slot_eid[pos] = torch.arange(E, device=dev)
+        return cls(tile_ptr, _i32(tile_atom).view(nt, tv), _i32(rt_ptr64), _i32(slots), _i32(slot_eid), tv)
 
 
 class MolGraph:

@@ -127,18 +127,19 @@ def edge_message_raw(h, A, graph, gate=None):
     return msg
 
 
-def tile_kernel_applies(A, gate, graph):
-    """The fused message+sum tile kernel covers: no gate, nf = mf = 64, a batch of separate molecules of at most one
-    tile each with few bond types (graph.tile_plan), default math.  MPNN_UNFUSED_MESSAGE=1 keeps the two-kernel path
-    (message rows to HBM, then the segmented-sum aggregator) for A/B runs."""
+def tile_kernel_applies(A, gate, w, graph):
+    """The fused message+sum tile kernel covers: no gate, unit edge weights, nf = mf = 64, a batch of separate
+    molecules of at most one tile each with few bond types (graph.tile_plan), default math.  MPNN_UNFUSED_MESSAGE=1
+    keeps the two-kernel path (message rows to HBM, then the segmented-sum aggregator) for A/B runs."""
     K, mf, nf = (int(s) for s in A.shape)
-    if gate is not None or mf != 64 or nf != 64 or math_mode() == "fp32" or os.environ.get("MPNN_UNFUSED_MESSAGE"):
+    if (gate is not None or w is not None or mf != 64 or nf != 64 or math_mode() == "fp32"
+            or os.environ.get("MPNN_UNFUSED_MESSAGE")):
         return False
     plan = graph.tile_plan
     return plan is not None and K == graph.num_types
 
 
-def message_aggregate_tile_raw(h, A, w, graph):
+def message_aggregate_tile_raw(h, A, graph):
     lib = _lib.load()
     K, mf, nf = (int(s) for s in A.shape)
     V = graph.num_nodes
@@ -147,9 +148,8 @@ def message_aggregate_tile_raw(h, A, w, graph):
     if V == 0:
         return out
     _lib.check(_timed("message_aggregate", lambda: lib.mpnn_message_aggregate_f32(
-        _lib.fptr(h), _lib.fptr(A), _lib.fptr(w), _lib.iptr(plan.tile_ptr), _lib.iptr(plan.rt_ptr),
-        _lib.iptr(plan.rt_type), _lib.iptr(plan.slots), _lib.iptr(plan.slot_eid), _lib.fptr(out), V, plan.num_tiles,
-        K, nf, mf, _lib.stream())), "mpnn_message_aggregate_f32")
+        _lib.fptr(h), _lib.fptr(A), _lib.iptr(plan.tile_rec), _lib.iptr(plan.tile_atom), _lib.iptr(plan.slots),
+        _lib.fptr(out), V, plan.num_tiles, K, nf, mf, _lib.stream())), "mpnn_message_aggregate_f32")
     return out
 
 
@@ -279,8 +279,8 @@ class MessageAggregate(torch.autograd.Function):
         gate = gate.contiguous() if gate is not None else None
         ctx.graph = graph
         ctx.save_for_backward(h, A, gate, w)
-        if tile_kernel_applies(A, gate, graph):
-            return message_aggregate_tile_raw(h, A, w, graph)
+        if tile_kernel_applies(A, gate, w, graph):
+            return message_aggregate_tile_raw(h, A, graph)
         msg = edge_message_raw(h, A, graph, gate)
         return segsum_raw(msg, graph.row_ptr, w, graph.num_nodes)
 

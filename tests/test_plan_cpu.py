@@ -1,6 +1,6 @@
-"""The tile plan of the fused message+sum kernels (graph.py::TilePlan), checked on the CPU: walking the plan exactly as
-the kernel does (tiles -> sub-tiles -> row-tiles -> 16 slots) must visit every edge once, with the right source row,
-destination row and bond type, and so reproduce sum_e A[type e] . h[src e] per destination atom."""
+"""The tile plan of the fused message+sum kernel (graph.py::TilePlan), checked on the CPU: walking the plan exactly as
+the kernel does (tiles -> sub-tiles -> row-tiles -> 16 slots whose ROW is a destination atom) must visit every edge once,
+with the right source row, destination atom and bond type, and so reproduce sum_e A[type e] . h[src e] per atom."""
 import numpy as np
 import pytest
 import torch
@@ -12,28 +12,29 @@ from mpnn_amd.graph import MolGraph
 def _walk(g, h, A):
     p = g.tile_plan
     out = torch.zeros(g.num_nodes, h.shape[1], dtype=torch.float64)
-    tp, rp, rty, sl, se = (x.numpy() for x in (p.tile_ptr, p.rt_ptr, p.rt_type, p.slots, p.slot_eid))
+    rec, ta, sl, se = (x.numpy() for x in (p.tile_rec, p.tile_atom, p.slots, p.slot_eid))
     seen = np.zeros(g.num_edges, int)
     for t in range(p.num_tiles):
-        a0, n = tp[t], tp[t + 1] - tp[t]
+        a0, n = rec[t, 0], rec[t, 1]
         assert 0 < n <= p.tile_atoms
-        ss = (n + 3) // 4
+        assert sorted(a for a in ta[t] if a >= 0) == list(range(a0, a0 + n))        # a permutation of the tile's atoms
         for q in range(4):
-            last_type = -1
-            for rt in range(rp[4 * t + q], rp[4 * t + q + 1]):
-                k = rty[rt]
-                assert k >= last_type                         # a sub-tile's row-tiles are grouped by type
-                last_type = k
-                for s in range(16):
-                    wd, e = sl[rt * 16 + s], se[rt * 16 + s]
+            last = (-1, -1)
+            for rt in range(rec[t, 2 + q], rec[t, 3 + q]):
+                k, bk = (sl[rt * 16] >> 16) & 15, (sl[rt * 16] >> 20) & 1
+                assert (k, bk) >= last                         # a sub-tile's row-tiles: by type, then destination block
+                last = (k, bk)
+                for m in range(16):
+                    wd, e = sl[rt * 16 + m], se[rt * 16 + m]
+                    assert ((wd >> 16) & 15) == k and ((wd >> 20) & 1) == bk
                     if e < 0:
-                        assert wd == 32 << 8                  # padding: source row 0, sink destination row
+                        assert (wd & 0x7fff) == p.tile_atoms  # empty: not valid, reads the zero row
                         continue
-                    src, d = a0 + (wd & 0xff), a0 + q * ss + ((wd >> 8) & 0x3f)
-                    assert src == g.col_idx[e] and d == g.edge_dst[e] and k == g.edge_type[e]
-                    assert ((wd >> 8) & 0x3f) < min(ss, 32)
+                    assert (wd >> 14) & 1
+                    d = ta[t, 64 * bk + 16 * q + m]            # row m of block (bk, q) is this atom
+                    assert d == g.edge_dst[e] and a0 + (wd & 0xff) == g.col_idx[e] and k == g.edge_type[e]
                     seen[e] += 1
-                    out[d] += A[k] @ h[src]
+                    out[d] += A[k] @ h[a0 + (wd & 0xff)]
     assert (seen == 1).all()
     return out
 
@@ -42,14 +43,34 @@ def _walk(g, h, A):
 def test_plan_walk_reproduces_the_neighbour_sum(n_mols, seed, dist):
     mb = synth.make_molecules(n_mols, 8, seed=seed, dist=dist)
     g = MolGraph.from_molbatch(mb, torch.device("cpu"))
-    assert g.tile_plan is not None
+    p = g.tile_plan
+    assert p is not None
     h = torch.randn(g.num_nodes, 8, dtype=torch.float64)
     A = torch.randn(g.num_types, 8, 8, dtype=torch.float64)
     ref = torch.zeros(g.num_nodes, 8, dtype=torch.float64)
     ref.index_add_(0, g.edge_dst.long(), torch.einsum("emn,en->em", A[g.edge_type.long()], h[g.col_idx.long()]))
     assert float((_walk(g, h, A) - ref).abs().max()) < 1e-12
-    tp = g.tile_plan.tile_ptr.numpy()
+    tp = p.tile_ptr.numpy()
     assert tp[0] == 0 and tp[-1] == g.num_nodes and set(tp.tolist()) <= set(g.graph_ptr.numpy().tolist())
+    rec = p.tile_rec.numpy()
+    assert np.array_equal(rec[:, 0], tp[:-1]) and np.array_equal(rec[:, 0] + rec[:, 1], tp[1:])
+    assert np.array_equal(rec[:, 2:6].reshape(-1), p.rt_ptr.numpy()[:-1]) and np.array_equal(rec[:, 6], p.rt_ptr.numpy()[4::4])
+
+
+def test_plan_edge_order_within_a_destination_and_type_is_rank_order():
+    """Accumulation order = row-tile order, so rank r of (atom, type) must be that pair's r-th edge in CSR order."""
+    mb = synth.make_molecules(50, 4, seed=8)
+    g = MolGraph.from_molbatch(mb, torch.device("cpu"))
+    p = g.tile_plan
+    se = p.slot_eid.numpy().reshape(-1, 16)
+    dst, typ = g.edge_dst.numpy(), g.edge_type.numpy()
+    last = {}
+    for rt in range(se.shape[0]):
+        for e in se[rt]:
+            if e >= 0:
+                key = (dst[e], typ[e])
+                assert last.get(key, -1) < e
+                last[key] = e
 
 
 def test_plan_refuses_what_the_kernel_cannot_do():

@@ -37,12 +37,12 @@ def timeit(fn, reps=20):
     return best, tot / reps
 
 
-for name, fn in (("tile kernel", lambda: ops.message_aggregate_tile_raw(h, A, None, g)),
+for name, fn in (("tile kernel", lambda: ops.message_aggregate_tile_raw(h, A, g)),
                  ("message + segsum", lambda: ops.segsum_raw(ops.edge_message_raw(h, A, g), g.row_ptr, None, V))):
     best, avg = timeit(fn)
     byt = 8.0 * 64 * V + p.nbytes
     print("%-18s best %.3f ms avg %.3f ms   (min-traffic %.2f GB -> %.0f GB/s at best)" % (name, best, avg, byt / 1e9,
                                                                                             byt / best / 1e6))
-a = ops.message_aggregate_tile_raw(h, A, None, g)
+a = ops.message_aggregate_tile_raw(h, A, g)
 b = ops.segsum_raw(ops.edge_message_raw(h, A, g), g.row_ptr, None, V)
 print("max |tile - two-kernel| = %.3e" % float((a - b).abs().max()))
