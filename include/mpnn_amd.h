@@ -138,14 +138,14 @@ int mpnn_edge_message_agg_bwd_dgate_f32(const float* dagg, const float* A, const
  *           also ggnn_msg_pass.py:30-31 (A = the bond-type table).
  * The edges arrive as a TILE PLAN (built once per batch from graph_ptr / row_ptr / src / type; layout in
  * mpnn_amd/graph.py::TilePlan): molecule-aligned tiles of at most mpnn_message_aggregate_tile_atoms() atoms whose h rows
- * are staged in LDS once; the tile's atoms sorted by per-type in-degree and dealt in blocks of 16 (block B: sub-tile
- * B % 4, destination block B / 4); a row-tile = the rank-th incoming type-k edge of each atom of one block.
- *   tile_rec[T][16]   first atom, atoms, first row-tile of sub-tile 0, 1, 2, 3, end of sub-tile 3, zeros
- *   tile_atom[T][128] atom id at every sorted position of the tile, -1 = none
- *   slots[16R]        (source atom - first atom) | valid << 14 | bond type << 16 | destination block << 20; an empty
- *                     slot names source row 128 (zeros); row-tiles in (tile, sub-tile, type, block, rank) order
+ * are staged in LDS once; the tile's atoms sorted by per-type in-degree and dealt in blocks of 16 (one per wave);
+ * a row-tile = the rank-th incoming type-k edge of each atom of one block.
+ *   tile_rec[T][16]   first atom, atoms, first row-tile of block 0..7, end of block 7, zeros
+ *   tile_atom[T][128] atom id at every sorted position of the tile (block = position / 16), -1 = none
+ *   slots[16R]        (source atom - first atom) | valid << 14 | bond type << 16; an empty slot names source row 128
+ *                     (zeros); row-tiles in (tile, block, type, rank) order
  * nf = mf = 64, K <= mpnn_message_aggregate_max_types(), at most mpnn_message_aggregate_max_row_tiles() row-tiles per
- * sub-tile, unit edge weights only (callers run mpnn_edge_message_f32 + mpnn_segsum_f32 otherwise).  Sum order inside
+ * block, unit edge weights only (callers run mpnn_edge_message_f32 + mpnn_segsum_f32 otherwise).  Sum order inside
  * a row: types ascending, edge order within a type (deterministic).
  * mpnn_plan_tiles_host is a HOST helper (host pointers, no device work): greedy packing of whole molecules into
  * tiles; writes tile_ptr (capacity G+2) and returns the tile count, or -1 if a molecule exceeds max_atoms.

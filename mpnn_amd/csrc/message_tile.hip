@@ -16,13 +16,14 @@
 //     summed across lanes or split again; an atom without a rank-th type-k edge reads a row of zeros.  (Measured on the
 //     way here: per-edge row-tiles + LDS float atomics 3.5 ms, + rank-ordered LDS read-modify-write 0.64 ms, + a second
 //     MFMA with a one-hot incidence operand 0.67 ms, all bound by the vector instructions around the MFMAs.)
-//   * wave PAIR q owns sub-tile q (destination blocks q and q + 4 of the tile); the two waves of a pair run the same
-//     row-tiles and split the 64 output features, two waves per SIMD.  A operands are gathered from the LDS image by
-//     source row (ds_read_b128, no conversion in the loop), the type's matrix fragments stay in registers across its
-//     row-tiles and the next type's are fetched behind the last MFMA of the current one; slot words run two row-tiles
-//     ahead, gathered fragments one;
+//   * wave PAIR p owns blocks 2p and 2p+1 of the tile (the plan labels the blocks so that these are the p-th heaviest
+//     and the p-th lightest: with one block per wave the heaviest block's wave ran 6.7k cycles per tile and the lightest
+//     1.6k); the two waves of a pair run the same row-tiles and split the 64 output features.  A operands are gathered from the LDS image by source row (ds_read_b128,
+//     no conversion in the loop), the type's matrix fragments stay in registers across its row-tiles and the next
+//     type's are fetched behind the last MFMA of the current one; slot words run two row-tiles ahead, gathered
+//     fragments one, in two register sets used alternately (no copies);
 //   * sum order inside an output row: types ascending, edge order within a type (accumulator order) -- deterministic;
-//   * at the end of a sub-tile the accumulators are scaled back, transposed through LDS and stored as 128-byte half rows
+//   * at the end of a tile the accumulators are scaled back, transposed through LDS and stored as 128-byte half rows
 //     at their atoms' places.  The next tile's h rows, slot words and atom list are in registers by then.
 //
 // Math ("fp16x3"): the tile's h rows share one power-of-two scale s_h and the K matrices one scale s_A (max |x| lands
@@ -31,8 +32,6 @@
 // pieces normal fp16 numbers.  A product uses three MFMAs, hi*hi into one accumulator and hi*lo + lo*hi into a second
 // one folded in with 2^-11 at the end; every partial product is exact in the fp32 accumulators.  Dropped: lo*lo
 // (<= 2^-22 relative).  The scales are undone, exactly, when the accumulators are stored.
-#include <stdlib.h>
-
 #include "common.h"
 
 namespace mpnn {
@@ -45,12 +44,12 @@ constexpr int MT_TV = 128;          // atoms per tile (upper bound); LDS image r
 constexpr int MT_F = 64;
 constexpr int MT_OSTR = 68;         // floats per row of the out transposition tile
 constexpr int MT_KMAX = 4;          // bond-type matrices resident in LDS (16 KB each as an fp16 image pair)
-constexpr int MT_RTMAX = 32;        // row-tiles per sub-tile (their slot words are parked in LDS)
+constexpr int MT_RTMAX = 16;        // row-tiles per block (their slot words are parked in LDS)
 constexpr int MT_IMG = MT_F * MT_F * 2;          // one fp16 piece of one matrix: 8 KB
 constexpr int MT_HT = (MT_TV + 1) * MT_F * 2;    // one fp16 piece of the h tile + the zero row
 
 __host__ __device__ constexpr int mt_lds_bytes(int K) {
-    return K * 2 * MT_IMG + 2 * MT_HT + 4 * 32 * MT_OSTR * 4 + 4 * 16 * MT_RTMAX * 4 + MT_TV * 4 + 256;
+    return K * 2 * MT_IMG + 2 * MT_HT + 8 * 16 * MT_OSTR * 4 + 8 * 16 * MT_RTMAX * 4 + MT_TV * 4 + 256;
 }
 
 // power-of-two scale that puts `maxabs` into [2^14, 2^15), and its inverse
@@ -66,24 +65,32 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
     lo = (_Float16)((v - (float)hi) * 2048.0f);
 }
 
+#ifdef MT_STAMP   // diagnostic build only (-DMT_STAMP): per-phase cycle sums of one block, read by tools/_stamp.py
+__device__ unsigned long long g_mt_stamps[16];
+#define MT_T(var) unsigned long long var; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0)
+#else
+#define MT_T(var)
+#endif
+
 __global__ void __launch_bounds__(512, 2) message_sum_tile_kernel(
     const float* __restrict__ h, const float* __restrict__ A, const int32_t* __restrict__ tile_rec,
     const int32_t* __restrict__ tile_atom, const int32_t* __restrict__ slots, float* __restrict__ out, int num_tiles,
-    int K, int dbg) {
+    int K) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int sub = wv >> 1, half = wv & 1;              // sub-tile of this wave pair; which 32 output features are mine
+    const int pr = wv >> 1, half = wv & 1;               // my pair's blocks are 2 pr and 2 pr + 1; my 32 output features
     const int q16 = lane & 15, g = lane >> 4;
     auto swz = [](int n) { return (n >> 1) & 7; };
 
     const int HT_OFF = K * 2 * MT_IMG;
-    const int OW_OFF = HT_OFF + 2 * MT_HT;               // out transposition tiles, one per sub-tile
-    const int SL_OFF = OW_OFF + 4 * 32 * MT_OSTR * 4;    // slot words, one region per sub-tile
-    const int AT_OFF = SL_OFF + 4 * 16 * MT_RTMAX * 4;   // atom id of every sorted position of the tile
-    const int RED_OFF = AT_OFF + MT_TV * 4;              // partial maxima (8 floats for A, 8 for the tile) + the A scale
-    float* outw = reinterpret_cast<float*>(smem + OW_OFF) + sub * (32 * MT_OSTR);
-    int* slw = reinterpret_cast<int*>(smem + SL_OFF) + sub * (16 * MT_RTMAX);
+    const int OW_OFF = HT_OFF + 2 * MT_HT;               // out transposition tiles, one per wave
+    const int SL_OFF = OW_OFF + 8 * 16 * MT_OSTR * 4;    // slot words, one region per wave
+    const int AT_OFF = SL_OFF + 8 * 16 * MT_RTMAX * 4;   // atom id of every sorted position of the tile
+    const int RED_OFF = AT_OFF + MT_TV * 4;              // partial maxima (8 floats for A, 8 for the tile)
+    float* outw = reinterpret_cast<float*>(smem + OW_OFF) + pr * (32 * MT_OSTR);     // the pair's two blocks: 32 rows
+    int* slw_mine = reinterpret_cast<int*>(smem + SL_OFF) + wv * (16 * MT_RTMAX);     // block wv: I park its slot words
+    int* slw_pair = reinterpret_cast<int*>(smem + SL_OFF) + 2 * pr * (16 * MT_RTMAX);
     int* atoms = reinterpret_cast<int*>(smem + AT_OFF);
     float* red = reinterpret_cast<float*>(smem + RED_OFF);
 
@@ -144,23 +151,24 @@ __global__ void __launch_bounds__(512, 2) message_sum_tile_kernel(
     }
 
     // ---------------------------------------------------------------- tile loop
-    // tile record: (first atom, atoms, first row-tile of sub-tile 0..3, end, ...) -- one scalar load per tile, fetched two
-    // tiles ahead; h rows, the sub-tiles' slot words and the atom list are fetched ONE tile ahead into registers and
+    // tile record: (first atom, atoms, first row-tile of block 0..7, end, ...) -- one scalar load per tile, fetched two
+    // tiles ahead; h rows, the blocks' slot words and the atom list are fetched ONE tile ahead into registers and
     // parked in LDS at the top of their tile, so nothing in the row-tile loop waits on global memory.
-    struct Rec { int a0, n, r0, r1; };
+    struct Rec { int a0, n, r0, r1, r2; };   // row-tiles of block 2 pr: [r0, r1), of block 2 pr + 1: [r1, r2)
     auto load_rec = [&](int t) {
         const int32_t* p = tile_rec + 16 * (int64_t)t;
         Rec r;
         r.a0 = p[0];
         r.n = p[1];
-        r.r0 = p[2 + sub];
-        r.r1 = p[3 + sub];
+        r.r0 = p[2 + 2 * pr];
+        r.r1 = p[3 + 2 * pr];
+        r.r2 = p[4 + 2 * pr];
         return r;
     };
     // staging thread (tid, j): float4 number tid + 512 j of the tile = row (tid >> 4) + 32 j, columns 4 (tid & 15) ..
     const int srow = tid >> 4, sc4 = tid & 15;
     f32x4 stage[4];
-    int slotreg[MT_RTMAX / 8];                                        // the pair's waves take alternate 64-word chunks
+    int slotreg[MT_RTMAX / 4];
     int atomreg = -1;
     auto stage_load = [&](const Rec& r, int t) {
 #pragma unroll
@@ -169,18 +177,18 @@ __global__ void __launch_bounds__(512, 2) message_sum_tile_kernel(
             const int rr = row < r.n ? row : 0;                      // clamped: loads stay unconditional
             stage[j] = *reinterpret_cast<const f32x4*>(h + (int64_t)(r.a0 + rr) * MT_F + 4 * sc4);
         }
-        const int nw = 16 * (r.r1 - r.r0);                            // the sub-tile's slot words
+        const int rb = half ? r.r1 : r.r0;                            // I fetch block wv's slot words
+        const int nw = 16 * ((half ? r.r2 : r.r1) - rb);
 #pragma unroll
-        for (int j = 0; j < MT_RTMAX / 8; ++j) {
-            const int c = 2 * j + half;
-            if (64 * c < nw) {                                        // wave-uniform
-                const int i = 64 * c + lane;
-                slotreg[j] = slots[(int64_t)16 * r.r0 + (i < nw ? i : 0)];
+        for (int j = 0; j < MT_RTMAX / 4; ++j) {
+            if (64 * j < nw) {                                        // wave-uniform
+                const int i = 64 * j + lane;
+                slotreg[j] = slots[(int64_t)16 * rb + (i < nw ? i : 0)];
             }
         }
         if (tid < MT_TV) atomreg = tile_atom[(int64_t)t * MT_TV + tid];
     };
-    auto stage_max = [&](const Rec& r) {                              // this wave's part of max |h| over the tile
+    auto stage_max = [&]() {                                          // this wave's part of max |h| over the tile
         float mx = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -211,12 +219,10 @@ __global__ void __launch_bounds__(512, 2) message_sum_tile_kernel(
             *reinterpret_cast<f16x4*>(smem + off) = hi;
             *reinterpret_cast<f16x4*>(smem + off + MT_HT) = lo;
         }
-        const int nw = 16 * (r.r1 - r.r0);
+        const int nw = 16 * (half ? r.r2 - r.r1 : r.r1 - r.r0);
 #pragma unroll
-        for (int j = 0; j < MT_RTMAX / 8; ++j) {
-            const int c = 2 * j + half;
-            if (64 * c < nw) slw[64 * c + lane] = slotreg[j];
-        }
+        for (int j = 0; j < MT_RTMAX / 4; ++j)
+            if (64 * j < nw) slw_mine[64 * j + lane] = slotreg[j];
         if (tid < MT_TV) atoms[tid] = atomreg;
         return inv;
     };
@@ -227,17 +233,21 @@ __global__ void __launch_bounds__(512, 2) message_sum_tile_kernel(
     Rec nxt = load_rec(t + G < num_tiles ? t + G : 0);
     if (t < num_tiles) stage_load(cur, t);
     for (; t < num_tiles; t += G) {
-        stage_max(cur);
+        MT_T(t0);
+        stage_max();
+        MT_T(t0b);
         __syncthreads();                    // every wave is done with the previous tile's LDS data; maxima are in
+        MT_T(t1);
         const float h_inv = stage_write(cur);
+        MT_T(t1b);
         __syncthreads();
+        MT_T(t2);
         const Rec nn = load_rec(t + 2 * G < num_tiles ? t + 2 * G : 0);
-        if (t + G < num_tiles && !(dbg & 4)) stage_load(nxt, t + G);   // in flight during this tile's contractions
+        if (t + G < num_tiles) stage_load(nxt, t + G);           // in flight during this tile's contractions
+        MT_T(t3);
 
-        const int nrt = (dbg & 2) ? 0 : cur.r1 - cur.r0;
-        // slot word (graph.py::TilePlan): source row | valid << 14 | type << 16 | destination block << 20; an empty slot
-        // names the zero row.  Lane (q16, g) gathers k-group g of the source row of slot q16 = destination atom q16.
-        auto my_word = [&](int i) { return slw[16 * (i < nrt ? i : 0) + q16]; };
+        // slot word (graph.py::TilePlan): source row | valid << 14 | type << 16; an empty slot names the zero row.
+        // Lane (q16, g) gathers k-group g of the source row of slot q16 = destination atom q16 of the block.
         auto gather = [&](int word, f16x8 (&ah)[2], f16x8 (&al)[2]) {
             const int src = word & 0xff;
 #pragma unroll
@@ -247,7 +257,8 @@ __global__ void __launch_bounds__(512, 2) message_sum_tile_kernel(
                 al[s] = *reinterpret_cast<const f16x8*>(smem + off + MT_HT);
             }
         };
-        f16x8 bh[2][2], bl[2][2];
+        f16x8 bh[2][2], bl[2][2];                                     // the running type's matrix, my two column tiles
+        int cur_k = -1;
         auto load_matrix = [&](int k) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -260,82 +271,90 @@ __global__ void __launch_bounds__(512, 2) message_sum_tile_kernel(
                 }
             }
         };
-        f32x4 chh[2][2], cx[2][2];                                    // [destination block][my column tile]
-#pragma unroll
-        for (int bk = 0; bk < 2; ++bk)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                chh[bk][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-                cx[bk][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        f16x8 ah[2], al[2], ah_n[2], al_n[2];
-        int w0 = my_word(0), w1 = my_word(1);
-        int cur_k = __builtin_amdgcn_readfirstlane((w0 >> 16) & 15);
-        if (nrt > 0) {
-            gather(w0, ah, al);
-            load_matrix(cur_k);
-        }
-        for (int i = 0; i < nrt; ++i) {
-            const int w2 = my_word(i + 2);
-            gather(w1, ah_n, al_n);                                   // next row-tile's operand (a harmless re-read at the end)
-            __builtin_amdgcn_sched_barrier(0);
-            const int bk = __builtin_amdgcn_readfirstlane((w0 >> 20) & 1);
-            if (bk == 0) {
+        // one block: its row-tiles (type-major) accumulate into chh / cx = [16 atoms x my 32 features], hi*hi and cross
+        // terms.  Slot words run two row-tiles ahead, gathered fragments one, in two register sets used alternately.
+        auto run_block = [&](const int* slw, int nrt, f32x4 (&chh)[2], f32x4 (&cx)[2]) {
+            auto my_word = [&](int i) { return slw[16 * (i < nrt ? i : 0) + q16]; };
+            auto contract = [&](const f16x8 (&ah)[2], const f16x8 (&al)[2]) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
-                        chh[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], bh[c][s], chh[0][c], 0, 0, 0);
-                        cx[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], bl[c][s], cx[0][c], 0, 0, 0);
-                        cx[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s], bh[c][s], cx[0][c], 0, 0, 0);
+                        chh[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], bh[c][s], chh[c], 0, 0, 0);
+                        cx[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], bl[c][s], cx[c], 0, 0, 0);
+                        cx[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s], bh[c][s], cx[c], 0, 0, 0);
                     }
-            } else {
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        chh[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], bh[c][s], chh[1][c], 0, 0, 0);
-                        cx[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], bl[c][s], cx[1][c], 0, 0, 0);
-                        cx[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s], bh[c][s], cx[1][c], 0, 0, 0);
-                    }
+            };
+            // the next row-tile's matrix, if its type differs (wave-uniform), goes behind the last MFMA that read this one
+            auto next_matrix = [&](int word, bool more) {
+                const int k_n = __builtin_amdgcn_readfirstlane((word >> 16) & 15);
+                if (k_n != cur_k && more) {
+                    cur_k = k_n;
+                    load_matrix(k_n);
+                }
+            };
+            if (nrt <= 0) return;
+            f16x8 fah[2], fal[2], fbh[2], fbl[2];
+            const int w0 = my_word(0);
+            int wn1 = my_word(1);
+            next_matrix(w0, true);
+            gather(w0, fah, fal);
+            for (int i = 0; i < nrt; i += 2) {
+                const int wn2 = my_word(i + 2);
+                gather(wn1, fbh, fbl);                                // row-tile i + 1 (a harmless re-read at the end)
+                __builtin_amdgcn_sched_barrier(0);
+                contract(fah, fal);                                   // row-tile i
+                __builtin_amdgcn_sched_barrier(0);
+                next_matrix(wn1, i + 1 < nrt);
+                if (i + 1 >= nrt) break;
+                const int wn3 = my_word(i + 3);
+                gather(wn2, fah, fal);                                // row-tile i + 2
+                __builtin_amdgcn_sched_barrier(0);
+                contract(fbh, fbl);                                   // row-tile i + 1
+                __builtin_amdgcn_sched_barrier(0);
+                next_matrix(wn2, i + 2 < nrt);
+                wn1 = wn3;
             }
-            __builtin_amdgcn_sched_barrier(0);
-            // the next row-tile's matrix, if its type differs (wave-uniform), behind the last MFMA that read this one
-            const int k_n = __builtin_amdgcn_readfirstlane((w1 >> 16) & 15);
-            if (k_n != cur_k && i + 1 < nrt) {
-                cur_k = k_n;
-                load_matrix(k_n);
-            }
+        };
+        f32x4 chh0[2], cx0[2], chh1[2], cx1[2];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                ah[s] = ah_n[s];
-                al[s] = al_n[s];
-            }
-            w0 = w1;
-            w1 = w2;
+        for (int c = 0; c < 2; ++c) {
+            chh0[c] = cx0[c] = chh1[c] = cx1[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        // ---- my 32 columns of the sub-tile's out rows: accumulators (scales undone) -> the pair's LDS tile
-        // (transposition) -> HBM as 128-byte half rows at the atoms' places.
-        // acc[bk][c][r] = out[atom of (block bk, row 4 g + r)][feature 32 half + 16 c + q16]
+        run_block(slw_pair, cur.r1 - cur.r0, chh0, cx0);
+        run_block(slw_pair + 16 * MT_RTMAX, cur.r2 - cur.r1, chh1, cx1);
+        MT_T(t4);
+        // ---- my 32 columns of the pair's 32 out rows: accumulators (scales undone) -> the pair's LDS tile (transposition)
+        // -> HBM as 128-byte half rows at the atoms' places.  (c, r) = out[atom of row 4 g + r][32 half + 16 c + q16]
         const float f = h_inv * a_inv, fx = f * (1.0f / 2048.0f);
 #pragma unroll
-        for (int bk = 0; bk < 2; ++bk)
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    outw[(16 * bk + 4 * g + r) * MT_OSTR + 32 * half + 16 * c + q16] = chh[bk][c][r] * f + cx[bk][c][r] * fx;
+            for (int r = 0; r < 4; ++r) {
+                outw[(4 * g + r) * MT_OSTR + 32 * half + 16 * c + q16] = chh0[c][r] * f + cx0[c][r] * fx;
+                outw[(16 + 4 * g + r) * MT_OSTR + 32 * half + 16 * c + q16] = chh1[c][r] * f + cx1[c][r] * fx;
+            }
         const int r8 = lane >> 3, c8 = lane & 7;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int row = 8 * it + r8;                              // block row / 16 of the pair, atom row % 16 of it
-            const int atom = atoms[64 * (row >> 4) + 16 * sub + (row & 15)];   // tile block = 4 (row / 16) + sub
+            const int row = 8 * it + r8;                              // rows 0..15: block 2 pr, 16..31: block 2 pr + 1
+            const int atom = atoms[32 * pr + row];
             const f32x4 v = *reinterpret_cast<const f32x4*>(outw + row * MT_OSTR + 32 * half + 4 * c8);
             if (atom >= 0)
                 __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + (int64_t)atom * MT_F + 32 * half + 4 * c8));
         }
         cur = nxt;
         nxt = nn;
+#ifdef MT_STAMP
+        MT_T(t5);
+        if (blockIdx.x == 3 && lane == 0) {
+            unsigned long long* q = g_mt_stamps + 8 * (wv == 0 ? 0 : 1);
+            if (wv == 0 || wv == 7) {
+                atomicAdd(q + 0, t0b - t0); atomicAdd(q + 1, t1 - t0b); atomicAdd(q + 2, t1b - t1); atomicAdd(q + 3, t2 - t1b);
+                atomicAdd(q + 4, t3 - t2); atomicAdd(q + 5, t4 - t3); atomicAdd(q + 6, t5 - t4); atomicAdd(q + 7, 1ull);
+            }
+        }
+#endif
     }
 }
 
@@ -362,6 +381,16 @@ extern "C" int64_t mpnn_plan_tiles_host(const int32_t* graph_ptr, int64_t G, int
     return nt;
 }
 
+#ifdef MT_STAMP
+extern "C" int mpnn_debug_mt_stamps(unsigned long long* host16, int reset) {
+    if (reset) {
+        unsigned long long z[16] = {0};
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_mt_stamps), z, sizeof(z));
+    }
+    return (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_mt_stamps), 16 * sizeof(unsigned long long));
+}
+#endif
+
 extern "C" int mpnn_message_aggregate_tile_atoms(void) { return MT_TV; }
 extern "C" int mpnn_message_aggregate_max_types(void) { return MT_KMAX; }
 extern "C" int mpnn_message_aggregate_max_row_tiles(void) { return MT_RTMAX; }
@@ -384,8 +413,7 @@ extern "C" int mpnn_message_aggregate_f32(const float* h, const float* A, const 
     int64_t blocks = 256;                                             // one block per CU
     if (blocks > num_tiles) blocks = num_tiles;
     hipStream_t s = (hipStream_t)stream;
-    const int dbg = getenv("MPNN_MT_DEBUG") ? atoi(getenv("MPNN_MT_DEBUG")) : 0;   // TEMPORARY timing ablations
     hipLaunchKernelGGL(message_sum_tile_kernel, dim3((unsigned)blocks), dim3(512), lds, s, h, A, tile_rec, tile_atom, slots,
-                       out, (int)num_tiles, K, dbg);
+                       out, (int)num_tiles, K);
     return launch_status("mpnn_message_aggregate_f32");
 }

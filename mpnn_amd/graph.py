@@ -29,19 +29,19 @@ class TilePlan:
     """Work list of the fused message+sum kernel (csrc/message_tile.hip).
 
     Atoms are cut into molecule-aligned TILES of at most `tile_atoms` atoms (greedy, whole molecules).  Inside a tile
-    the atoms are SORTED by their per-type in-degree pattern and dealt in BLOCKS of 16 consecutive sorted atoms; block
-    B belongs to sub-tile B % 4 (one wave pair each) as its destination block B // 4.  A ROW-TILE is then
-    "the rank-th incoming edge of type k of each of the block's 16 atoms": row m of the contraction IS destination atom
-    m of the block, so the contraction's accumulator rows are output rows and nothing has to be summed afterwards.  A
-    block needs max-over-its-atoms(count of type-k edges) row-tiles for type k; sorting atoms by pattern keeps that
-    close to what each atom really has (the slot fill).
+    the atoms are SORTED by their per-type in-degree pattern and dealt in BLOCKS of 16 consecutive sorted atoms; the
+    blocks are then labelled so that blocks 2p and 2p+1 (wave pair p of the kernel) are the p-th heaviest and the p-th
+    lightest of the tile.  A ROW-TILE is "the rank-th incoming edge of type k of each of the block's 16 atoms":
+    row m of the contraction IS destination atom m of the block, so the contraction's accumulator rows are output rows
+    and nothing has to be summed afterwards.  A block needs max-over-its-atoms(count of type-k edges) row-tiles for
+    type k; sorting atoms by pattern keeps that close to what each atom really has (the slot fill).
 
-        tile_rec[T,16]  first atom, atoms, first row-tile of sub-tile 0..3, end of sub-tile 3, 0, 8 x 0
-        tile_atom[T,128] atom id of every sorted position of the tile (block B = position // 16), -1 = none
-        slots[16*R]     row-tiles in (tile, sub-tile, type, destination block, rank) order, 16 words each:
-                        (source atom - tile start) | valid << 14 | bond type << 16 | destination block << 20;
-                        an empty slot reads source row `tile_atoms` (a row of zeros in the kernel's LDS image)
-        slot_eid[16*R]  edge id of the slot (-1 = empty); tests and the backward use it
+        tile_rec[T,16]   first atom, atoms, first row-tile of block 0..7, end of block 7, zeros
+        tile_atom[T,128] atom id of every (block, row) of the tile (index 16 * block + row), -1 = none
+        slots[16*R]      row-tiles in (tile, block, type, rank) order, 16 words each:
+                         (source atom - tile start) | valid << 14 | bond type << 16;
+                         an empty slot reads source row `tile_atoms` (a row of zeros in the kernel's LDS image)
+        slot_eid[16*R]   edge id of the slot (-1 = empty); tests and the backward use it
     """
 
     def __init__(self, tile_ptr, tile_atom, rt_ptr, slots, slot_eid, tile_atoms):
@@ -49,12 +49,12 @@ class TilePlan:
         self.num_tiles = int(tile_ptr.shape[0]) - 1
         self.num_row_tiles = int(slots.shape[0]) // 16
         self.tile_atoms = tile_atoms
-        T = self.num_tiles
+        T, nb = self.num_tiles, tile_atoms // 16
         rec = torch.zeros(T, 16, dtype=torch.int32, device=tile_ptr.device)
         rec[:, 0] = tile_ptr[:-1]
         rec[:, 1] = tile_ptr[1:] - tile_ptr[:-1]
-        rec[:, 2:6] = rt_ptr[:4 * T].view(T, 4)
-        rec[:, 6] = rt_ptr[4::4]
+        rec[:, 2:2 + nb] = rt_ptr[:nb * T].view(T, nb)
+        rec[:, 2 + nb] = rt_ptr[nb::nb]
         self.tile_rec = rec.contiguous()
         # what one launch reads: a record and the sorted-atom list per tile, every slot word once
         self.nbytes = 4 * (16 * T + tile_atoms * T + 16 * self.num_row_tiles)
@@ -86,8 +86,6 @@ class TilePlan:
             return None                                   # an edge leaves its tile: not a batch of separate molecules
         # ---- per-atom in-degree by type, and the sort of every tile's atoms by that pattern (high counts first)
         cnt = torch.bincount(dst * K + et, minlength=V * K).view(V, K)
-        if int(cnt.max()) > rtmax:
-            return None
         code = torch.zeros(V, dtype=torch.int64, device=dev)
         for k in reversed(range(K)):                     # rare types (high ids) first: measured best fill on c2
             code = code * 256 + (255 - cnt[:, k].clamp(max=255))
@@ -95,42 +93,47 @@ class TilePlan:
         pos_in_tile = torch.empty(V, dtype=torch.int64, device=dev)
         pos_in_tile[perm] = torch.arange(V, device=dev) - tp64[tile_of_atom[perm]]
         nblk = tv // 16
-        tile_atom = torch.full((nt * tv,), -1, dtype=torch.int64, device=dev)
-        tile_atom[tile_of_atom * tv + pos_in_tile] = torch.arange(V, device=dev)
-        blk_of_atom = tile_of_atom * nblk + pos_in_tile // 16                         # global block id
+        sblk_of_atom = tile_of_atom * nblk + pos_in_tile // 16                        # block in sorted order
         row_of_atom = pos_in_tile % 16
-        # ---- row-tiles: block (t, B) needs max_count(type k) of them for type k; memory order (t, q = B % 4, k, B // 4, rank)
-        # (type-major inside a sub-tile: the kernel keeps one type's matrix fragments in registers at a time)
+        # ---- row-tiles: a block needs max_count(type k) of them for type k
         need = torch.zeros(nt * nblk * K, dtype=torch.int64, device=dev)
-        need.scatter_reduce_(0, (blk_of_atom.unsqueeze(1) * K + torch.arange(K, device=dev)).reshape(-1), cnt.reshape(-1),
+        need.scatter_reduce_(0, (sblk_of_atom.unsqueeze(1) * K + torch.arange(K, device=dev)).reshape(-1), cnt.reshape(-1),
                              reduce="amax")
-        need = need.view(nt, nblk // 4, 4, K).permute(0, 2, 3, 1).contiguous()       # [t][q][k][B // 4]
+        # ---- balance: the kernel gives blocks 2p and 2p+1 of a tile to wave pair p, so relabel the sorted blocks such
+        # that the p-th heaviest (most row-tiles) sits next to the p-th lightest
+        load = need.view(nt, nblk, K).sum(-1)
+        by_load = torch.sort(load, dim=1, descending=True, stable=True).indices       # [t][i] = i-th heaviest block
+        label = torch.empty(nblk, dtype=torch.int64, device=dev)
+        label[: nblk // 2] = 2 * torch.arange(nblk // 2, device=dev)
+        label[nblk // 2:] = 2 * torch.arange(nblk // 2 - 1, -1, -1, device=dev) + 1
+        new_of_sorted = torch.empty_like(by_load)
+        new_of_sorted.scatter_(1, by_load, label.expand(nt, nblk))
+        blk_of_atom = tile_of_atom * nblk + new_of_sorted.reshape(-1)[sblk_of_atom]  # global block id, kernel order
+        need = torch.zeros_like(need).view(nt, nblk, K).scatter_(
+            1, new_of_sorted.unsqueeze(-1).expand(nt, nblk, K), need.view(nt, nblk, K)).reshape(-1)
+        tile_atom = torch.full((nt * tv,), -1, dtype=torch.int64, device=dev)
+        tile_atom[blk_of_atom * 16 + row_of_atom] = torch.arange(V, device=dev)
+        # memory order of the row-tiles: (t, block, k, rank)
         rt_start = torch.zeros(need.numel() + 1, dtype=torch.int64, device=dev)
-        rt_start[1:] = torch.cumsum(need.reshape(-1), 0)
+        rt_start[1:] = torch.cumsum(need, 0)
         R = int(rt_start[-1].item())
-        per_sub = (nblk // 4) * K
-        rt_ptr64 = rt_start[::per_sub]
+        rt_ptr64 = rt_start[::K]
         if R and int((rt_ptr64[1:] - rt_ptr64[:-1]).max()) > rtmax:
-            return None                                   # a sub-tile with more row-tiles than the kernel parks in LDS
+            return None                                   # a block with more row-tiles than the kernel parks in LDS
         grp = torch.arange(need.numel(), device=dev)
-        g_hi = grp % (nblk // 4)
-        g_k = (grp // (nblk // 4)) % K
-        rt_grp = torch.repeat_interleave(grp, need.reshape(-1), output_size=R)
-        slots = (tv | (g_k[rt_grp] << 16) | (g_hi[rt_grp] << 20)).repeat_interleave(16)   # empty: the zero row
+        rt_grp = torch.repeat_interleave(grp, need, output_size=R)
+        slots = (tv | ((rt_grp % K) << 16)).repeat_interleave(16)                      # empty: the zero row
         slot_eid = torch.full((16 * R,), -1, dtype=torch.int64, device=dev)
         if E:
             # rank of an edge among the edges of its (destination, type), in edge order
             key = dst * K + et
             order = torch.sort(key, stable=True).indices
-            skey = key[order]
             first = torch.zeros(V * K + 1, dtype=torch.int64, device=dev)
             first[1:] = torch.cumsum(cnt.reshape(-1), 0)
             rank = torch.empty(E, dtype=torch.int64, device=dev)
-            rank[order] = torch.arange(E, device=dev) - first[skey]
-            t_e, b_e = tile_of_atom[dst], pos_in_tile[dst] // 16
-            gid = ((t_e * 4 + b_e % 4) * K + et) * (nblk // 4) + b_e // 4
-            pos = (rt_start[gid] + rank) * 16 + row_of_atom[dst]
-            slots[pos] = src_local | (1 << 14) | (et << 16) | ((b_e // 4) << 20)
+            rank[order] = torch.arange(E, device=dev) - first[key[order]]
+            pos = (rt_start[blk_of_atom[dst] * K + et] + rank) * 16 + row_of_atom[dst]
+            slots[pos] = src_local | (1 << 14) | (et << 16)
             slot_eid[pos] = torch.arange(E, device=dev)
         return cls(tile_ptr, _i32(tile_atom).view(nt, tv), _i32(rt_ptr64), _i32(slots), _i32(slot_eid), tv)
 

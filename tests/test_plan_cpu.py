@@ -18,24 +18,28 @@ def _walk(g, h, A):
         a0, n = rec[t, 0], rec[t, 1]
         assert 0 < n <= p.tile_atoms
         assert sorted(a for a in ta[t] if a >= 0) == list(range(a0, a0 + n))        # a permutation of the tile's atoms
-        for q in range(4):
-            last = (-1, -1)
-            for rt in range(rec[t, 2 + q], rec[t, 3 + q]):
-                k, bk = (sl[rt * 16] >> 16) & 15, (sl[rt * 16] >> 20) & 1
-                assert (k, bk) >= last                         # a sub-tile's row-tiles: by type, then destination block
-                last = (k, bk)
+        for B in range(8):
+            last = -1
+            for rt in range(rec[t, 2 + B], rec[t, 3 + B]):
+                k = (sl[rt * 16] >> 16) & 15
+                assert k >= last                               # a block's row-tiles: by type (then rank)
+                last = k
                 for m in range(16):
                     wd, e = sl[rt * 16 + m], se[rt * 16 + m]
-                    assert ((wd >> 16) & 15) == k and ((wd >> 20) & 1) == bk
+                    assert ((wd >> 16) & 15) == k
                     if e < 0:
                         assert (wd & 0x7fff) == p.tile_atoms  # empty: not valid, reads the zero row
                         continue
                     assert (wd >> 14) & 1
-                    d = ta[t, 64 * bk + 16 * q + m]            # row m of block (bk, q) is this atom
+                    d = ta[t, 16 * B + m]                      # row m of block B is this atom
                     assert d == g.edge_dst[e] and a0 + (wd & 0xff) == g.col_idx[e] and k == g.edge_type[e]
                     seen[e] += 1
                     out[d] += A[k] @ h[a0 + (wd & 0xff)]
     assert (seen == 1).all()
+    # balance: blocks 2p / 2p+1 of a tile are its p-th heaviest / p-th lightest by row-tile count
+    loads = np.diff(rec[:, 2:11], axis=1)
+    assert (np.diff(loads[:, 0::2], axis=1) <= 0).all() and (np.diff(loads[:, 1::2], axis=1) >= 0).all()
+    assert (loads[:, 0::2].min(axis=1) >= loads[:, 1::2].max(axis=1)).all()
     return out
 
 
@@ -54,7 +58,7 @@ def test_plan_walk_reproduces_the_neighbour_sum(n_mols, seed, dist):
     assert tp[0] == 0 and tp[-1] == g.num_nodes and set(tp.tolist()) <= set(g.graph_ptr.numpy().tolist())
     rec = p.tile_rec.numpy()
     assert np.array_equal(rec[:, 0], tp[:-1]) and np.array_equal(rec[:, 0] + rec[:, 1], tp[1:])
-    assert np.array_equal(rec[:, 2:6].reshape(-1), p.rt_ptr.numpy()[:-1]) and np.array_equal(rec[:, 6], p.rt_ptr.numpy()[4::4])
+    assert np.array_equal(rec[:, 2:10].reshape(-1), p.rt_ptr.numpy()[:-1]) and np.array_equal(rec[:, 10], p.rt_ptr.numpy()[8::8])
 
 
 def test_plan_edge_order_within_a_destination_and_type_is_rank_order():
