@@ -447,19 +447,20 @@ def main():
         weighted = graph.agg_weight is not None
         fused_ms = timer.mean_ms("message_aggregate")
         if fused_ms is not None:
-            # every h row read once (LDS-staged molecule tile), every out row written once, the tile plan's slot and
-            # row-tile words read once: the kernel's minimum traffic.  SURVEY 8(d)'s fused-gather formula counts the
-            # gathered row of every EDGE (4*nf*E) -- bytes this kernel serves from LDS instead -- and is given beside it.
-            plan_bytes = float(graph.plan_bytes())
-            alg_bytes = 4.0 * F * Vb + 4.0 * F * Vb + plan_bytes
-            survey_bytes = 4.0 * F * Eb + 4.0 * Eb + 4.0 * (Vb + 1) + 4.0 * F * Vb
+            # SURVEY 8(d) gives two aggregator byte formulas and asks to say which is used.  The fused kernel is priced
+            # with the FUSED-GATHER one (a gathered source row per edge + the out rows + indices): that is the work the
+            # reference's fused bmm does per step, and what a kernel without the LDS tile would have to move.  What this
+            # kernel really has to fetch is less -- every h row once, every out row once, the plan words -- and is
+            # reported beside it as `min_traffic`, the figure to hold PMC `traffic` against.
+            alg_bytes = 4.0 * F * Eb + 4.0 * Eb + 4.0 * (Vb + 1) + 4.0 * F * Vb
+            min_bytes = 4.0 * F * Vb + 4.0 * F * Vb + float(graph.plan_bytes())
             agg_ms, kname, ksub = fused_ms, "message_sum_tile_kernel (fused typed message + neighbour sum, mpnn_message_aggregate_f32)", "message_sum_tile"
-            formula = "4*nf*V + 4*mf*V + tile-plan words (h rows and out rows once each; gathers served from the LDS tile)"
+            formula = "SURVEY 8(d) fused-gather: 4*nf*E + 4*E + 4*(V+1) + 4*mf*V"
         else:
             alg_bytes = 4.0 * F * (Eb + Vb) + 4.0 * (Vb + 1) + (4.0 * Eb if weighted else 0.0)
-            survey_bytes = None
+            min_bytes = None
             agg_ms, kname, ksub = timer.mean_ms("segsum"), "segsum_pair_kernel (aggregator, mpnn_segsum_f32)", "segsum"
-            formula = "4*mf*(E+V) + 4*(V+1) (+4*E weights)"
+            formula = "SURVEY 8(d): 4*mf*(E+V) + 4*(V+1) (+4*E weights)"
         achieved = alg_bytes / (agg_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(args.workload, ksub)
         out = {
@@ -487,11 +488,11 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "formula": formula},
             "kernels_ms": {k: timer.mean_ms(k) for k in sorted(timer.names)},
         }
-        if survey_bytes is not None:
-            out["roofline"]["survey_8d_fused_gather"] = {
-                "formula": "4*nf*E + 4*E + 4*(V+1) + 4*mf*V", "bytes": survey_bytes,
-                "GB/s": survey_bytes / (agg_ms * 1e-3) / 1e9,
-                "note": "counts one gathered row per edge; above the HBM peak means the rows were NOT fetched per edge"}
+        if min_bytes is not None:
+            out["roofline"]["min_traffic"] = {
+                "formula": "4*nf*V + 4*mf*V + tile-plan words (h rows and out rows once each; gathers served from the LDS tile)",
+                "bytes": min_bytes, "GB/s": min_bytes / (agg_ms * 1e-3) / 1e9, "frac_of_peak": min_bytes / (agg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "the bytes this kernel must move; `traffic` (PMC) is to be read against this number"}
         if world > 1 or args.scaling == "strong":
             out["sharding"] = {"global_mols": int(sum(mols_per_rank)), "global_edges": int(total_edges),
                                "edges_per_rank_max": max(edges_per_rank), "edges_per_rank_min": min(edges_per_rank),

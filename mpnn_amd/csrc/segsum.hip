@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(256) segsum_kernel(const float* __restrict__ m
 // Variant 2: each lane group reduces TWO adjacent atoms per pass (their rows are one contiguous
 // span [e0,e2)), up to 8 row loads in flight per group, and the next pass's three row_ptr values are
 // requested before the current rows are summed (one dependent round trip per pass instead of two).
-template <int VEC, int LPR, bool NT>
+template <int VEC, int LPR, bool NT, bool HUB = (LPR >= 32)>
 __global__ void __launch_bounds__(256) segsum_pair_kernel(const float* __restrict__ msg,
                                                           const int32_t* __restrict__ row_ptr,
                                                           const float* __restrict__ w, float* __restrict__ out,
@@ -124,35 +124,51 @@ __global__ void __launch_bounds__(256) segsum_pair_kernel(const float* __restric
             int a = e0, b = e1;
             while (a < e1 || b < e2) {
                 const int na = e1 - a, nb = e2 - b;
+                // Skewed degrees (configs[4]): a hub row outlives its partner by many passes and would then run with four
+                // loads in flight instead of eight.  At the wide widths (a lane group = half a wave or a whole one, so
+                // the branch below is all but uniform) the finished atom's four load slots go to the survivor: its
+                // rows a+4 .. a+7 ride in them and are added AFTER rows a .. a+3 -- same edge order, same result.
+                const bool soloA = HUB && nb <= 0, soloB = HUB && na <= 0;
+                const int sb = soloA ? a + 4 : b, cb = soloA ? na - 4 : nb;       // what the B slots load, and how many
+                const int sa = soloB ? b + 4 : a, ca = soloB ? nb - 4 : na;       // (solo B: the A slots take b+4 .. b+7)
                 Row<VEC> ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
                 ra0.zero(); ra1.zero(); ra2.zero(); ra3.zero();
                 rb0.zero(); rb1.zero(); rb2.zero(); rb3.zero();
                 float wa0 = 0.f, wa1 = 0.f, wa2 = 0.f, wa3 = 0.f, wb0 = 0.f, wb1 = 0.f, wb2 = 0.f, wb3 = 0.f;
-                if (na > 0) { if (NT) ra0.load_nt(msg + (int64_t)(a + 0) * F + c); else ra0.load(msg + (int64_t)(a + 0) * F + c); }
-                if (na > 1) { if (NT) ra1.load_nt(msg + (int64_t)(a + 1) * F + c); else ra1.load(msg + (int64_t)(a + 1) * F + c); }
-                if (na > 2) { if (NT) ra2.load_nt(msg + (int64_t)(a + 2) * F + c); else ra2.load(msg + (int64_t)(a + 2) * F + c); }
-                if (na > 3) { if (NT) ra3.load_nt(msg + (int64_t)(a + 3) * F + c); else ra3.load(msg + (int64_t)(a + 3) * F + c); }
-                if (nb > 0) { if (NT) rb0.load_nt(msg + (int64_t)(b + 0) * F + c); else rb0.load(msg + (int64_t)(b + 0) * F + c); }
-                if (nb > 1) { if (NT) rb1.load_nt(msg + (int64_t)(b + 1) * F + c); else rb1.load(msg + (int64_t)(b + 1) * F + c); }
-                if (nb > 2) { if (NT) rb2.load_nt(msg + (int64_t)(b + 2) * F + c); else rb2.load(msg + (int64_t)(b + 2) * F + c); }
-                if (nb > 3) { if (NT) rb3.load_nt(msg + (int64_t)(b + 3) * F + c); else rb3.load(msg + (int64_t)(b + 3) * F + c); }
+                if (ca > 0) { if (NT) ra0.load_nt(msg + (int64_t)(sa + 0) * F + c); else ra0.load(msg + (int64_t)(sa + 0) * F + c); }
+                if (ca > 1) { if (NT) ra1.load_nt(msg + (int64_t)(sa + 1) * F + c); else ra1.load(msg + (int64_t)(sa + 1) * F + c); }
+                if (ca > 2) { if (NT) ra2.load_nt(msg + (int64_t)(sa + 2) * F + c); else ra2.load(msg + (int64_t)(sa + 2) * F + c); }
+                if (ca > 3) { if (NT) ra3.load_nt(msg + (int64_t)(sa + 3) * F + c); else ra3.load(msg + (int64_t)(sa + 3) * F + c); }
+                if (cb > 0) { if (NT) rb0.load_nt(msg + (int64_t)(sb + 0) * F + c); else rb0.load(msg + (int64_t)(sb + 0) * F + c); }
+                if (cb > 1) { if (NT) rb1.load_nt(msg + (int64_t)(sb + 1) * F + c); else rb1.load(msg + (int64_t)(sb + 1) * F + c); }
+                if (cb > 2) { if (NT) rb2.load_nt(msg + (int64_t)(sb + 2) * F + c); else rb2.load(msg + (int64_t)(sb + 2) * F + c); }
+                if (cb > 3) { if (NT) rb3.load_nt(msg + (int64_t)(sb + 3) * F + c); else rb3.load(msg + (int64_t)(sb + 3) * F + c); }
                 if (w) {
-                    if (na > 0) wa0 = w[a];
-                    if (na > 1) wa1 = w[a + 1];
-                    if (na > 2) wa2 = w[a + 2];
-                    if (na > 3) wa3 = w[a + 3];
-                    if (nb > 0) wb0 = w[b];
-                    if (nb > 1) wb1 = w[b + 1];
-                    if (nb > 2) wb2 = w[b + 2];
-                    if (nb > 3) wb3 = w[b + 3];
-                    accA.fma(ra0, wa0); accA.fma(ra1, wa1); accA.fma(ra2, wa2); accA.fma(ra3, wa3);
-                    accB.fma(rb0, wb0); accB.fma(rb1, wb1); accB.fma(rb2, wb2); accB.fma(rb3, wb3);
+                    if (ca > 0) wa0 = w[sa];
+                    if (ca > 1) wa1 = w[sa + 1];
+                    if (ca > 2) wa2 = w[sa + 2];
+                    if (ca > 3) wa3 = w[sa + 3];
+                    if (cb > 0) wb0 = w[sb];
+                    if (cb > 1) wb1 = w[sb + 1];
+                    if (cb > 2) wb2 = w[sb + 2];
+                    if (cb > 3) wb3 = w[sb + 3];
+                    ra0.scale(wa0); ra1.scale(wa1); ra2.scale(wa2); ra3.scale(wa3);
+                    rb0.scale(wb0); rb1.scale(wb1); rb2.scale(wb2); rb3.scale(wb3);
+                }
+                if (soloA) {            // rows a .. a+7 of atom A, in order
+                    accA.add(ra0); accA.add(ra1); accA.add(ra2); accA.add(ra3);
+                    accA.add(rb0); accA.add(rb1); accA.add(rb2); accA.add(rb3);
+                    a += 8;
+                } else if (soloB) {     // rows b .. b+7 of atom B: the B slots hold b .. b+3, the A slots b+4 .. b+7
+                    accB.add(rb0); accB.add(rb1); accB.add(rb2); accB.add(rb3);
+                    accB.add(ra0); accB.add(ra1); accB.add(ra2); accB.add(ra3);
+                    b += 8;
                 } else {
                     accA.add(ra0); accA.add(ra1); accA.add(ra2); accA.add(ra3);
                     accB.add(rb0); accB.add(rb1); accB.add(rb2); accB.add(rb3);
+                    a += 4;
+                    b += 4;
                 }
-                a += 4;
-                b += 4;
             }
             if (NT) {
                 accA.store_nt(out + i * F + c);

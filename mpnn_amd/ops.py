@@ -144,9 +144,9 @@ def message_aggregate_tile_raw(h, A, graph):
     K, mf, nf = (int(s) for s in A.shape)
     V = graph.num_nodes
     plan = graph.tile_plan
+    if V == 0 or graph.num_edges == 0:                  # no bonds at all: every row is an empty sum
+        return torch.zeros(V, mf, dtype=torch.float32, device=h.device)
     out = _empty((V, mf), h)
-    if V == 0:
-        return out
     _lib.check(_timed("message_aggregate", lambda: lib.mpnn_message_aggregate_f32(
         _lib.fptr(h), _lib.fptr(A), _lib.iptr(plan.tile_rec), _lib.iptr(plan.tile_atom), _lib.iptr(plan.slots),
         _lib.fptr(out), V, plan.num_tiles, K, nf, mf, _lib.stream())), "mpnn_message_aggregate_f32")

@@ -4,7 +4,8 @@
 MI355X_MICROARCH.md "HBM": counters are in KiB; FETCH_SIZE reports exactly half of a wide
 (16 B/lane) coalesced read stream, WRITE_SIZE is exact for 16-B-per-lane stores.
 
-    python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_c2.json
+    python tools/pmc_summary.py gpurun_out/m_fetch gpurun_out/m_write profiles/r02_pmc_c2.json [commit]
+(called by tools/refresh_profiles.py, the only writer of profiles/r02_pmc_*.json)
 """
 import csv
 import glob
@@ -24,8 +25,8 @@ def per_kernel(dirname, counter):
 def main():
     fetch, n = per_kernel(sys.argv[1], "FETCH_SIZE")
     write, _ = per_kernel(sys.argv[2], "WRITE_SIZE")
-    out = {"workload": "c2", "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) "
-                                        "-- python3 bench.py --steps 2 --warmup 1 --no-cpu --mode fwd",
+    out = {"workload": "c2", "commit": sys.argv[4] if len(sys.argv) > 4 else None, "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) "
+                                        "-- python3 bench.py --steps 2 --warmup 1 --no-cpu",
            "corrections": "KiB -> bytes (x1024); FETCH_SIZE x2 (gfx950 counts a 16 B/lane coalesced stream at half)",
            "kernels": {}}
     for k in fetch:

@@ -4,7 +4,7 @@
     rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
         SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 \
         -d gpurun_out/pmc_sq --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu
-    python tools/sq_summary.py gpurun_out/pmc_sq profiles/r01_sq_c2.json
+    python tools/sq_summary.py gpurun_out/pmc_sq profiles/r02_sq_c2.json
 
 Units (MI355X_MICROARCH.md "rocprofv3 PMC slots"): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles
 summed over waves; WAIT_ANY (parked on s_waitcnt/barrier) + WAIT_INST_ANY (issue stall) + ACTIVE_INST_ANY ~= WAVE_CYCLES.
