@@ -158,6 +158,25 @@ int mpnn_message_aggregate_f32(const float* h, const float* A, const int32_t* ti
                                const int32_t* slots, float* out,
                                int64_t V, int64_t num_tiles, int K, int nf, int mf, void* stream);
 
+/*
+ * Weight gradient of the above, on the same tile plan and with dagg and h each read once:
+ *   dA[k] += sum_{e of type k} dagg[dst[e], :] (x) h[src[e], :]        (K x mf x nf, zeroed by the caller)
+ * replaces: the autograd of edge_network.py:50-51 with respect to the edge matrices (the dA part of
+ * mpnn_edge_message_agg_bwd_da_f32, which gathers both rows per edge from HBM).
+ *   tile_rtk[T][8K+1]  first row-tile of every (block, type) of the tile, then the tile's end
+ * Same limits as mpnn_message_aggregate_f32 (nf = mf = 64, K <= 4, unit weights, no gate).
+ */
+int mpnn_message_aggregate_bwd_da_f32(const float* dagg, const float* h, const int32_t* tile_rec, const int32_t* tile_atom,
+                                      const int32_t* tile_rtk, const int32_t* slots, float* dA,
+                                      int64_t V, int64_t num_tiles, int K, int nf, int mf, void* stream);
+
+/*
+ * BiLiniearEdgeNetwork message on the dense padded batch: out[b,i,j,k] = sum_{a,c} afm[b,j,a] T[b,i,j][a,k,c] afm[b,i,c]
+ * with T = the pair's nf^3 bond features viewed (nf, nf, nf).
+ * replaces: mpnn_functions/message/bilinear_edge_network.py:25-37.  afm [B,N,nf], bfm [B,N,N,nf^3], out [B,N,N,nf]; nf <= 8.
+ */
+int mpnn_bilinear_message_f32(const float* afm, const float* bfm, float* out, int64_t B, int N, int nf, void* stream);
+
 /* ------------------------------------------------------------------ edge tower ----- */
 /*
  * The run of n_layers aliased Linear(L, L, bias=False) + ReLU blocks of the bond-feature tower

@@ -48,6 +48,8 @@ _SIGNATURES = {
     "mpnn_message_aggregate_max_types": (ctypes.c_int, []),
     "mpnn_message_aggregate_max_row_tiles": (ctypes.c_int, []),
     "mpnn_message_aggregate_f32": (ctypes.c_int, [c_f, c_f, c_i, c_i, c_i, c_f, i64, i64, i32, i32, i32, c_v]),
+    "mpnn_message_aggregate_bwd_da_f32": (ctypes.c_int, [c_f, c_f, c_i, c_i, c_i, c_i, c_f, i64, i64, i32, i32, i32, c_v]),
+    "mpnn_bilinear_message_f32": (ctypes.c_int, [c_f, c_f, c_f, i64, i32, i32, c_v]),
     "mpnn_segsum_f32": (ctypes.c_int, [c_f, c_i, c_f, c_f, i64, i32, c_v]),
     "mpnn_segsum_bwd_f32": (ctypes.c_int, [c_f, c_i, c_f, c_f, i64, i32, c_v]),
     "mpnn_segsum_gather_f32": (ctypes.c_int, [c_f, c_i, c_i, c_f, c_f, i64, i32, c_v]),

@@ -297,6 +297,16 @@ class MessageAggregate(torch.autograd.Function):
                 return None, None, None, None, None
             lib = _lib.load()
             dA = torch.zeros_like(A)
+            # The tile-plan weight gradient (dagg and h read once, no per-edge gathers from HBM) is parity-green but
+            # measured SLOWER than the per-edge gather kernel at the c2 size (0.76 vs 0.65-0.70 ms: three MFMAs per
+            # row-tile and wave leave its loop latency-bound), so it is opt-in: MPNN_TILE_BWD=1.
+            if os.environ.get("MPNN_TILE_BWD") and tile_kernel_applies(A, gate, w, g) and g.num_edges:
+                plan = g.tile_plan
+                _lib.check(_timed("message_aggregate_bwd", lambda: lib.mpnn_message_aggregate_bwd_da_f32(
+                    _lib.fptr(dout), _lib.fptr(h), _lib.iptr(plan.tile_rec), _lib.iptr(plan.tile_atom),
+                    _lib.iptr(plan.tile_rtk), _lib.iptr(plan.slots), _lib.fptr(dA), g.num_nodes, plan.num_tiles, K, nf, mf,
+                    _lib.stream())), "mpnn_message_aggregate_bwd_da_f32")
+                return None, dA, None, None, None
             if g.num_edges:
                 _lib.check(_timed("message_aggregate_bwd", lambda: lib.mpnn_edge_message_agg_bwd_da_f32(
                     _lib.fptr(dout), _lib.fptr(h), _lib.iptr(g.col_idx), _lib.iptr(g.edge_dst), _lib.fptr(w),

@@ -73,6 +73,26 @@ def test_bilinear(dev):
         assert max_err(BiLiniearEdgeNetwork(3, 27, 3)(i["afm"], i["bfm"]).cpu(), f.out[""]) < TOL
 
 
+@pytest.mark.parametrize("nf,B,N", [(1, 2, 3), (4, 3, 7), (5, 2, 6), (8, 5, 11)])
+def test_bilinear_kernel_and_gradients_against_float64(dev, nf, B, N):
+    """mpnn_bilinear_message_f32 and the autograd of the module against the reference's two matmuls in float64
+    (mpnn_functions/message/bilinear_edge_network.py:35-37)."""
+    from mpnn_amd.mpnn_functions import BiLiniearEdgeNetwork
+    gen = torch.Generator(device=dev).manual_seed(nf)
+    afm = torch.randn(B, N, nf, device=dev, generator=gen, requires_grad=True)
+    bfm = torch.randn(B, N, N, nf ** 3, device=dev, generator=gen, requires_grad=True)
+    cot = torch.randn(B, N, N, nf, device=dev, generator=gen)
+    out = BiLiniearEdgeNetwork(nf, nf ** 3, nf)(afm, bfm).reshape(B, N, N, nf)
+    out.backward(cot)
+    a64, b64 = afm.detach().double().requires_grad_(True), bfm.detach().double().requires_grad_(True)
+    ees = (B, N, N, nf, -1)
+    ref = a64.unsqueeze(1).unsqueeze(-2).matmul(b64.view(ees)).view(ees).matmul(a64.unsqueeze(2).unsqueeze(-1)).reshape(B, N, N, nf)
+    ref.backward(cot.double())
+    assert max_err(out.detach(), ref.detach()) < 1e-5 * max(1.0, float(ref.abs().max()))
+    assert max_err(afm.grad, a64.grad) < 1e-5 * max(1.0, float(a64.grad.abs().max()))
+    assert max_err(bfm.grad, b64.grad) < 1e-5 * max(1.0, float(b64.grad.abs().max()))
+
+
 def test_aggregators_on_dense_messages(dev):
     from mpnn_amd.mpnn_functions import AdjMsgAgg, AttMsgAgg, WAdjMsgAgg
     for name, make in (("agg_adj", lambda: AdjMsgAgg(9)), ("agg_adj_weighted", lambda: AdjMsgAgg(9)),
