@@ -37,7 +37,44 @@ __device__ __forceinline__ int col_swizzle(int col) {
     return H == 64 ? ((col >> 1) & 7) : (col & 15);
 }
 
-template <int H, int NCS, int NW, bool HAS_MASK, bool SAVE>
+// ---- "fp16x3" (F16 = true): two fp16 pieces per operand and three MFMAs per product instead of three bf16 pieces and six.
+// fp16 has 11 significant bits but only 5 exponent bits, so the operands are range-guarded by exact power-of-two scales:
+// one for the weight images of a block (its largest |w| lands in [2^14, 2^15)), one per 32-atom tile for its m and h
+// rows together (they share the r / z accumulators); x*s = hi + lo, hi = fp16(x*s), lo = fp16(x*s - hi).  Entries more
+// than 2^18 below their tile's largest lose relative (not absolute) accuracy: the error of a gate pre-activation is
+// ~2^-22 of (tile max) x (weight max) per term, as for a GEMM.  The scales are undone in the epilogue.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void pow2_scale_of(float maxabs, float& scale, float& inv) {
+    int e = (__float_as_int(maxabs) >> 23) & 0xff;
+    e = e < 20 ? 20 : e;
+    scale = __int_as_float((268 - e) << 23);
+    inv = __int_as_float((e - 14) << 23);
+}
+
+__device__ __forceinline__ void split8_f16(const f32x4& x0, const f32x4& x1, float sc, f16x8& ph, f16x8& pl) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = x0[j] * sc, b = x1[j] * sc;
+        ph[j] = (_Float16)a;
+        pl[j] = (_Float16)(a - (float)ph[j]);
+        ph[4 + j] = (_Float16)b;
+        pl[4 + j] = (_Float16)(b - (float)ph[4 + j]);
+    }
+}
+
+// three partial products of one K=16 step, two independent accumulators that share the A pieces, small terms first
+__device__ __forceinline__ void mma3x2_a(f32x16& c0, f32x16& c1, const f16x8& ah, const f16x8& al, const f16x8& b0h,
+                                         const f16x8& b0l, const f16x8& b1h, const f16x8& b1l) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b0h, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b1h, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0l, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1l, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0h, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1h, c1, 0, 0, 0);
+}
+
+template <int H, int NCS, int NW, bool HAS_MASK, bool SAVE, bool F16 = false>
 __global__ void __launch_bounds__(64 * NW) gru_update_split_kernel(
     const float* __restrict__ m, const float* __restrict__ h, const float* __restrict__ mask,
     const float* __restrict__ W_ih, const float* __restrict__ W_hh, const float* __restrict__ b_ih,
@@ -56,7 +93,30 @@ __global__ void __launch_bounds__(64 * NW) gru_update_split_kernel(
     const int c0 = slice * CS;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
-    // ---- one-time: split this block's weight slices into the three bf16 images ----
+    // ---- one-time: split this block's weight slices into the three bf16 images (F16: two fp16 images, one scale) ----
+    float w_sc = 1.0f, w_inv = 1.0f;
+    if (F16) {
+        float mx = 0.f;
+        for (int idx = tid; idx < 2 * H * (NCOL / 4); idx += 64 * NW) {
+            const int mat = idx / (H * (NCOL / 4));
+            const int rem = idx % (H * (NCOL / 4));
+            const int k = rem / (NCOL / 4), q = rem % (NCOL / 4);
+            const int g = (4 * q) / CS, cc = (4 * q) % CS;
+            const float* W = mat == 0 ? W_ih : W_hh;
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(W + (int64_t)k * 3 * H + g * H + c0 + cc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mx = fmaxf(mx, fabsf(w4[j]));
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float* redw = reinterpret_cast<float*>(smem);                 // scratch: the images are written after the barrier
+        if (lane == 0) redw[wv] = mx;
+        __syncthreads();
+        mx = 0.f;
+        for (int u = 0; u < NW; ++u) mx = fmaxf(mx, redw[u]);
+        __syncthreads();
+        pow2_scale_of(mx, w_sc, w_inv);
+    }
     for (int idx = tid; idx < 2 * H * (NCOL / 4); idx += 64 * NW) {
         const int mat = idx / (H * (NCOL / 4));
         const int rem = idx % (H * (NCOL / 4));
@@ -67,12 +127,20 @@ __global__ void __launch_bounds__(64 * NW) gru_update_split_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int col = g * CS + cc + j;
-            __bf16 ph, pm, pl;
-            split3(w4[j], ph, pm, pl);
             const int off = col * ROWB + (((k >> 3) ^ col_swizzle<H>(col)) << 4) + ((k & 7) << 1);
-            *reinterpret_cast<__bf16*>(smem + (mat * 3 + 0) * IMG + off) = ph;
-            *reinterpret_cast<__bf16*>(smem + (mat * 3 + 1) * IMG + off) = pm;
-            *reinterpret_cast<__bf16*>(smem + (mat * 3 + 2) * IMG + off) = pl;
+            if (F16) {
+                const float a = w4[j] * w_sc;
+                const _Float16 ph = (_Float16)a;
+                const _Float16 pl = (_Float16)(a - (float)ph);
+                *reinterpret_cast<_Float16*>(smem + (mat * 3 + 0) * IMG + off) = ph;
+                *reinterpret_cast<_Float16*>(smem + (mat * 3 + 1) * IMG + off) = pl;
+            } else {
+                __bf16 ph, pm, pl;
+                split3(w4[j], ph, pm, pl);
+                *reinterpret_cast<__bf16*>(smem + (mat * 3 + 0) * IMG + off) = ph;
+                *reinterpret_cast<__bf16*>(smem + (mat * 3 + 1) * IMG + off) = pm;
+                *reinterpret_cast<__bf16*>(smem + (mat * 3 + 2) * IMG + off) = pl;
+            }
         }
     }
     __syncthreads();
@@ -113,7 +181,13 @@ __global__ void __launch_bounds__(64 * NW) gru_update_split_kernel(
                                                 ((chunk ^ col_swizzle<H>(col)) << 4));
     };
 
+    auto bfrag16 = [&](int mat, int piece, int col, int s) {
+        const int chunk = hi * (NCH / 2) + s;
+        return *reinterpret_cast<const f16x8*>(smem + (mat * 3 + piece) * IMG + col * ROWB +
+                                               ((chunk ^ col_swizzle<H>(col)) << 4));
+    };
     load_frags(m, t, fa);
+    if (F16) load_frags(h, t, fb);                       // fp16 pieces need the tile's scale: both operands up front
     for (; t < tiles; t += stride) {
         f32x16 acc_r[NCS], acc_z[NCS], acc_ni[NCS], acc_nh[NCS];
 #pragma unroll
@@ -121,10 +195,50 @@ __global__ void __launch_bounds__(64 * NW) gru_update_split_kernel(
 #pragma unroll
             for (int i = 0; i < 16; ++i) { acc_r[s][i] = 0.f; acc_z[s][i] = 0.f; acc_ni[s][i] = 0.f; acc_nh[s][i] = 0.f; }
 
-        load_frags(h, t, fb);                            // in flight while the m-products run
-        __builtin_amdgcn_sched_barrier(0);
+        float t_sc = 1.0f, t_inv = 1.0f;
+        if (F16) {
+            float mx = 0.f;
 #pragma unroll
-        for (int st = 0; st < STEPS; ++st) {
+            for (int q = 0; q < NF4; ++q)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fmaxf(fabsf(fa[q][u]), fabsf(fb[q][u])));
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            pow2_scale_of(mx, t_sc, t_inv);
+            t_inv *= w_inv;
+        } else {
+            load_frags(h, t, fb);                        // in flight while the m-products run
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (F16) {
+            static_assert(!F16 || NCS == 2, "the fp16 variant is written for two column slices per gate");
+#pragma unroll
+            for (int st = 0; st < STEPS; ++st) {
+                f16x8 ah, al;
+                split8_f16(fa[2 * st], fa[2 * st + 1], t_sc, ah, al);
+                auto pair = [&](f32x16 (&acc)[NCS], int g) {
+                    const int c0_ = g * CS + r, c1_ = g * CS + 32 + r;
+                    mma3x2_a(acc[0], acc[NCS - 1], ah, al, bfrag16(0, 0, c0_, st), bfrag16(0, 1, c0_, st),
+                             bfrag16(0, 0, c1_, st), bfrag16(0, 1, c1_, st));
+                };
+                pair(acc_r, 0); pair(acc_z, 1); pair(acc_ni, 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int st = 0; st < STEPS; ++st) {
+                f16x8 ah, al;
+                split8_f16(fb[2 * st], fb[2 * st + 1], t_sc, ah, al);
+                auto pair = [&](f32x16 (&acc)[NCS], int g) {
+                    const int c0_ = g * CS + r, c1_ = g * CS + 32 + r;
+                    mma3x2_a(acc[0], acc[NCS - 1], ah, al, bfrag16(1, 0, c0_, st), bfrag16(1, 1, c0_, st),
+                             bfrag16(1, 0, c1_, st), bfrag16(1, 1, c1_, st));
+                };
+                pair(acc_r, 0); pair(acc_z, 1); pair(acc_nh, 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < (F16 ? 0 : STEPS); ++st) {
             bf16x8 ah, am, al;
             split8(fa[2 * st], fa[2 * st + 1], ah, am, al);
             if (NCS == 2) {
@@ -148,7 +262,7 @@ __global__ void __launch_bounds__(64 * NW) gru_update_split_kernel(
             __builtin_amdgcn_sched_barrier(0);           // bounds how far ahead weight fragments are read (registers)
         }
 #pragma unroll
-        for (int st = 0; st < STEPS; ++st) {
+        for (int st = 0; st < (F16 ? 0 : STEPS); ++st) {
             bf16x8 ah, am, al;
             split8(fb[2 * st], fb[2 * st + 1], ah, am, al);
             if (NCS == 2) {
@@ -207,10 +321,16 @@ __global__ void __launch_bounds__(64 * NW) gru_update_split_kernel(
             // next tile's m rows: behind the epilogue loads, ahead of the stores (both operand fragments are dead here);
             // the ragged tile is the last one
             // (unconditional, tile index clamped: under a condition the old fragments would stay live as the other arm)
-            if (FULL) load_frags(m, t + stride < tiles ? t + stride : t, fa);
-            else {
+            if (FULL) {
+                load_frags(m, t + stride < tiles ? t + stride : t, fa);
+                if (F16) load_frags(h, t + stride < tiles ? t + stride : t, fb);
+            } else {
 #pragma unroll
                 for (int q = 0; q < NF4; ++q) fa[q] = f32x4{0.f, 0.f, 0.f, 0.f};   // last tile: defined, never used
+                if (F16) {
+#pragma unroll
+                    for (int q = 0; q < NF4; ++q) fb[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             float* ob = out + t * 32 * H + eo;
@@ -227,10 +347,10 @@ __global__ void __launch_bounds__(64 * NW) gru_update_split_kernel(
                 }
 #pragma unroll
                 for (int s = 0; s < NCS; ++s) {
-                    const float rg = sigmoid_fast(acc_r[s][i] + br[s]) * mk;
-                    const float zg = sigmoid_fast(acc_z[s][i] + bz[s]) * mk;
-                    const float nh = acc_nh[s][i] + bnh[s];
-                    const float ng = tanh_fast(acc_ni[s][i] + bni[s] + rg * nh) * mk;
+                    const float rg = sigmoid_fast((F16 ? acc_r[s][i] * t_inv : acc_r[s][i]) + br[s]) * mk;
+                    const float zg = sigmoid_fast((F16 ? acc_z[s][i] * t_inv : acc_z[s][i]) + bz[s]) * mk;
+                    const float nh = (F16 ? acc_nh[s][i] * t_inv : acc_nh[s][i]) + bnh[s];
+                    const float ng = tanh_fast((F16 ? acc_ni[s][i] * t_inv : acc_ni[s][i]) + bni[s] + rg * nh) * mk;
                     const float hval = FULL ? hv[i][s] : (row0 + dr < V ? hb[dr * H + 32 * s] : 0.f);
                     const float o = ((1.0f - zg) * ng + zg * hval) * mk;
                     if (FULL || row0 + dr < V) {
@@ -276,6 +396,28 @@ static int launch_split(const float* m, const float* h, const float* mask, const
 #define MPNN_LAUNCH_SPLIT(MASKED, SAVED)                                                                                   \
     hipLaunchKernelGGL((gru_update_split_kernel<H, NCS, NW, MASKED, SAVED>), grid, block, lds, s, m, h, mask, W_ih, W_hh,  \
                        b_ih, b_hh, out, saved, V, slices)
+    if (H == 64 && NCS == 2 && switches().gru_fwd_fp16) {          // A/B: two fp16 pieces, three MFMAs per product
+        constexpr bool F = (H == 64 && NCS == 2);
+        static const hipError_t attr16 = [&] {
+            LdsOptIn opt_in_;
+            const int n = (int)lds;
+            opt_in_((const void*)gru_update_split_kernel<H, NCS, NW, true, true, F>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
+            opt_in_((const void*)gru_update_split_kernel<H, NCS, NW, true, false, F>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
+            opt_in_((const void*)gru_update_split_kernel<H, NCS, NW, false, true, F>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
+            opt_in_((const void*)gru_update_split_kernel<H, NCS, NW, false, false, F>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
+            return opt_in_.err;
+        }();
+        if (attr16 != hipSuccess) return lds_opt_in_failed(attr16);
+#define MPNN_LAUNCH_F16(MASKED, SAVED)                                                                                     \
+    hipLaunchKernelGGL((gru_update_split_kernel<H, NCS, NW, MASKED, SAVED, F>), grid, block, lds, s, m, h, mask, W_ih, W_hh, \
+                       b_ih, b_hh, out, saved, V, slices)
+        if (mask && saved) MPNN_LAUNCH_F16(true, true);
+        else if (mask) MPNN_LAUNCH_F16(true, false);
+        else if (saved) MPNN_LAUNCH_F16(false, true);
+        else MPNN_LAUNCH_F16(false, false);
+#undef MPNN_LAUNCH_F16
+        return launch_status("mpnn_gru_update_f32(fp16x3)");
+    }
     if (mask && saved) MPNN_LAUNCH_SPLIT(true, true);
     else if (mask) MPNN_LAUNCH_SPLIT(true, false);
     else if (saved) MPNN_LAUNCH_SPLIT(false, true);

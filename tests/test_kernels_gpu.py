@@ -323,3 +323,20 @@ def test_att_gate_forward_backward(dev, V, F, K):
     assert max_err(gate.detach(), ref.detach()) < 2e-6
     assert max_err(z.grad, z64.grad) < 1e-5
     assert max_err(q.grad, q64.grad) / max(1.0, float(q64.grad.abs().max())) < 1e-5
+
+
+def test_gru_forward_fp16_two_piece_variant_holds_the_parity_bar():
+    """MPNN_GRU_FWD_FP16=1 (two fp16 pieces + power-of-two range guards, three MFMAs per product; an A/B alternate of the
+    default three-way bf16 split, see DESIGN 'fp16 operand pieces') against float64 at the c2 size.  The switch is read
+    once per process, so the variant runs in a child process (tools/bench_gru_fwd.py prints its error)."""
+    import os
+    import re
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = dict(os.environ, MPNN_GRU_FWD_FP16="1")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "bench_gru_fwd.py")], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    err = float(re.search(r"max \|out - float64\| over \d+ atoms = ([0-9.e+-]+)", r.stdout).group(1))
+    assert err < 1e-5
