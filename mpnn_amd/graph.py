@@ -177,10 +177,13 @@ class MolGraph:
         g.edge_feat = None
         return g
 
-    def prepare(self):
-        """Build every derived index array now (type order, transposed graph, destination list, tile plan), so
-        that none of it lands inside a timed or captured region."""
-        self.order, self.type_ptr, self.transpose, self.edge_dst, self.agg_weight, self.tile_plan
+    def prepare(self, tile_plan=True):
+        """Build every derived index array now (type order, transposed graph, destination list and, unless the caller
+        knows the width-64 tile kernels will not run, the tile plan), so that none of it lands inside a timed or
+        captured region."""
+        self.order, self.type_ptr, self.transpose, self.edge_dst, self.agg_weight
+        if tile_plan:
+            self.tile_plan
         return self
 
     def plan_bytes(self):

@@ -23,4 +23,6 @@ for w in $W; do
     timeout -k 10 400 python bench.py --workload $w --warmup 3 > gpurun_out/m_bench_$w.log 2>gpurun_out/m_bench_$w.err
     echo done $w
 done
+# BASELINE configs[3] as a strong-scaling run at one rank: 1 M molecules in 8 micro-batches per step
+timeout -k 10 700 python bench.py --workload c4 --scaling strong --steps 3 --warmup 1 --no-cpu > gpurun_out/m_bench_c4strong.log 2>gpurun_out/m_bench_c4strong.err
 cut -c1-260 gpurun_out/m_bench_c2.log

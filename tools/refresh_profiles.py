@@ -24,7 +24,7 @@ def bench_line(path):
     return lines[-1] if lines else None
 
 
-for w in ("c2", "c1", "c3", "c3a", "c4", "c5"):
+for w in ("c2", "c1", "c3", "c3a", "c4", "c5", "c4strong"):
     f = os.path.join(G, "m_bench_%s.log" % w)
     if os.path.exists(f) and bench_line(f):
         d = json.loads(bench_line(f))
