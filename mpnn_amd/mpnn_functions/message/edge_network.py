@@ -117,7 +117,6 @@ class EdgeNetwork(nn.Module):
             return self._pair_messages(h, emb)
         # HEAD behaviour: m_i = sum_{j in molecule} A(e_ij) h_j + b
         #               = sum_{e in row i} (A_e - A0) h_src(e) + A0 . S_mol(i) + b
-        msg = ops.edge_message(h, emb.A - emb.A0, g)
-        agg = ops.segsum(msg, g.row_ptr)
+        agg = ops.message_aggregate(h, emb.A - emb.A0, g)        # message + neighbour sum as one node (one kernel at width 64)
         base = ops.molecule_sum(h, g) @ emb.A0.t() + self.message_bias
         return g.node_unview(agg + base[g.node_graph])
