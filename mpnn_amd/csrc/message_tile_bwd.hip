@@ -203,13 +203,17 @@ __global__ void __launch_bounds__(512, 2) message_sum_tile_bwd_kernel(
         for (int k = 0; k < MB_KMAX; ++k)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
-        // (A flat, software-pipelined walk over the row-tiles -- next operands requested before the current MFMAs -- was
-        // measured at 0.90 ms against 0.76 ms for these plain loops: its scalar bookkeeping costs more than it hides.)
+        // Block by block; inside a block its row-tiles in memory order (type-major), the type loop unrolled so that each
+        // type has its own static accumulator.  The h fragments of row-tile i + 1 and the slot words of row-tile i + 2
+        // are requested before the MFMAs of row-tile i, across the type boundaries (they do not depend on the type).
+        // (A flat walk over all four blocks driven by a scalar state machine was measured at 0.90 ms: its bookkeeping
+        // cost more than it hid.)
 #pragma unroll 1
         for (int b = 0; b < 4; ++b) {
             const int blk = 4 * bhalf + b;
             const int rb0 = __builtin_amdgcn_readfirstlane(rtk[blk * K]);
-            if (__builtin_amdgcn_readfirstlane(rtk[blk * K + K]) == rb0) continue;   // block without row-tiles (wave-uniform)
+            const int nblk = __builtin_amdgcn_readfirstlane(rtk[blk * K + K]) - rb0;
+            if (nblk == 0) continue;                                   // block without row-tiles (wave-uniform)
             // A operand: the block's own dagg rows, transposed (rows of A = dagg columns of my quadrant)
             f16x8 ah, al;
             {
@@ -220,21 +224,39 @@ __global__ void __launch_bounds__(512, 2) message_sum_tile_bwd_kernel(
                 al = mb_tr8(smem + D_OFF + MB_HT + o0, smem + D_OFF + MB_HT + o1);
             }
             const int* slw = slw_all + blk * 16 * MB_RTMAX;
+            auto words = [&](int i, int& w0, int& w1) {
+                const int ii = i < nblk ? i : 0;
+                w0 = slw[16 * ii + mrow];
+                w1 = slw[16 * ii + mrow + 4];
+            };
+            auto frags = [&](int w0, int w1, f16x8& bh, f16x8& bl) {
+                const int o0 = img_off(w0 & 0xff, xcol), o1 = img_off(w1 & 0xff, xcol);
+                bh = mb_tr8(smem + X_OFF + o0, smem + X_OFF + o1);
+                bl = mb_tr8(smem + X_OFF + MB_HT + o0, smem + X_OFF + MB_HT + o1);
+            };
+            int wa0, wa1, wb0, wb1;
+            f16x8 bh, bl, bh_n, bl_n;
+            words(0, wa0, wa1);
+            frags(wa0, wa1, bh, bl);
+            words(1, wa0, wa1);                                        // (wa: words of the next row-tile)
+            int i = 0;
 #pragma unroll
             for (int k = 0; k < MB_KMAX; ++k) {
                 if (k < K) {
-                    // row-tiles of (block, type k), counted from the block's first (its words start at slw[0]); scalar
-                    // bounds: the transposed reads below need every lane active
-                    const int i0 = __builtin_amdgcn_readfirstlane(rtk[blk * K + k]) - rb0;
+                    // scalar bounds: the transposed reads need every lane active
                     const int i1 = __builtin_amdgcn_readfirstlane(rtk[blk * K + k + 1]) - rb0;
-                    for (int i = i0; i < i1; ++i) {
-                        const int w0 = slw[16 * i + mrow], w1 = slw[16 * i + mrow + 4];
-                        const int o0 = img_off(w0 & 0xff, xcol), o1 = img_off(w1 & 0xff, xcol);
-                        const f16x8 bh = mb_tr8(smem + X_OFF + o0, smem + X_OFF + o1);
-                        const f16x8 bl = mb_tr8(smem + X_OFF + MB_HT + o0, smem + X_OFF + MB_HT + o1);
+                    for (; i < i1; ++i) {
+                        words(i + 2, wb0, wb1);
+                        frags(wa0, wa1, bh_n, bl_n);                   // row-tile i + 1 (a harmless re-read at the end)
+                        __builtin_amdgcn_sched_barrier(0);
                         acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[k], 0, 0, 0);
                         acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[k], 0, 0, 0);
                         acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[k], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        bh = bh_n;
+                        bl = bl_n;
+                        wa0 = wb0;
+                        wa1 = wb1;
                     }
                 }
             }

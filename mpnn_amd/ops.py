@@ -298,7 +298,7 @@ class MessageAggregate(torch.autograd.Function):
             lib = _lib.load()
             dA = torch.zeros_like(A)
             # The tile-plan weight gradient (dagg and h read once, no per-edge gathers from HBM) is parity-green but
-            # measured SLOWER than the per-edge gather kernel at the c2 size (0.76 vs 0.65-0.70 ms: three MFMAs per
+            # measured no faster than the per-edge gather kernel at the c2 size (0.70 vs 0.64-0.70 ms: three MFMAs per
             # row-tile and wave leave its loop latency-bound), so it is opt-in: MPNN_TILE_BWD=1.
             if os.environ.get("MPNN_TILE_BWD") and tile_kernel_applies(A, gate, w, g) and g.num_edges:
                 plan = g.tile_plan
