@@ -506,8 +506,6 @@ def main():
                                 "not a scaling measurement" % (world, ndev, backend))
         # ---- the dense contractions against the pipe they run on: 16-bit MFMA peak divided by the MFMAs issued per fp32
         # product (6 for the three-way bf16 split, 3 for the two-way fp16 split); the fp32-MFMA-peak ratio is a side figure
-        per = ops.mfma_per_product()
-        peak_eq = MFMA_16BIT_PEAK_TF / per if per else MFMA_F32_PEAK_TF
         rows = []
         for key, name, flops in (("edge_message", "typed edge message (mpnn_edge_message_f32)", 2.0 * F * F * Eb),
                                  ("gru_update", "masked GRU update forward (mpnn_gru_update_f32)", 12.0 * F * F * Vb),
@@ -515,6 +513,8 @@ def main():
             ms = timer.mean_ms(key)
             if ms is None:
                 continue
+            per = ops.mfma_per_product(key, hidden)
+            peak_eq = MFMA_16BIT_PEAK_TF / per if per else MFMA_F32_PEAK_TF
             tf = flops / (ms * 1e-3) / 1e12
             rows.append({"kernel": name, "bound": "mfma", "unit": "TFLOP/s (fp32-equivalent)", "achieved": tf,
                          "peak": peak_eq, "frac": tf / peak_eq, "avg_launch_ms": ms,

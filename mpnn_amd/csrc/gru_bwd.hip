@@ -663,6 +663,9 @@ __global__ void __launch_bounds__(512) gru_bwd_uniform_kernel(
 int launch_gru_bwd_presplit64(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
                               const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
                               float* db_ih, float* db_hh, int64_t V, hipStream_t s);   // gru_bwd_presplit.hip
+int launch_gru_bwd_f16_64(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
+                          const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
+                          float* db_ih, float* db_hh, int64_t V, hipStream_t s);       // gru_bwd_f16.hip
 
 int launch_gru_bwd_fused64(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
                            const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
@@ -697,9 +700,12 @@ int launch_gru_bwd_fused64(const float* dout, const float* m, const float* h, co
                                mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, V);
         return launch_status("mpnn_gru_update_bwd_f32(uniform)");
     }
-    // default: gate gradients split once at staging (gru_bwd_presplit.hip); MPNN_GRU_BWD_FP32TILE=1 keeps the fp32
-    // tile whose consumers split what they read
+    // default: gate gradients, m | h and weights as two fp16 pieces, split once at staging (gru_bwd_f16.hip);
+    // MPNN_GRU_BWD_BF16=1: three bf16 pieces (gru_bwd_presplit.hip); MPNN_GRU_BWD_FP32TILE=1 keeps the fp32 tile whose
+    // consumers split what they read
     const bool fp32_tile = switches().gru_bwd_fp32tile;
+    if (!fp32_only && !fp32_tile && !switches().gru_bwd_bf16)
+        return launch_gru_bwd_f16_64(dout, m, h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, V, s);
     if (!fp32_only && !fp32_tile)
         return launch_gru_bwd_presplit64(dout, m, h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, V, s);
     if (!fp32_only) {

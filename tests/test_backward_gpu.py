@@ -66,6 +66,84 @@ def test_gru_backward_random(dev, V, H):
         assert _rel(a.cpu(), b) < 2e-5, (name, _rel(a.cpu(), b))
 
 
+def _gru_bwd_ref64(m, h, mask, dout, W1, W2, b1, b2):
+    H = m.shape[1]
+    m64, h64 = m.double().requires_grad_(True), h.double().requires_grad_(True)
+    W1d, W2d, b1d, b2d = (x.double().requires_grad_(True) for x in (W1, W2, b1, b2))
+    gi, gh = m64 @ W1d + b1d, h64 @ W2d + b2d
+    mk = mask.double().reshape(-1, 1)
+    r = torch.sigmoid(gi[:, :H] + gh[:, :H]) * mk
+    z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H]) * mk
+    n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:]) * mk
+    (((1 - z) * n + z * h64) * mk).backward(dout.double())
+    return m64.grad, h64.grad, W1d.grad, W2d.grad, b1d.grad, b2d.grad
+
+
+@pytest.mark.parametrize("profile", ["unit", "x1e-6", "x1e-20", "x1e+8", "rising", "falling", "one_hot_tile", "small_x_tiles"])
+def test_gru_backward_h64_range_guards(dev, profile):
+    """The width-64 GRU backward runs on two fp16 pieces per operand behind power-of-two range guards (per 32-atom tile
+    for the gate gradients, per block and running for m | h, csrc/gru_bwd_f16.hip).  Gradient magnitudes that sit far
+    from 1, that climb or fall by 1e8 across the batch (the running scale of the dW accumulators changes on the way),
+    or that differ by 1e6 between neighbouring tiles (and m | h rows that differ by 1e3) must keep the float32 bar, per tensor AND per row of dm / dh."""
+    from mpnn_amd import ops
+    V, H = 70_001, 64                                        # 2188 tiles over 256 blocks: ~9 tiles per block, ragged tail
+    g = torch.Generator(device=dev).manual_seed(11)
+    m, h, dout = (torch.randn(V, H, device=dev, generator=g) for _ in range(3))
+    mask = (torch.rand(V, device=dev, generator=g) > 0.1).float()
+    W1, W2 = (torch.randn(H, 3 * H, device=dev, generator=g) / 8 for _ in range(2))
+    b1, b2 = (torch.randn(3 * H, device=dev, generator=g) / 8 for _ in range(2))
+    ramp = torch.logspace(-8, 0, V, device=dev).reshape(-1, 1)
+    if profile == "x1e-6":
+        dout = dout * 1e-6
+    elif profile == "x1e-20":
+        dout = dout * 1e-20
+    elif profile == "x1e+8":
+        dout = dout * 1e8
+    elif profile == "rising":
+        dout = dout * ramp
+    elif profile == "falling":
+        dout = dout * ramp.flip(0)
+    elif profile == "one_hot_tile":                           # every 7th tile carries gradients 1e6 larger
+        tile = torch.arange(V, device=dev) // 32
+        dout = dout * torch.where(tile % 7 == 0, 1e6, 1.0).reshape(-1, 1)
+    elif profile == "small_x_tiles":                          # m | h of two tiles in three are 1e-3 of the others'
+        tile = torch.arange(V, device=dev) // 32
+        f = torch.where(tile % 3 == 0, 1.0, 1e-3).reshape(-1, 1)
+        m, h = (m * f).contiguous(), (h * f).contiguous()
+    dout = dout.contiguous()
+    _, saved = ops.gru_update_raw(m, h, mask, W1, W2, b1, b2, True)
+    got = ops.gru_update_bwd_raw(dout, m, h, mask, W1, W2, saved)
+    want = _gru_bwd_ref64(m, h, mask, dout, W1, W2, b1, b2)
+    for a, b, name in zip(got, want, ("dm", "dh", "dW_ih", "dW_hh", "db_ih", "db_hh")):
+        err = float((a.double() - b).abs().max() / b.abs().max())
+        assert err < 1e-5, (profile, name, err)
+    for k, name in ((0, "dm"), (1, "dh")):
+        e = (got[k].double() - want[k]).abs().amax(1)
+        s = want[k].abs().amax(1)
+        live = s > 0
+        worst = float((e[live] / s[live]).max())
+        assert worst < (1e-4 if profile == "one_hot_tile" else 2e-5), (profile, name, worst)
+        assert float(got[k][~live].abs().max()) == 0.0       # masked atoms: exact zeros
+
+
+def test_gru_backward_h64_bf16_alternate_holds_the_parity_bar():
+    """MPNN_GRU_BWD_BF16=1 (three bf16 pieces, six MFMAs per product: round 1's kernel, kept as the A/B alternate of the
+    fp16 default) against float64 at the c2 size.  Switches are read once per process, so it runs in a child
+    (tools/bench_gru_bwd.py prints the errors)."""
+    import os
+    import re
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = dict(os.environ, MPNN_GRU_BWD_BF16="1")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "bench_gru_bwd.py")], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    errs = [float(x) for line in r.stdout.splitlines() if "max err / max |ref|" in line
+            for x in re.findall(r"(?:dm|dh|dW_ih|dW_hh|db_ih|db_hh) ([0-9.]+e[+-][0-9]+)", line)]
+    assert len(errs) == 24 and max(errs) < 1e-5, r.stdout
+
+
 @pytest.mark.parametrize("nf,mf,K,V", [(8, 8, 4, 60), (22, 22, 5, 333), (64, 64, 4, 3000), (128, 128, 4, 700),
                                        (256, 256, 3, 300), (64, 32, 2, 500), (64, 64, 100, 900),
                                        (64, 64, 5000, 2500), (24, 40, 4500, 2400), (130, 70, 4200, 2300)])

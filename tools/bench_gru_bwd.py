@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Time the GRU forward/backward kernels alone on c2-sized arrays (env knobs select variants)."""
+"""GRU forward/backward kernels alone at hidden 64, c2 size: timing and float64 error of the running math mode.
+    python tools/bench_gru_bwd.py                        (default: three bf16 pieces, six MFMAs per product)
+    MPNN_GRU_BWD_FP16=1 python tools/bench_gru_bwd.py    (two fp16 pieces, three MFMAs per product)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mpnn_amd import ops
@@ -23,3 +25,41 @@ print("env", {k: v for k, v in os.environ.items() if k.startswith("MPNN_")})
 print("fwd (save)   %.3f ms" % t(lambda: ops.gru_update_raw(m, h, mask, W1, W2, b1, b2, True)))
 print("fwd (nosave) %.3f ms" % t(lambda: ops.gru_update_raw(m, h, mask, W1, W2, b1, b2, False)))
 print("bwd          %.3f ms" % t(lambda: ops.gru_update_bwd_raw(dout, m, h, mask, W1, W2, saved)))
+
+
+def ref64(m, h, mask, dout):
+    m64, h64 = m.double().requires_grad_(True), h.double().requires_grad_(True)
+    W1d, W2d, b1d, b2d = (x.double().requires_grad_(True) for x in (W1, W2, b1, b2))
+    gi, gh = m64 @ W1d + b1d, h64 @ W2d + b2d
+    mk = mask.double().reshape(-1, 1)
+    r = torch.sigmoid(gi[:, :H] + gh[:, :H]) * mk
+    z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H]) * mk
+    n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:]) * mk
+    o = ((1 - z) * n + z * h64) * mk
+    o.backward(dout.double())
+    return m64.grad, h64.grad, W1d.grad, W2d.grad, b1d.grad, b2d.grad
+
+
+def rel(a, b):
+    return float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-300))
+
+
+# float64 error over the first n atoms, three gradient profiles: unit scale; tiny gradients; magnitudes that climb / fall
+# by 1e8 across the rows (the per-tile range guards of the fp16 variant change along the way)
+n = 300_001
+mk = (torch.rand(n, device=dev, generator=g) > 0.1).float()
+ramp = torch.logspace(-8, 0, n, device=dev).reshape(-1, 1)
+for name, d in (("unit", dout[:n]), ("x1e-6", dout[:n] * 1e-6), ("rising 1e-8..1", dout[:n] * ramp),
+                ("falling 1..1e-8", dout[:n] * ramp.flip(0))):
+    d = d.contiguous()
+    o, sv = ops.gru_update_raw(m[:n].contiguous(), h[:n].contiguous(), mk, W1, W2, b1, b2, True)
+    got = ops.gru_update_bwd_raw(d, m[:n].contiguous(), h[:n].contiguous(), mk, W1, W2, sv)
+    want = ref64(m[:n], h[:n], mk, d)
+    print("%-16s max err / max |ref|: dm %.2e dh %.2e dW_ih %.2e dW_hh %.2e db_ih %.2e db_hh %.2e" %
+          ((name,) + tuple(rel(a, b) for a, b in zip(got, want))))
+    # per-row accuracy of dm, dh: the worst row's error relative to that row's largest entry
+    for k, nm in ((0, "dm"), (1, "dh")):
+        e = (got[k].double() - want[k]).abs().amax(1)
+        s = want[k].abs().amax(1)
+        live = s > 0
+        print("    %s worst row: %.2e" % (nm, float((e[live] / s[live]).max())))
