@@ -230,8 +230,10 @@ int mpnn_gru_update_f32(const float* m, const float* h, const float* mask,
  * dW_ih, dW_hh [H,3H], db_ih, db_hh [3H] (caller zeroes them).  `workspace`: mpnn_gru_bwd_workspace_bytes(V, H)
  * bytes.  At H = 64 the backward is one kernel that keeps the gate gradients in LDS and needs NO workspace (the
  * function returns a token 16 bytes); at H = 128 / 256 it holds the compact gate gradients
- * [V,4H] = (d a_r | d a_z | d a_n | r * d a_n) that the dm/dh and dW kernels read; at other widths (and with
- * MPNN_GRU_MATH=fp32) the pre-activation gradients [V,6H] = (dgi | dgh).
+ * (d a_r | d a_z | d a_n | r * d a_n), 4H values per atom, that the dm/dh and dW kernels read -- at H = 128 as two
+ * fp16 pieces per value behind one power-of-two scale per 32-atom tile (the same 16 H bytes per atom, V rounded up to
+ * 32, plus the scales), at H = 256 as floats; at other widths (and with MPNN_GRU_MATH=fp32) the pre-activation
+ * gradients [V,6H] = (dgi | dgh).
  */
 size_t mpnn_gru_bwd_workspace_bytes(int64_t V, int H);
 int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const float* h, const float* mask,

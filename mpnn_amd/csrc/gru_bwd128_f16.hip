@@ -1,0 +1,588 @@
+// GRU backward at H = 128 on two fp16 pieces per operand ("fp16x3": three MFMAs per fp32 product), gate gradients
+// split ONCE.  Reference: mpnn_functions/update/gru_update.py:26-35 (autograd of it).
+//
+// At this width neither matrix's split images fit next to a tile (gru_bwd128.hip), so the work stays three kernels --
+// gate gradients, dm | dh, dW -- but what travels between them is no longer fp32: the gate-gradient kernel writes each
+// 32-atom tile's (dar daz dan dnh) as fp16 PIECES x*sg = hi + lo behind one power-of-two scale sg per tile (largest
+// magnitude of the tile in [2^14, 2^15)), as 1 KB blocks of 16 columns:
+//     pieces[tile][kstep 0..31][piece hi|lo][row 0..31][16 halves] = columns 16*kstep ... of the tile's rows
+// (kstep >> 3 = segment dar, daz, dan, dnh; an MFMA A fragment = 16 bytes at row*32 + 16*(lane >> 5)).  Same bytes as the fp32 workspace (4H floats per atom), and
+//   * the dm | dh kernel loads its A operand with one fully coalesced 1 KB request per (kstep, piece) and feeds it to
+//     the matrix pipe untouched (no splitting, 3 MFMAs per product instead of 6); weights: two fp16 images of the
+//     block's 32-column slice in LDS (96 KB) behind one scale per block;
+//   * the dW kernel parks the same fragments row-major in LDS ([32 atoms][128 columns] images per segment, the swizzle
+//     of gru_bwd_f16.hip) and reads COLUMNS with ds_read_b64_tr_b16; m | h are split by the kernel itself behind
+//     sx = C / sg, C = running minimum of sg * (best scale of the tile's m | h), so that every tile's products carry
+//     the same factor C and the register accumulators never need a per-tile fold (gru_bwd_f16.hip has the argument);
+//   * the bias gradients (column sums of the gate gradients) are taken by the gate-gradient kernel, in fp32.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+#include "common.h"
+
+namespace mpnn {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+constexpr int GH = 128;
+constexpr int G_IMG = 32 * 256;                        // bytes of one [32 rows][128 x fp16] image
+constexpr int G_TILE_BYTES = 32 * 4 * GH * 4;          // one tile of the piece workspace: 64 KB
+
+__device__ __forceinline__ int g_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+template <int SMAX>
+__device__ __forceinline__ void g_guard_scale(float maxabs, float& s, float& inv) {
+    int e = (__float_as_int(maxabs) >> 23) & 0xff;
+    e = e < 141 - SMAX ? 141 - SMAX : (e > 187 ? 187 : e);
+    s = __int_as_float((268 - e) << 23);
+    inv = __int_as_float((e - 14) << 23);
+}
+
+__device__ __forceinline__ float g_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+__device__ __forceinline__ void g_split8(const f32x4& x0, const f32x4& x1, float sc, h16x8& ph, h16x8& pl) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = x0[j] * sc, b = x1[j] * sc;
+        ph[j] = (_Float16)a;
+        pl[j] = (_Float16)(a - (float)ph[j]);
+        ph[4 + j] = (_Float16)b;
+        pl[4 + j] = (_Float16)(b - (float)ph[4 + j]);
+    }
+}
+
+// Block barrier that orders LDS traffic only.  __syncthreads() carries a workgroup fence over ALL address spaces, which
+// makes the compiler drain every outstanding global_load_lds copy (vmcnt(0)) -- the copies issued two tiles ahead are
+// waited for explicitly (s_waitcnt vmcnt(6)) where their buffer is needed.
+__device__ __forceinline__ void g_barrier_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// One wave copies 1 KB of global memory (lane L's 16 bytes at `src`) to LDS bytes [lds_dst + 16 L, +16) without touching
+// registers.  Issued as inline assembly on purpose: behind the builtin the compiler drains EVERY outstanding copy
+// (s_waitcnt vmcnt(0)) in front of the next LDS read that might alias it, which would undo the two-tile prefetch; the
+// waits that matter are written out where the buffers change hands.
+__device__ __forceinline__ void g_copy_to_lds(const char* src, const char* lds_dst) {
+    typedef __attribute__((address_space(3))) const char lds_char;
+    const unsigned dst = (unsigned)(uintptr_t)(lds_char*)lds_dst;
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
+}
+
+__device__ __forceinline__ h16x8 g_tr8(const char* a0, const char* a1) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a1);
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(h16x8, v);
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ gate gradients
+// Block = one 32-atom tile per iteration; thread = (row tid >> 4, eight columns 8 * (tid & 15) of every segment).
+template <bool HAS_MASK>
+__global__ void __launch_bounds__(512) gru_gate_f16_128_kernel(const float* __restrict__ dout, const float* __restrict__ h,
+                                                               const float* __restrict__ mask,
+                                                               const float* __restrict__ saved, char* __restrict__ pieces,
+                                                               float* __restrict__ inv_scale, float* __restrict__ dh,
+                                                               float* db_ih, float* db_hh, int64_t V) {
+    constexpr int H = GH;
+    __shared__ float red[2][8];
+    __shared__ float bsum[8][16][33];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int srow = tid >> 4, c16 = tid & 15, c8 = c16 * 8;
+    const int64_t tiles = (V + 31) / 32;
+    float cs[32];                                          // column sums: [segment][column]
+#pragma unroll
+    for (int k = 0; k < 32; ++k) cs[k] = 0.f;
+    int par = 0;
+    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x, par ^= 1) {
+        int64_t row = t * 32 + srow;
+        const bool ok = row < V;
+        if (!ok) row = V - 1;
+        const float mk = ok ? (HAS_MASK ? mask[row] : 1.0f) : 0.0f;
+        f32x4 seg[4][2], gz[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int64_t at = row * H + c8 + 4 * q;
+            const f32x4 v_do = *reinterpret_cast<const f32x4*>(dout + at);
+            const f32x4 vh = *reinterpret_cast<const f32x4*>(h + at);
+            const float* sv = saved + row * 4 * H + c8 + 4 * q;
+            const f32x4 r = *reinterpret_cast<const f32x4*>(sv);
+            const f32x4 z = *reinterpret_cast<const f32x4*>(sv + H);
+            const f32x4 n = *reinterpret_cast<const f32x4*>(sv + 2 * H);
+            const f32x4 nh = *reinterpret_cast<const f32x4*>(sv + 3 * H);
+            const f32x4 g = v_do * mk;                     // through the final "* mask"
+            const f32x4 dn = g * (1.0f - z);
+            const f32x4 dz = g * (vh - n);
+            const f32x4 dan = dn * mk * (1.0f - n * n);    // n = tanh(.)*mask
+            seg[0][q] = dan * nh * mk * r * (1.0f - r);
+            seg[1][q] = dz * mk * z * (1.0f - z);
+            seg[2][q] = dan;
+            seg[3][q] = dan * r;
+            gz[q] = g * z;
+        }
+        float mx = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    cs[8 * s + 4 * q + j] += seg[s][q][j];
+                    mx = fmaxf(mx, fabsf(seg[s][q][j]));
+                }
+        mx = g_wave_max(mx);
+        if (lane == 0) red[par][wv] = mx;
+        __syncthreads();
+        float gm = red[par][0];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) gm = fmaxf(gm, red[par][u]);
+        float sg, inv_sg;
+        g_guard_scale<90>(gm, sg, inv_sg);
+        if (tid == 0) inv_scale[t] = inv_sg;
+        // kstep = 8 * segment + (c16 >> 1); inside its 1 KB block: row srow, 16-byte half c16 & 1
+        char* base = pieces + t * (int64_t)G_TILE_BYTES + ((c16 >> 1) * 2) * 1024 + srow * 32 + (c16 & 1) * 16;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            h16x8 ph, pl;
+            g_split8(seg[s][0], seg[s][1], sg, ph, pl);
+            *reinterpret_cast<h16x8*>(base + s * 16 * 1024) = ph;
+            *reinterpret_cast<h16x8*>(base + s * 16 * 1024 + 1024) = pl;
+        }
+        if (ok) {
+            *reinterpret_cast<f32x4*>(dh + row * H + c8) = gz[0];
+            *reinterpret_cast<f32x4*>(dh + row * H + c8 + 4) = gz[1];
+        }
+    }
+    // bias gradients: rows of one column group sit 16 lanes apart in a wave; then across the eight waves through LDS
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        float v = cs[k];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        cs[k] = v;
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) bsum[wv][lane][k] = cs[k];
+    }
+    __syncthreads();
+    {
+        const int cg = tid >> 5, k = tid & 31;             // column group, (segment, column) of it
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += bsum[w][cg][k];
+        const int s = k >> 3, col = cg * 8 + (k & 7);
+        if (s < 2) {
+            atomicAdd(db_ih + s * H + col, v);
+            atomicAdd(db_hh + s * H + col, v);
+        } else if (s == 2) {
+            atomicAdd(db_ih + 2 * H + col, v);
+        } else {
+            atomicAdd(db_hh + 2 * H + col, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------ dm | dh
+// Column-sliced like gru_bwd_dx128_kernel: a block keeps the two fp16 images of 32 rows of W_ih and of W_hh in LDS
+// (image[mat][piece][n][k], 16-byte chunks XOR-swizzled by the row), four blocks per row tile on one XCD; a wave walks
+// 32-atom tiles and streams the tile's 32 x 2 pre-split A fragments through a register ring.
+__global__ void __launch_bounds__(512) gru_bwd_dx128_f16_kernel(const char* __restrict__ pieces,
+                                                                const float* __restrict__ inv_scale,
+                                                                const float* __restrict__ W_ih,
+                                                                const float* __restrict__ W_hh, float* __restrict__ dm,
+                                                                float* __restrict__ dh, int64_t V) {
+    constexpr int H = GH, KC = 3 * H;
+    constexpr int ROWB = 2 * KC;               // one image row = one weight row (3H gate columns) in fp16
+    constexpr int IMG = 32 * ROWB;             // one (matrix, piece) image: 32 output columns
+    constexpr int NW = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 matrices][2 pieces][32][384] fp16
+    __shared__ float redw[NW];
+
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int slice = jb & 3;
+    const int pblock = (jb >> 2) * 8 + xcd, pblocks = gridDim.x >> 2;
+    const int c0 = slice * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    float mx = 0.f;
+    for (int idx = tid; idx < 2 * 32 * (KC / 4); idx += 64 * NW) {
+        const int mat = idx / (32 * (KC / 4));
+        const int rem = idx % (32 * (KC / 4));
+        const int n = rem / (KC / 4), q = rem % (KC / 4);
+        const float* W = mat == 0 ? W_ih : W_hh;
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(W + (int64_t)(c0 + n) * KC + 4 * q);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fabsf(w4[u]));
+    }
+    mx = g_wave_max(mx);
+    if (lane == 0) redw[wv] = mx;
+    __syncthreads();
+    mx = redw[0];
+#pragma unroll
+    for (int u = 1; u < NW; ++u) mx = fmaxf(mx, redw[u]);
+    float sw, inv_sw;
+    g_guard_scale<30>(mx, sw, inv_sw);
+    for (int idx = tid; idx < 2 * 32 * (KC / 4); idx += 64 * NW) {
+        const int mat = idx / (32 * (KC / 4));
+        const int rem = idx % (32 * (KC / 4));
+        const int n = rem / (KC / 4), q = rem % (KC / 4);
+        const float* W = mat == 0 ? W_ih : W_hh;
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(W + (int64_t)(c0 + n) * KC + 4 * q);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = 4 * q + u;
+            const float a = w4[u] * sw;
+            const _Float16 ph = (_Float16)a;
+            const _Float16 pl = (_Float16)(a - (float)ph);
+            const int off = n * ROWB + (((k >> 3) ^ (n & 15)) << 4) + ((k & 7) << 1);
+            *reinterpret_cast<_Float16*>(smem + (mat * 2 + 0) * IMG + off) = ph;
+            *reinterpret_cast<_Float16*>(smem + (mat * 2 + 1) * IMG + off) = pl;
+        }
+    }
+    __syncthreads();
+
+    const int r = lane & 31, hi = lane >> 5;
+    const int64_t tiles = (V + 31) / 32;
+    const int64_t stride = (int64_t)pblocks * NW;
+    int64_t t = (int64_t)pblock * NW + wv;
+    if (t >= tiles) return;
+
+    auto bfrag = [&](int mat, int piece, int chunk) {
+        return *reinterpret_cast<const h16x8*>(smem + (mat * 2 + piece) * IMG + r * ROWB + ((chunk ^ (r & 15)) << 4));
+    };
+    // the tile's A fragments: (kstep, piece) at 1 KB steps, this lane's 16 bytes
+    constexpr int AHEAD = 8;                   // ring slots: ksteps are fetched six to seven ahead (12-14 KB per wave in flight)
+    h16x8 ring[AHEAD][2];
+    auto load_step = [&](int64_t tile, int ks, h16x8 (&f)[2]) {
+        const char* p = pieces + tile * (int64_t)G_TILE_BYTES + ks * 2048 + r * 32 + hi * 16;
+        f[0] = *reinterpret_cast<const h16x8*>(p);
+        f[1] = *reinterpret_cast<const h16x8*>(p + 1024);
+    };
+    // weight fragments of a PAIR of ksteps (2 pp, 2 pp + 1), fetched from LDS one pair ahead of the MFMAs that use them:
+    // segments dar, daz feed both products (4 fragments per kstep), dan only dm, dnh only dh (2 per kstep)
+    h16x8 Bf[2][8];
+    auto load_b = [&](int pp, h16x8 (&B)[8]) {
+        const int g = pp >> 2;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int ks = 2 * pp + e;
+            const int chunk = 16 * (g == 3 ? 2 : g) + 2 * (ks & 7) + hi;
+            if (g < 2) {
+                B[4 * e + 0] = bfrag(0, 0, chunk);
+                B[4 * e + 1] = bfrag(0, 1, chunk);
+                B[4 * e + 2] = bfrag(1, 0, chunk);
+                B[4 * e + 3] = bfrag(1, 1, chunk);
+            } else {
+                B[4 * e + 0] = bfrag(g - 2, 0, chunk);
+                B[4 * e + 1] = bfrag(g - 2, 1, chunk);
+            }
+        }
+    };
+#pragma unroll
+    for (int ks = 0; ks < AHEAD - 2; ++ks) load_step(t, ks, ring[ks]);
+    load_b(0, Bf[0]);
+    for (; t < tiles; t += stride) {
+        const int64_t tn = t + stride < tiles ? t + stride : t;
+        const float un = inv_scale[t] * inv_sw;
+        // even / odd ksteps of a pair go to different accumulators: no MFMA accumulates into its predecessor
+        f32x16 d_m, d_h, e_m, e_h;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { d_m[i] = 0.f; d_h[i] = 0.f; e_m[i] = 0.f; e_h[i] = 0.f; }
+#pragma unroll
+        for (int pp = 0; pp < 16; ++pp) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int kl = 2 * pp + e + AHEAD - 2;
+                if (kl < 32) load_step(t, kl, ring[kl % AHEAD]);
+                else load_step(tn, kl - 32, ring[kl % AHEAD]);
+            }
+            load_b((pp + 1) & 15, Bf[(pp + 1) & 1]);       // pair 0 of the next tile at pp = 15: same weights
+            __builtin_amdgcn_sched_barrier(0);
+            const int g = pp >> 2;
+            const h16x8(&B)[8] = Bf[pp & 1];
+            const h16x8 a0h = ring[(2 * pp) % AHEAD][0], a0l = ring[(2 * pp) % AHEAD][1];
+            const h16x8 a1h = ring[(2 * pp + 1) % AHEAD][0], a1l = ring[(2 * pp + 1) % AHEAD][1];
+            if (g < 2) {
+                d_m = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, B[0], d_m, 0, 0, 0);
+                d_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, B[2], d_h, 0, 0, 0);
+                e_m = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, B[4], e_m, 0, 0, 0);
+                e_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, B[6], e_h, 0, 0, 0);
+                d_m = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, B[1], d_m, 0, 0, 0);
+                d_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, B[3], d_h, 0, 0, 0);
+                e_m = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, B[5], e_m, 0, 0, 0);
+                e_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, B[7], e_h, 0, 0, 0);
+                d_m = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, B[0], d_m, 0, 0, 0);
+                d_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, B[2], d_h, 0, 0, 0);
+                e_m = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, B[4], e_m, 0, 0, 0);
+                e_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, B[6], e_h, 0, 0, 0);
+            } else {
+                f32x16& d = g == 2 ? d_m : d_h;
+                f32x16& ee = g == 2 ? e_m : e_h;
+                d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, B[0], d, 0, 0, 0);
+                ee = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, B[4], ee, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, B[1], d, 0, 0, 0);
+                ee = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, B[5], ee, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, B[0], d, 0, 0, 0);
+                ee = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, B[4], ee, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int col = c0 + r;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            float prev[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int64_t row = t * 32 + 8 * g4 + 4 * hi + u;
+                if (row >= V) row = V - 1;
+                prev[u] = dh[row * H + col];                      // dout*mask*z from the gate-gradient kernel
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = 4 * g4 + u;
+                const int64_t row = t * 32 + 8 * g4 + 4 * hi + u;
+                if (row < V) {
+                    dm[row * H + col] = (d_m[i] + e_m[i]) * un;
+                    dh[row * H + col] = (d_h[i] + e_h[i]) * un + prev[u];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------- dW
+// blockIdx.y = matrix: dW_ih = m^T [dar daz dan], dW_hh = h^T [dar daz dnh] (128 x 384 each = 4 x 12 tiles of 32 x 32,
+// wave = (a-pair, b-triple) as in gru_bwd_dw128_kernel).  Double-buffered 32-atom tile in LDS: three gate images + the
+// X image, two pieces each, every image as the workspace has it ([8 ksteps][32 rows][16 columns], 64 KB per buffer).
+// The gate pieces need no processing, so they go from global memory straight into LDS (global_load_lds_dwordx4: a wave
+// copies 1 KB blocks verbatim, tools/microbench/lds_direct_load.hip) TWO tiles ahead, into the buffer the block has just
+// finished reading; m | h rows travel through registers (they are split here) and are also fetched two tiles ahead.
+// Columns are read with ds_read_b64_tr_b16: a 16-lane group covers 4 rows x 16 columns = 128 contiguous bytes.
+__global__ void __launch_bounds__(512) gru_bwd_dw128_f16_kernel(const float* __restrict__ m, const float* __restrict__ h,
+                                                                const char* __restrict__ pieces,
+                                                                const float* __restrict__ inv_scale, float* dW_ih,
+                                                                float* dW_hh, int64_t V) {
+    constexpr int H = GH;
+    constexpr int BUF = 8 * G_IMG;             // image (piece, slot) at (4 * piece + slot) * G_IMG; slot 3 = X
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem + 2 * BUF);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31;
+    const int mat = blockIdx.y;
+    const float* X = mat == 0 ? m : h;
+    const int64_t tiles = (V + 31) / 32;
+    const int64_t t0 = blockIdx.x, tstep = gridDim.x;      // the launch keeps gridDim.x <= tiles
+
+    // wave wv copies blocks 6 wv .. 6 wv + 5 of the tile's 48 (slot, kstep, piece) blocks
+    auto issue_gates = [&](int64_t t, char* T) {
+        const char* p = pieces + t * (int64_t)G_TILE_BYTES + lane * 16;
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const int b = 6 * wv + it;
+            const int slot = b >> 4, ks8 = (b >> 1) & 7, piece = b & 1;
+            const int seg = slot == 2 ? 2 + mat : slot;
+            g_copy_to_lds(p + ((seg * 8 + ks8) * 2 + piece) * 1024, T + (4 * piece + slot) * G_IMG + ks8 * 1024);
+        }
+    };
+    const int srow = tid >> 4, c16 = tid & 15;
+    const int x_dst = 3 * G_IMG + (c16 >> 1) * 1024 + srow * 32 + (c16 & 1) * 16;
+    struct XRows { f32x4 x0, x1; float inv_sg, live; };     // consumed only in publish / park_x: nothing waits on the loads before
+    auto load_x = [&](int64_t t) {
+        XRows q;
+        int64_t row = t * 32 + srow;
+        const bool ok = row < V;
+        if (!ok) row = V - 1;
+        q.live = ok ? 1.0f : 0.0f;                         // rows past V count as zeros
+        q.x0 = *reinterpret_cast<const f32x4*>(X + row * H + c16 * 8);
+        q.x1 = *reinterpret_cast<const f32x4*>(X + row * H + c16 * 8 + 4);
+        q.inv_sg = inv_scale[t];
+        return q;
+    };
+    auto publish = [&](const XRows& q, int par) {
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mx = fmaxf(mx, fmaxf(fabsf(q.x0[j]), fabsf(q.x1[j])));
+        mx = g_wave_max(mx * q.live);
+        if (lane == 0) red[8 * par + wv] = mx;
+    };
+    float C_run = 3.0e38f;
+    auto park_x = [&](const XRows& q, char* T, int par) {  // after the barrier that follows publish()
+        float xm = red[8 * par];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) xm = fmaxf(xm, red[8 * par + u]);
+        float sxo, inv_sxo;
+        g_guard_scale<30>(xm, sxo, inv_sxo);
+        const float sg = __int_as_float((254 - ((__float_as_int(q.inv_sg) >> 23) & 0xff)) << 23);
+        C_run = fminf(C_run, sg * sxo);
+        const float sx = C_run * q.inv_sg;
+        h16x8 ph, pl;
+        g_split8(q.x0, q.x1, sx * q.live, ph, pl);
+        *reinterpret_cast<h16x8*>(T + x_dst) = ph;
+        *reinterpret_cast<h16x8*>(T + 4 * G_IMG + x_dst) = pl;
+    };
+
+    // transposed reads: a 16-lane group takes rows 8*(g2>>1) + 4j + (0..3), columns 16*(g2&1) + (0..15) of 32-column
+    // block cb = ksteps 2 cb, 2 cb + 1 of an image; lane 4q+p supplies row q, columns 4p..4p+3
+    const int ag = wv & 1, bg = wv >> 1;
+    const int g2 = lane >> 4, u16 = lane & 15, q4 = u16 >> 2, p4 = u16 & 3;
+    auto tr_addr = [&](int slot, int cb, int j) {
+        return slot * G_IMG + (2 * cb + (g2 & 1)) * 1024 + (8 * (g2 >> 1) + 4 * j + q4) * 32 + p4 * 8;
+    };
+    int LA[3][2], LX[2][2];
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) LA[b][j] = tr_addr((3 * bg + b) >> 2, (3 * bg + b) & 3, j);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) LX[a][j] = tr_addr(3, 2 * ag + a, j);
+
+    f32x16 R[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) R[j][q] = 0.f;
+
+    XRows xp, xq;                                          // alternate: one is used while the other is reloaded (no copies)
+    {
+        issue_gates(t0, smem);
+        const XRows xa = load_x(t0);
+        const bool two = t0 + tstep < tiles;
+        if (two) issue_gates(t0 + tstep, smem + BUF);
+        xp = load_x(two ? t0 + tstep : t0);
+        publish(xa, 0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's blocks of both tiles have landed
+        __syncthreads();
+        park_x(xa, smem, 0);
+    }
+    float C_acc = C_run, C_cur = C_run;
+    int cur = 0;
+    // one tile: `use` holds the m | h rows of tile t + 1 (requested one iteration ago), `reload` receives tile t + 2's
+    auto body = [&](int64_t t, const XRows& use, XRows& reload) {
+        g_barrier_lds();                                   // buffer `cur` is complete
+        const char* T = smem + cur * BUF;
+        const int64_t t2 = t + 2 * tstep;
+        const bool has2 = t2 < tiles;
+        reload = load_x(has2 ? t2 : t);                    // unconditional, clamped
+        if (__builtin_amdgcn_readfirstlane(__float_as_int(C_cur)) != __builtin_amdgcn_readfirstlane(__float_as_int(C_acc))) {
+            const float ratio = C_cur / C_acc;             // < 1, a power of two
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) R[j][q] *= ratio;
+            C_acc = C_cur;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const char* Tb = T + 512 * st;                 // rows +16
+            const h16x8 a0h = g_tr8(Tb + LX[0][0], Tb + LX[0][1]);
+            const h16x8 a0l = g_tr8(Tb + 4 * G_IMG + LX[0][0], Tb + 4 * G_IMG + LX[0][1]);
+            const h16x8 a1h = g_tr8(Tb + LX[1][0], Tb + LX[1][1]);
+            const h16x8 a1l = g_tr8(Tb + 4 * G_IMG + LX[1][0], Tb + 4 * G_IMG + LX[1][1]);
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const h16x8 bh = g_tr8(Tb + LA[b][0], Tb + LA[b][1]);
+                const h16x8 bl = g_tr8(Tb + 4 * G_IMG + LA[b][0], Tb + 4 * G_IMG + LA[b][1]);
+                R[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, bh, R[b], 0, 0, 0);
+                R[3 + b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, bh, R[3 + b], 0, 0, 0);
+                R[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bl, R[b], 0, 0, 0);
+                R[3 + b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bl, R[3 + b], 0, 0, 0);
+                R[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bh, R[b], 0, 0, 0);
+                R[3 + b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bh, R[3 + b], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        publish(use, cur ^ 1);
+        g_barrier_lds();                                   // every wave is done reading buffer `cur`
+        park_x(use, smem + (cur ^ 1) * BUF, cur ^ 1);
+        C_cur = C_run;
+        __builtin_amdgcn_sched_barrier(0);
+        // Everything in flight is due now: tile t + 1's gate copies (issued one iteration ago) and tile t + 2's m | h rows
+        // (requested at the top).  Draining HERE, before the next copies go out, also keeps the compiler from parking its
+        // own vmcnt(0) for the rows behind them (it does not see the copies).
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        asm volatile("" ::"v"(reload.x0), "v"(reload.x1), "v"(reload.inv_sg));
+        if (has2) issue_gates(t2, smem + cur * BUF);       // into the buffer just read; lands during the next iteration
+        cur ^= 1;
+    };
+    for (int64_t t = t0; t < tiles; t += 2 * tstep) {
+        body(t, xp, xq);
+        if (t + tstep < tiles) body(t + tstep, xq, xp);
+    }
+    const float inv_C = 1.0f / C_acc;
+    float* dW = mat == 0 ? dW_ih : dW_hh;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int col = 32 * (3 * bg + b) + i;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = 32 * (2 * ag + a) + acc_row(q, lane);
+                atomicAdd(dW + (int64_t)row * 3 * H + col, R[3 * a + b][q] * inv_C);
+            }
+        }
+}
+
+size_t gru_bwd128_f16_workspace_bytes(int64_t V) {
+    const int64_t tiles = (V + 31) / 32;
+    return (size_t)tiles * G_TILE_BYTES + (size_t)((tiles + 63) / 64 * 64) * sizeof(float);
+}
+
+int launch_gru_bwd128_f16(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
+                          const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
+                          float* db_ih, float* db_hh, void* workspace, int64_t V, hipStream_t s) {
+    const int64_t tiles = (V + 31) / 32;
+    char* pieces = (char*)workspace;
+    float* inv_scale = (float*)(pieces + (size_t)tiles * G_TILE_BYTES);
+    const size_t lds_dx = (size_t)2 * 2 * 32 * (2 * 3 * GH);
+    const size_t lds_dw = (size_t)2 * 8 * G_IMG + 64;
+    static const hipError_t attr_done = [&] {   // once per process, thread-safe (C++11 static initialisation)
+        LdsOptIn opt_in_;
+        opt_in_((const void*)gru_bwd_dx128_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dx);
+        opt_in_((const void*)gru_bwd_dw128_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dw);
+        return opt_in_.err;
+    }();
+    if (attr_done != hipSuccess) return lds_opt_in_failed(attr_done);
+
+    int64_t gg = 1024;
+    if (gg > tiles) gg = tiles;
+    if (mask)
+        hipLaunchKernelGGL(gru_gate_f16_128_kernel<true>, dim3((unsigned)gg), dim3(512), 0, s, dout, h, mask, saved, pieces,
+                           inv_scale, dh, db_ih, db_hh, V);
+    else
+        hipLaunchKernelGGL(gru_gate_f16_128_kernel<false>, dim3((unsigned)gg), dim3(512), 0, s, dout, h, mask, saved, pieces,
+                           inv_scale, dh, db_ih, db_hh, V);
+    int rc = launch_status("mpnn_gru_update_bwd_f32(gates, fp16 pieces)");
+    if (rc) return rc;
+
+    int64_t pblocks = 64;                                   // x 4 slices = one block per CU
+    if (pblocks * 8 > tiles) pblocks = (tiles + 7) / 8;
+    pblocks = (pblocks + 7) / 8 * 8;
+    hipLaunchKernelGGL(gru_bwd_dx128_f16_kernel, dim3((unsigned)(pblocks * 4)), dim3(512), lds_dx, s, pieces, inv_scale, W_ih,
+                       W_hh, dm, dh, V);
+    rc = launch_status("mpnn_gru_update_bwd_f32(dx, H=128, fp16 pieces)");
+    if (rc) return rc;
+
+    int64_t gx = 128;                                       // x 2 matrices = one block per CU (128 KB of LDS)
+    if (gx > tiles) gx = tiles;
+    hipLaunchKernelGGL(gru_bwd_dw128_f16_kernel, dim3((unsigned)gx, 2), dim3(512), lds_dw, s, m, h, pieces, inv_scale, dW_ih,
+                       dW_hh, V);
+    return launch_status("mpnn_gru_update_bwd_f32(dW, H=128, fp16 pieces)");
+}
+
+}  // namespace mpnn

@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""GRU forward/backward kernels alone at hidden 64, c2 size: timing and float64 error of the running math mode.
-    python tools/bench_gru_bwd.py                        (default: three bf16 pieces, six MFMAs per product)
-    MPNN_GRU_BWD_FP16=1 python tools/bench_gru_bwd.py    (two fp16 pieces, three MFMAs per product)"""
+"""GRU forward/backward kernels alone at hidden 64 (c2 size) or 128 (c4 size): timing and float64 error.
+    python tools/bench_gru_bwd.py [128]                      (default: backward on two fp16 pieces, three MFMAs per product)
+    MPNN_GRU_BWD_BF16=1 python tools/bench_gru_bwd.py [128]  (three bf16 pieces, six MFMAs per product)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mpnn_amd import ops
 dev = torch.device("cuda:0")
-V, H = 2_997_659, 64
+H = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+V = {64: 2_997_659, 128: 3_749_258}[H]
 g = torch.Generator(device=dev).manual_seed(0)
 m, h, dout = (torch.randn(V, H, device=dev, generator=g) for _ in range(3))
 mask = torch.ones(V, device=dev)
@@ -25,6 +26,8 @@ print("env", {k: v for k, v in os.environ.items() if k.startswith("MPNN_")})
 print("fwd (save)   %.3f ms" % t(lambda: ops.gru_update_raw(m, h, mask, W1, W2, b1, b2, True)))
 print("fwd (nosave) %.3f ms" % t(lambda: ops.gru_update_raw(m, h, mask, W1, W2, b1, b2, False)))
 print("bwd          %.3f ms" % t(lambda: ops.gru_update_bwd_raw(dout, m, h, mask, W1, W2, saved)))
+if len(sys.argv) > 2 and sys.argv[2] == "time":          # timing only (under rocprofv3)
+    sys.exit(0)
 
 
 def ref64(m, h, mask, dout):
