@@ -659,20 +659,19 @@ extern "C" int mpnn_edge_message_bwd_f32(const float* h, const float* A, const i
 }
 
 namespace mpnn {
-size_t gru_bwd128_f16_workspace_bytes(int64_t V);                          // gru_bwd128_f16.hip
-int launch_gru_bwd128_f16(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
-                          const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
-                          float* db_ih, float* db_hh, void* workspace, int64_t V, hipStream_t s);
+size_t gru_bwd_f16_workspace_bytes(int64_t V, int H);                      // gru_bwd128_f16.hip (H = 128, 256)
+int launch_gru_bwd_f16_wide(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
+                            const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
+                            float* db_ih, float* db_hh, void* workspace, int64_t V, int H, hipStream_t s);
 }  // namespace mpnn
 
 extern "C" size_t mpnn_gru_bwd_workspace_bytes(int64_t V, int H) {
     if (V < 0 || H <= 0) return 0;
     if (H == 64) return 16;                                               // one kernel, gate gradients stay in LDS
-    if (H == 128 && !switches().math_fp32) {                              // fp16 pieces per 32-atom tile + tile scales
-        const size_t a = (size_t)V * 4 * H * sizeof(float), b = gru_bwd128_f16_workspace_bytes(V);
-        return a > b ? a : b;
+    if ((H == 128 || H == 256) && !switches().math_fp32) {                // fp16 pieces per 32-atom tile + tile scales
+        const size_t a = (size_t)V * 4 * H * sizeof(float), b = gru_bwd_f16_workspace_bytes(V, H);
+        return a > b ? a : b;                                              // (a: the compact float layout of MPNN_GRU_BWD_BF16)
     }
-    if (H == 256 && !switches().math_fp32) return (size_t)V * 4 * H * sizeof(float);   // compact layout
     return (size_t)V * 6 * H * sizeof(float);                            // generic widths: (dgi | dgh)
 }
 
@@ -698,10 +697,11 @@ extern "C" int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const 
     if (g > 256 * 16) g = 256 * 16;
     const bool fp32_only = switches().math_fp32;
     int rc;
-    // hidden 128: gate gradients as fp16 pieces, split once (gru_bwd128_f16.hip); MPNN_GRU_BWD_BF16=1 keeps the three
+    // hidden 128 / 256: gate gradients as fp16 pieces, split once (gru_bwd128_f16.hip); MPNN_GRU_BWD_BF16=1 keeps the three
     // bf16x6 kernels below
-    if (H == 128 && !fp32_only && !switches().gru_bwd_bf16)
-        return launch_gru_bwd128_f16(dout, m, h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, workspace, V, s);
+    if ((H == 128 || H == 256) && !fp32_only && !switches().gru_bwd_bf16)
+        return launch_gru_bwd_f16_wide(dout, m, h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, workspace, V, H,
+                                       s);
     if ((H == 128 || H == 256) && !fp32_only) {
         hipLaunchKernelGGL(gru_gate_grad_kernel<true>, dim3((unsigned)g), dim3(256), 0, s, dout, h, mask, saved, ws, dh, V,
                            H);

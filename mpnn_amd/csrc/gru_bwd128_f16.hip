@@ -85,59 +85,65 @@ __device__ __forceinline__ h16x8 g_tr8(const char* a0, const char* a1) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ gate gradients
-// Block = one 32-atom tile per iteration; thread = (row tid >> 4, eight columns 8 * (tid & 15) of every segment).
-template <bool HAS_MASK>
-__global__ void __launch_bounds__(512) gru_gate_f16_128_kernel(const float* __restrict__ dout, const float* __restrict__ h,
-                                                               const float* __restrict__ mask,
-                                                               const float* __restrict__ saved, char* __restrict__ pieces,
-                                                               float* __restrict__ inv_scale, float* __restrict__ dh,
-                                                               float* db_ih, float* db_hh, int64_t V) {
-    constexpr int H = GH;
+// Block = one 32-atom tile per iteration; thread = (row tid >> 4, column groups c16 + 16 j (8 columns each) of every
+// segment, j < H / 128).  The tile's values stay in registers between the maximum and the split.
+template <int H, bool HAS_MASK>
+__global__ void __launch_bounds__(512) gru_gate_f16_kernel(const float* __restrict__ dout, const float* __restrict__ h,
+                                                           const float* __restrict__ mask, const float* __restrict__ saved,
+                                                           char* __restrict__ pieces, float* __restrict__ inv_scale,
+                                                           float* __restrict__ dh, float* db_ih, float* db_hh, int64_t V) {
+    constexpr int NG = H / 128;                            // column groups per thread
+    constexpr int TILE_BYTES = 32 * 4 * H * 4;
+    constexpr int SEG_BYTES = (H / 16) * 2048;             // ksteps of one segment
     __shared__ float red[2][8];
-    __shared__ float bsum[8][16][33];
+    __shared__ float bsum[8][16][32 * NG + 1];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int srow = tid >> 4, c16 = tid & 15, c8 = c16 * 8;
+    const int srow = tid >> 4, c16 = tid & 15;
     const int64_t tiles = (V + 31) / 32;
-    float cs[32];                                          // column sums: [segment][column]
+    float cs[32 * NG];                                     // column sums: [group][segment][column]
 #pragma unroll
-    for (int k = 0; k < 32; ++k) cs[k] = 0.f;
+    for (int k = 0; k < 32 * NG; ++k) cs[k] = 0.f;
     int par = 0;
     for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x, par ^= 1) {
         int64_t row = t * 32 + srow;
         const bool ok = row < V;
         if (!ok) row = V - 1;
         const float mk = ok ? (HAS_MASK ? mask[row] : 1.0f) : 0.0f;
-        f32x4 seg[4][2], gz[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int64_t at = row * H + c8 + 4 * q;
-            const f32x4 v_do = *reinterpret_cast<const f32x4*>(dout + at);
-            const f32x4 vh = *reinterpret_cast<const f32x4*>(h + at);
-            const float* sv = saved + row * 4 * H + c8 + 4 * q;
-            const f32x4 r = *reinterpret_cast<const f32x4*>(sv);
-            const f32x4 z = *reinterpret_cast<const f32x4*>(sv + H);
-            const f32x4 n = *reinterpret_cast<const f32x4*>(sv + 2 * H);
-            const f32x4 nh = *reinterpret_cast<const f32x4*>(sv + 3 * H);
-            const f32x4 g = v_do * mk;                     // through the final "* mask"
-            const f32x4 dn = g * (1.0f - z);
-            const f32x4 dz = g * (vh - n);
-            const f32x4 dan = dn * mk * (1.0f - n * n);    // n = tanh(.)*mask
-            seg[0][q] = dan * nh * mk * r * (1.0f - r);
-            seg[1][q] = dz * mk * z * (1.0f - z);
-            seg[2][q] = dan;
-            seg[3][q] = dan * r;
-            gz[q] = g * z;
-        }
+        f32x4 seg[NG][4][2], gz[NG][2];
         float mx = 0.f;
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int j = 0; j < NG; ++j) {
+            const int c8 = 8 * (c16 + 16 * j);
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
+            for (int q = 0; q < 2; ++q) {
+                const int64_t at = row * H + c8 + 4 * q;
+                const f32x4 v_do = *reinterpret_cast<const f32x4*>(dout + at);
+                const f32x4 vh = *reinterpret_cast<const f32x4*>(h + at);
+                const float* sv = saved + row * 4 * H + c8 + 4 * q;
+                const f32x4 r = *reinterpret_cast<const f32x4*>(sv);
+                const f32x4 z = *reinterpret_cast<const f32x4*>(sv + H);
+                const f32x4 n = *reinterpret_cast<const f32x4*>(sv + 2 * H);
+                const f32x4 nh = *reinterpret_cast<const f32x4*>(sv + 3 * H);
+                const f32x4 g = v_do * mk;                 // through the final "* mask"
+                const f32x4 dn = g * (1.0f - z);
+                const f32x4 dz = g * (vh - n);
+                const f32x4 dan = dn * mk * (1.0f - n * n);    // n = tanh(.)*mask
+                seg[j][0][q] = dan * nh * mk * r * (1.0f - r);
+                seg[j][1][q] = dz * mk * z * (1.0f - z);
+                seg[j][2][q] = dan;
+                seg[j][3][q] = dan * r;
+                gz[j][q] = g * z;
+            }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    cs[8 * s + 4 * q + j] += seg[s][q][j];
-                    mx = fmaxf(mx, fabsf(seg[s][q][j]));
-                }
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        cs[32 * j + 8 * s + 4 * q + u] += seg[j][s][q][u];
+                        mx = fmaxf(mx, fabsf(seg[j][s][q][u]));
+                    }
+        }
         mx = g_wave_max(mx);
         if (lane == 0) red[par][wv] = mx;
         __syncthreads();
@@ -147,23 +153,27 @@ __global__ void __launch_bounds__(512) gru_gate_f16_128_kernel(const float* __re
         float sg, inv_sg;
         g_guard_scale<90>(gm, sg, inv_sg);
         if (tid == 0) inv_scale[t] = inv_sg;
-        // kstep = 8 * segment + (c16 >> 1); inside its 1 KB block: row srow, 16-byte half c16 & 1
-        char* base = pieces + t * (int64_t)G_TILE_BYTES + ((c16 >> 1) * 2) * 1024 + srow * 32 + (c16 & 1) * 16;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            h16x8 ph, pl;
-            g_split8(seg[s][0], seg[s][1], sg, ph, pl);
-            *reinterpret_cast<h16x8*>(base + s * 16 * 1024) = ph;
-            *reinterpret_cast<h16x8*>(base + s * 16 * 1024 + 1024) = pl;
-        }
-        if (ok) {
-            *reinterpret_cast<f32x4*>(dh + row * H + c8) = gz[0];
-            *reinterpret_cast<f32x4*>(dh + row * H + c8 + 4) = gz[1];
+        for (int j = 0; j < NG; ++j) {
+            // kstep inside the segment = (c16 + 16 j) >> 1; inside its 1 KB block: row srow, 16-byte half c16 & 1
+            char* base = pieces + t * (int64_t)TILE_BYTES + ((c16 + 16 * j) >> 1) * 2048 + srow * 32 + (c16 & 1) * 16;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                h16x8 ph, pl;
+                g_split8(seg[j][s][0], seg[j][s][1], sg, ph, pl);
+                *reinterpret_cast<h16x8*>(base + s * SEG_BYTES) = ph;
+                *reinterpret_cast<h16x8*>(base + s * SEG_BYTES + 1024) = pl;
+            }
+            if (ok) {
+                const int c8 = 8 * (c16 + 16 * j);
+                *reinterpret_cast<f32x4*>(dh + row * H + c8) = gz[j][0];
+                *reinterpret_cast<f32x4*>(dh + row * H + c8 + 4) = gz[j][1];
+            }
         }
     }
     // bias gradients: rows of one column group sit 16 lanes apart in a wave; then across the eight waves through LDS
 #pragma unroll
-    for (int k = 0; k < 32; ++k) {
+    for (int k = 0; k < 32 * NG; ++k) {
         float v = cs[k];
         v += __shfl_xor(v, 16);
         v += __shfl_xor(v, 32);
@@ -171,15 +181,15 @@ __global__ void __launch_bounds__(512) gru_gate_f16_128_kernel(const float* __re
     }
     if (lane < 16) {
 #pragma unroll
-        for (int k = 0; k < 32; ++k) bsum[wv][lane][k] = cs[k];
+        for (int k = 0; k < 32 * NG; ++k) bsum[wv][lane][k] = cs[k];
     }
     __syncthreads();
-    {
-        const int cg = tid >> 5, k = tid & 31;             // column group, (segment, column) of it
+    for (int idx = tid; idx < 16 * 32 * NG; idx += 512) {
+        const int cg = idx / (32 * NG), k = idx % (32 * NG);   // lane group, (column group j, segment, column)
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) v += bsum[w][cg][k];
-        const int s = k >> 3, col = cg * 8 + (k & 7);
+        const int j = k >> 5, s = (k >> 3) & 3, col = 8 * (cg + 16 * j) + (k & 7);
         if (s < 2) {
             atomicAdd(db_ih + s * H + col, v);
             atomicAdd(db_hh + s * H + col, v);
@@ -360,60 +370,266 @@ __global__ void __launch_bounds__(512) gru_bwd_dx128_f16_kernel(const char* __re
     }
 }
 
+// ------------------------------------------------------------------------------------- dm | dh, weights streamed
+// gru_bwd_dx_stream_kernel (gru_bwd128.hip) on fp16 pieces: a block owns 64 output features of dm and of dh (H / 64
+// slice blocks per row group instead of H / 32), a round = 256 rows (every wave its own 32-row tile, 32 x 64 of dm and
+// of dh in registers), the contraction runs over 64-wide chunks of one gate block; all threads split the NEXT chunk of
+// the block's W_ih / W_hh rows (two fp16 pieces behind one scale per block) into a double-buffered LDS image while the
+// waves multiply the current one.  The A operand is the pre-split workspace: four (kstep, piece) fragment pairs per
+// chunk, fetched one chunk ahead, no vector work.
+template <int H>
+__global__ void __launch_bounds__(512) gru_bwd_dx_stream_f16_kernel(const char* __restrict__ pieces,
+                                                                    const float* __restrict__ inv_scale,
+                                                                    const float* __restrict__ W_ih,
+                                                                    const float* __restrict__ W_hh, float* __restrict__ dm,
+                                                                    float* __restrict__ dh, int64_t V) {
+    constexpr int NS = H / 64, CPS = H / 64, NCT = 3 * CPS;
+    constexpr int TILE_BYTES = 32 * 4 * H * 4;
+    constexpr int IMGC = 64 * 128;             // one (matrix, piece) chunk image: 64 output rows x 64 k fp16
+    constexpr int BUF = 4 * IMGC;              // 32 KB
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float redw[8];
+
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int slice = jb % NS;
+    const int pblock = (jb / NS) * 8 + xcd, pblocks = gridDim.x / NS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hi = lane >> 5;
+
+    const int64_t rounds_total = (V + 255) / 256;              // a round = 256 rows: every wave its own 32-row tile
+    if (pblock >= rounds_total) return;
+    const int64_t nrounds = (rounds_total - pblock + pblocks - 1) / pblocks;
+
+    // one scale for the block's weights: largest magnitude of its 64 rows of both matrices
+    float inv_sw, sw;
+    {
+        float mx = 0.f;
+        for (int idx = tid; idx < 2 * 64 * (3 * H / 4); idx += 512) {
+            const int mat = idx / (64 * (3 * H / 4)), rem = idx % (64 * (3 * H / 4));
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>((mat ? W_hh : W_ih) + (int64_t)(64 * slice) * 3 * H + 4 * rem);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fabsf(w4[u]));
+        }
+        mx = g_wave_max(mx);
+        if (lane == 0) redw[wv] = mx;
+        __syncthreads();
+        mx = redw[0];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) mx = fmaxf(mx, redw[u]);
+        g_guard_scale<30>(mx, sw, inv_sw);
+    }
+
+    // staging unit = (matrix, output row n, k-octet): 1024 units, two per thread, 32 contiguous bytes each
+    const float* wsrc[2];
+    int ldst[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int u = tid + 512 * j;
+        const int mat = u / 512, rem = u % 512;
+        const int n = rem / 8, o = rem % 8;
+        wsrc[j] = (mat ? W_hh : W_ih) + (int64_t)(64 * slice + n) * 3 * H + 8 * o;
+        ldst[j] = mat * 2 * IMGC + n * 128 + ((o ^ ((n >> 1) & 7)) << 4);
+    }
+    f32x4 raw[2][2];
+    auto stage_load = [&](int ct) {                        // chunk ct = gate block ct / CPS, 64 columns at 64*(ct % CPS)
+        const int off = (ct / CPS) * H + 64 * (ct % CPS);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            raw[j][0] = *reinterpret_cast<const f32x4*>(wsrc[j] + off);
+            raw[j][1] = *reinterpret_cast<const f32x4*>(wsrc[j] + off + 4);
+        }
+    };
+    auto stage_write = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            h16x8 ph, pl;
+            g_split8(raw[j][0], raw[j][1], sw, ph, pl);
+            char* base = smem + buf * BUF + ldst[j];
+            *reinterpret_cast<h16x8*>(base) = ph;
+            *reinterpret_cast<h16x8*>(base + IMGC) = pl;
+        }
+    };
+    // k-octet of the chunk that step st of lane half hi multiplies: columns 16 st + 8 hi ... of the chunk
+    auto bfrag = [&](int buf, int mat, int piece, int nb, int st) {
+        const int n = 32 * nb + r;
+        const int o = 2 * st + hi;
+        return *reinterpret_cast<const h16x8*>(smem + buf * BUF + (mat * 2 + piece) * IMGC + n * 128 +
+                                               ((o ^ ((n >> 1) & 7)) << 4));
+    };
+    // this lane's four (hi, lo) fragment pairs of chunk cc of gradient segment `seg` for row tile `tile`
+    auto load_rows = [&](int64_t tile, int seg, int cc, h16x8 (&f)[8]) {
+        const char* p = pieces + tile * (int64_t)TILE_BYTES + (seg * (H / 16) + 4 * cc) * 2048 + r * 32 + hi * 16;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            f[2 * st] = *reinterpret_cast<const h16x8*>(p + st * 2048);
+            f[2 * st + 1] = *reinterpret_cast<const h16x8*>(p + st * 2048 + 1024);
+        }
+    };
+
+    f32x16 d_m[2], d_h[2];                                 // 32 rows x 64 features of dm and of dh per wave
+    h16x8 a0[8], a1[8], b0[8], b1[8];                      // operand of dm (a*) and of dh (b*, only in the n block)
+    int cur = 0;
+    int64_t tile = (int64_t)pblock * 8 + wv;
+    const int64_t tiles = (V + 31) / 32;
+
+    auto chunk = [&](int ct, int64_t tile_next, h16x8 (&xa)[8], h16x8 (&xb)[8], h16x8 (&na)[8], h16x8 (&nb_)[8]) {
+        __syncthreads();
+        const int cn = (ct + 1) % NCT;
+        const int gn = cn / CPS;
+        stage_load(cn);
+        load_rows(cn == 0 ? tile_next : tile, gn, cn % CPS, na);
+        if (gn == 2) load_rows(tile, 3, cn % CPS, nb_);    // dnh (never the first chunk of a round)
+        __builtin_amdgcn_sched_barrier(0);
+        const bool shared = ct / CPS < 2;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const h16x8 ah = xa[2 * st], al = xa[2 * st + 1];
+            const h16x8 bh = shared ? ah : xb[2 * st], bl = shared ? al : xb[2 * st + 1];
+            {
+                const h16x8 w0h = bfrag(cur, 0, 0, 0, st), w0l = bfrag(cur, 0, 1, 0, st);
+                const h16x8 w1h = bfrag(cur, 0, 0, 1, st), w1l = bfrag(cur, 0, 1, 1, st);
+                d_m[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, w0h, d_m[0], 0, 0, 0);
+                d_m[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, w1h, d_m[1], 0, 0, 0);
+                d_m[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w0l, d_m[0], 0, 0, 0);
+                d_m[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w1l, d_m[1], 0, 0, 0);
+                d_m[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w0h, d_m[0], 0, 0, 0);
+                d_m[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w1h, d_m[1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const h16x8 w0h = bfrag(cur, 1, 0, 0, st), w0l = bfrag(cur, 1, 1, 0, st);
+                const h16x8 w1h = bfrag(cur, 1, 0, 1, st), w1l = bfrag(cur, 1, 1, 1, st);
+                d_h[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, w0h, d_h[0], 0, 0, 0);
+                d_h[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, w1h, d_h[1], 0, 0, 0);
+                d_h[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, w0l, d_h[0], 0, 0, 0);
+                d_h[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, w1l, d_h[1], 0, 0, 0);
+                d_h[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, w0h, d_h[0], 0, 0, 0);
+                d_h[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, w1h, d_h[1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stage_write(cur ^ 1);
+        cur ^= 1;
+    };
+
+    stage_load(0);
+    stage_write(0);
+    if (tile >= tiles) tile = tiles - 1;                   // a wave past the end repeats the last tile and stores nothing
+    load_rows(tile, 0, 0, a0);
+    for (int64_t rd = 0; rd < nrounds; ++rd) {
+        int64_t tile_next = rd + 1 < nrounds ? (int64_t)(pblock + (rd + 1) * pblocks) * 8 + wv : tile;
+        if (tile_next >= tiles) tile_next = tiles - 1;
+        const bool live_tile = (int64_t)(pblock + rd * pblocks) * 8 + wv < tiles;
+        const float un = inv_scale[tile] * inv_sw;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { d_m[0][i] = 0.f; d_m[1][i] = 0.f; d_h[0][i] = 0.f; d_h[1][i] = 0.f; }
+#pragma unroll 1
+        for (int ct = 0; ct < NCT; ct += 2) {
+            chunk(ct, tile_next, a0, b0, a1, b1);
+            chunk(ct + 1, tile_next, a1, b1, a0, b0);
+        }
+        if (live_tile) {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const int fcol = 64 * slice + 32 * nb + r;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float prev[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        int64_t row = tile * 32 + 8 * g4 + 4 * hi + u;
+                        if (row >= V) row = V - 1;
+                        prev[u] = dh[row * H + fcol];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = 4 * g4 + u;
+                        const int64_t row = tile * 32 + 8 * g4 + 4 * hi + u;
+                        if (row < V) {
+                            dm[row * H + fcol] = d_m[nb][i] * un;
+                            dh[row * H + fcol] = d_h[nb][i] * un + prev[u];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        tile = tile_next;
+    }
+}
+
 // ----------------------------------------------------------------------------------------------------------- dW
-// blockIdx.y = matrix: dW_ih = m^T [dar daz dan], dW_hh = h^T [dar daz dnh] (128 x 384 each = 4 x 12 tiles of 32 x 32,
-// wave = (a-pair, b-triple) as in gru_bwd_dw128_kernel).  Double-buffered 32-atom tile in LDS: three gate images + the
-// X image, two pieces each, every image as the workspace has it ([8 ksteps][32 rows][16 columns], 64 KB per buffer).
-// The gate pieces need no processing, so they go from global memory straight into LDS (global_load_lds_dwordx4: a wave
-// copies 1 KB blocks verbatim, tools/microbench/lds_direct_load.hip) TWO tiles ahead, into the buffer the block has just
-// finished reading; m | h rows travel through registers (they are split here) and are also fetched two tiles ahead.
-// Columns are read with ds_read_b64_tr_b16: a 16-lane group covers 4 rows x 16 columns = 128 contiguous bytes.
-__global__ void __launch_bounds__(512) gru_bwd_dw128_f16_kernel(const float* __restrict__ m, const float* __restrict__ h,
-                                                                const char* __restrict__ pieces,
-                                                                const float* __restrict__ inv_scale, float* dW_ih,
-                                                                float* dW_hh, int64_t V) {
-    constexpr int H = GH;
-    constexpr int BUF = 8 * G_IMG;             // image (piece, slot) at (4 * piece + slot) * G_IMG; slot 3 = X
+// H = 128: blockIdx.y = matrix: dW_ih = m^T [dar daz dan], dW_hh = h^T [dar daz dnh] (128 x 384 each = 4 x 12 tiles of
+//          32 x 32; wave = 2 a-tiles x 3 b-tiles); LDS images per buffer: three gate segments + X.
+// H = 256: blockIdx.y = 3 * matrix + gate: one 256 x 256 block of dW_matrix (8 x 8 tiles; wave = 2 a-tiles x 4 b-tiles);
+//          LDS images per buffer: the two halves of the gate segment + the two halves of X.
+// An image = 8 ksteps = 128 columns of the 32-atom tile, as the workspace has it ([kstep][32 rows][16 columns], 8 KB per
+// piece); a buffer = 4 images x 2 pieces = 64 KB, double-buffered.  The gate pieces need no processing, so they go from
+// global memory straight into LDS (global_load_lds_dwordx4: a wave copies 1 KB blocks verbatim,
+// tools/microbench/lds_direct_load.hip) TWO tiles ahead, into the buffer the block has just finished reading; m | h rows
+// travel through registers (they are split here) and are also fetched two tiles ahead.  Columns are read with
+// ds_read_b64_tr_b16: a 16-lane group covers 4 rows x 16 columns = 128 contiguous bytes.
+template <int H>
+__global__ void __launch_bounds__(512) gru_bwd_dw_f16_kernel(const float* __restrict__ m, const float* __restrict__ h,
+                                                             const char* __restrict__ pieces,
+                                                             const float* __restrict__ inv_scale, float* dW_ih,
+                                                             float* dW_hh, int64_t V) {
+    constexpr int TILE_BYTES = 32 * 4 * H * 4;
+    constexpr int KS = H / 16;                 // ksteps per segment
+    constexpr int NXI = H / 128;               // X images (slots 4 - NXI .. 3); gate images in slots 0 .. 3 - NXI
+    constexpr int NGB = (4 - NXI) * 16;        // 1 KB gate blocks per tile: 48 / 32
+    constexpr int NB = H == 128 ? 3 : 4;       // b-tiles per wave
+    constexpr int NACC = 2 * NB;
+    constexpr int BUF = 8 * G_IMG;             // image (piece, slot) at (4 * piece + slot) * G_IMG
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem + 2 * BUF);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31;
-    const int mat = blockIdx.y;
+    const int mat = H == 128 ? blockIdx.y : blockIdx.y / 3;
+    const int gate = H == 128 ? 0 : blockIdx.y % 3;            // H = 256: the gate block of dW this block owns
     const float* X = mat == 0 ? m : h;
     const int64_t tiles = (V + 31) / 32;
     const int64_t t0 = blockIdx.x, tstep = gridDim.x;      // the launch keeps gridDim.x <= tiles
 
-    // wave wv copies blocks 6 wv .. 6 wv + 5 of the tile's 48 (slot, kstep, piece) blocks
+    // wave wv copies blocks (NGB / 8) wv ... of the tile's NGB (slot, kstep, piece) gate blocks
     auto issue_gates = [&](int64_t t, char* T) {
-        const char* p = pieces + t * (int64_t)G_TILE_BYTES + lane * 16;
+        const char* p = pieces + t * (int64_t)TILE_BYTES + lane * 16;
 #pragma unroll
-        for (int it = 0; it < 6; ++it) {
-            const int b = 6 * wv + it;
+        for (int it = 0; it < NGB / 8; ++it) {
+            const int b = (NGB / 8) * wv + it;
             const int slot = b >> 4, ks8 = (b >> 1) & 7, piece = b & 1;
-            const int seg = slot == 2 ? 2 + mat : slot;
-            g_copy_to_lds(p + ((seg * 8 + ks8) * 2 + piece) * 1024, T + (4 * piece + slot) * G_IMG + ks8 * 1024);
+            int ks;                                        // kstep of the workspace tile
+            if (H == 128) ks = (slot == 2 ? 2 + mat : slot) * KS + ks8;
+            else ks = (gate == 2 ? 2 + mat : gate) * KS + 8 * slot + ks8;
+            g_copy_to_lds(p + (ks * 2 + piece) * 1024, T + (4 * piece + slot) * G_IMG + ks8 * 1024);
         }
     };
     const int srow = tid >> 4, c16 = tid & 15;
-    const int x_dst = 3 * G_IMG + (c16 >> 1) * 1024 + srow * 32 + (c16 & 1) * 16;
-    struct XRows { f32x4 x0, x1; float inv_sg, live; };     // consumed only in publish / park_x: nothing waits on the loads before
+    const int x_dst = (4 - NXI) * G_IMG + (c16 >> 1) * 1024 + srow * 32 + (c16 & 1) * 16;
+    struct XRows { f32x4 x[NXI][2]; float inv_sg, live; };     // consumed only in publish / park_x: nothing waits on the loads before
     auto load_x = [&](int64_t t) {
         XRows q;
         int64_t row = t * 32 + srow;
         const bool ok = row < V;
         if (!ok) row = V - 1;
         q.live = ok ? 1.0f : 0.0f;                         // rows past V count as zeros
-        q.x0 = *reinterpret_cast<const f32x4*>(X + row * H + c16 * 8);
-        q.x1 = *reinterpret_cast<const f32x4*>(X + row * H + c16 * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < NXI; ++j) {
+            q.x[j][0] = *reinterpret_cast<const f32x4*>(X + row * H + 128 * j + c16 * 8);
+            q.x[j][1] = *reinterpret_cast<const f32x4*>(X + row * H + 128 * j + c16 * 8 + 4);
+        }
         q.inv_sg = inv_scale[t];
         return q;
     };
     auto publish = [&](const XRows& q, int par) {
         float mx = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) mx = fmaxf(mx, fmaxf(fabsf(q.x0[j]), fabsf(q.x1[j])));
+        for (int j = 0; j < NXI; ++j)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fmaxf(fabsf(q.x[j][0][u]), fabsf(q.x[j][1][u])));
         mx = g_wave_max(mx * q.live);
         if (lane == 0) red[8 * par + wv] = mx;
     };
@@ -427,32 +643,35 @@ __global__ void __launch_bounds__(512) gru_bwd_dw128_f16_kernel(const float* __r
         const float sg = __int_as_float((254 - ((__float_as_int(q.inv_sg) >> 23) & 0xff)) << 23);
         C_run = fminf(C_run, sg * sxo);
         const float sx = C_run * q.inv_sg;
-        h16x8 ph, pl;
-        g_split8(q.x0, q.x1, sx * q.live, ph, pl);
-        *reinterpret_cast<h16x8*>(T + x_dst) = ph;
-        *reinterpret_cast<h16x8*>(T + 4 * G_IMG + x_dst) = pl;
+#pragma unroll
+        for (int j = 0; j < NXI; ++j) {
+            h16x8 ph, pl;
+            g_split8(q.x[j][0], q.x[j][1], sx * q.live, ph, pl);
+            *reinterpret_cast<h16x8*>(T + j * G_IMG + x_dst) = ph;
+            *reinterpret_cast<h16x8*>(T + (4 + j) * G_IMG + x_dst) = pl;
+        }
     };
 
     // transposed reads: a 16-lane group takes rows 8*(g2>>1) + 4j + (0..3), columns 16*(g2&1) + (0..15) of 32-column
     // block cb = ksteps 2 cb, 2 cb + 1 of an image; lane 4q+p supplies row q, columns 4p..4p+3
-    const int ag = wv & 1, bg = wv >> 1;
+    const int ag = H == 128 ? (wv & 1) : (wv & 3), bg = H == 128 ? (wv >> 1) : (wv >> 2);
     const int g2 = lane >> 4, u16 = lane & 15, q4 = u16 >> 2, p4 = u16 & 3;
     auto tr_addr = [&](int slot, int cb, int j) {
         return slot * G_IMG + (2 * cb + (g2 & 1)) * 1024 + (8 * (g2 >> 1) + 4 * j + q4) * 32 + p4 * 8;
     };
-    int LA[3][2], LX[2][2];
+    int LA[NB][2], LX[2][2];
 #pragma unroll
-    for (int b = 0; b < 3; ++b)
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) LA[b][j] = tr_addr((3 * bg + b) >> 2, (3 * bg + b) & 3, j);
+        for (int j = 0; j < 2; ++j) LA[b][j] = tr_addr((NB * bg + b) >> 2, (NB * bg + b) & 3, j);
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) LX[a][j] = tr_addr(3, 2 * ag + a, j);
+        for (int j = 0; j < 2; ++j) LX[a][j] = tr_addr((4 - NXI) + ((2 * ag + a) >> 2), (2 * ag + a) & 3, j);
 
-    f32x16 R[6];
+    f32x16 R[NACC];
 #pragma unroll
-    for (int j = 0; j < 6; ++j)
+    for (int j = 0; j < NACC; ++j)
 #pragma unroll
         for (int q = 0; q < 16; ++q) R[j][q] = 0.f;
 
@@ -480,7 +699,7 @@ __global__ void __launch_bounds__(512) gru_bwd_dw128_f16_kernel(const float* __r
         if (__builtin_amdgcn_readfirstlane(__float_as_int(C_cur)) != __builtin_amdgcn_readfirstlane(__float_as_int(C_acc))) {
             const float ratio = C_cur / C_acc;             // < 1, a power of two
 #pragma unroll
-            for (int j = 0; j < 6; ++j)
+            for (int j = 0; j < NACC; ++j)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) R[j][q] *= ratio;
             C_acc = C_cur;
@@ -494,15 +713,15 @@ __global__ void __launch_bounds__(512) gru_bwd_dw128_f16_kernel(const float* __r
             const h16x8 a1h = g_tr8(Tb + LX[1][0], Tb + LX[1][1]);
             const h16x8 a1l = g_tr8(Tb + 4 * G_IMG + LX[1][0], Tb + 4 * G_IMG + LX[1][1]);
 #pragma unroll
-            for (int b = 0; b < 3; ++b) {
+            for (int b = 0; b < NB; ++b) {
                 const h16x8 bh = g_tr8(Tb + LA[b][0], Tb + LA[b][1]);
                 const h16x8 bl = g_tr8(Tb + 4 * G_IMG + LA[b][0], Tb + 4 * G_IMG + LA[b][1]);
                 R[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, bh, R[b], 0, 0, 0);
-                R[3 + b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, bh, R[3 + b], 0, 0, 0);
+                R[NB + b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, bh, R[NB + b], 0, 0, 0);
                 R[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bl, R[b], 0, 0, 0);
-                R[3 + b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bl, R[3 + b], 0, 0, 0);
+                R[NB + b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bl, R[NB + b], 0, 0, 0);
                 R[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bh, R[b], 0, 0, 0);
-                R[3 + b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bh, R[3 + b], 0, 0, 0);
+                R[NB + b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bh, R[NB + b], 0, 0, 0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -515,7 +734,9 @@ __global__ void __launch_bounds__(512) gru_bwd_dw128_f16_kernel(const float* __r
         // (requested at the top).  Draining HERE, before the next copies go out, also keeps the compiler from parking its
         // own vmcnt(0) for the rows behind them (it does not see the copies).
         __builtin_amdgcn_s_waitcnt(0x0F70);
-        asm volatile("" ::"v"(reload.x0), "v"(reload.x1), "v"(reload.inv_sg));
+#pragma unroll
+        for (int j = 0; j < NXI; ++j) asm volatile("" ::"v"(reload.x[j][0]), "v"(reload.x[j][1]));
+        asm volatile("" ::"v"(reload.inv_sg));
         if (has2) issue_gates(t2, smem + cur * BUF);       // into the buffer just read; lands during the next iteration
         cur ^= 1;
     };
@@ -528,61 +749,86 @@ __global__ void __launch_bounds__(512) gru_bwd_dw128_f16_kernel(const float* __r
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            const int col = 32 * (3 * bg + b) + i;
+        for (int b = 0; b < NB; ++b) {
+            const int col = (H == 128 ? 0 : gate * H) + 32 * (NB * bg + b) + i;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int row = 32 * (2 * ag + a) + acc_row(q, lane);
-                atomicAdd(dW + (int64_t)row * 3 * H + col, R[3 * a + b][q] * inv_C);
+                atomicAdd(dW + (int64_t)row * 3 * H + col, R[NB * a + b][q] * inv_C);
             }
         }
 }
 
-size_t gru_bwd128_f16_workspace_bytes(int64_t V) {
+size_t gru_bwd_f16_workspace_bytes(int64_t V, int H) {
     const int64_t tiles = (V + 31) / 32;
-    return (size_t)tiles * G_TILE_BYTES + (size_t)((tiles + 63) / 64 * 64) * sizeof(float);
+    return (size_t)tiles * (32 * 4 * H * 4) + (size_t)((tiles + 63) / 64 * 64) * sizeof(float);
 }
 
-int launch_gru_bwd128_f16(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
-                          const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
-                          float* db_ih, float* db_hh, void* workspace, int64_t V, hipStream_t s) {
+template <int H>
+static int launch_gru_bwd_f16_t(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
+                                const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
+                                float* db_ih, float* db_hh, void* workspace, int64_t V, hipStream_t s) {
     const int64_t tiles = (V + 31) / 32;
     char* pieces = (char*)workspace;
-    float* inv_scale = (float*)(pieces + (size_t)tiles * G_TILE_BYTES);
-    const size_t lds_dx = (size_t)2 * 2 * 32 * (2 * 3 * GH);
+    float* inv_scale = (float*)(pieces + (size_t)tiles * (32 * 4 * H * 4));
+    // dm | dh: streamed weights, 64-column slices (H = 128: 3.85 ms on c4); MPNN_GRU128_SLICED_DX=1 selects the kernel
+    // with resident 32-column slices at H = 128 (4.06 ms)
+    const bool kSlicedDx = H == 128 && switches().gru128_sliced_dx;
+    const size_t lds_sliced = (size_t)2 * 2 * 32 * (2 * 3 * GH), lds_stream = (size_t)2 * 4 * 64 * 128;
+    const size_t lds_dx = kSlicedDx ? lds_sliced : lds_stream;
     const size_t lds_dw = (size_t)2 * 8 * G_IMG + 64;
     static const hipError_t attr_done = [&] {   // once per process, thread-safe (C++11 static initialisation)
         LdsOptIn opt_in_;
-        opt_in_((const void*)gru_bwd_dx128_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dx);
-        opt_in_((const void*)gru_bwd_dw128_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dw);
+        if (H == 128) opt_in_((const void*)gru_bwd_dx128_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sliced);
+        opt_in_((const void*)gru_bwd_dx_stream_f16_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_stream);
+        opt_in_((const void*)gru_bwd_dw_f16_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dw);
         return opt_in_.err;
     }();
     if (attr_done != hipSuccess) return lds_opt_in_failed(attr_done);
 
-    int64_t gg = 1024;
+    int64_t gg = H == 128 ? 1024 : 512;
     if (gg > tiles) gg = tiles;
     if (mask)
-        hipLaunchKernelGGL(gru_gate_f16_128_kernel<true>, dim3((unsigned)gg), dim3(512), 0, s, dout, h, mask, saved, pieces,
+        hipLaunchKernelGGL((gru_gate_f16_kernel<H, true>), dim3((unsigned)gg), dim3(512), 0, s, dout, h, mask, saved, pieces,
                            inv_scale, dh, db_ih, db_hh, V);
     else
-        hipLaunchKernelGGL(gru_gate_f16_128_kernel<false>, dim3((unsigned)gg), dim3(512), 0, s, dout, h, mask, saved, pieces,
+        hipLaunchKernelGGL((gru_gate_f16_kernel<H, false>), dim3((unsigned)gg), dim3(512), 0, s, dout, h, mask, saved, pieces,
                            inv_scale, dh, db_ih, db_hh, V);
     int rc = launch_status("mpnn_gru_update_bwd_f32(gates, fp16 pieces)");
     if (rc) return rc;
 
-    int64_t pblocks = 64;                                   // x 4 slices = one block per CU
-    if (pblocks * 8 > tiles) pblocks = (tiles + 7) / 8;
-    pblocks = (pblocks + 7) / 8 * 8;
-    hipLaunchKernelGGL(gru_bwd_dx128_f16_kernel, dim3((unsigned)(pblocks * 4)), dim3(512), lds_dx, s, pieces, inv_scale, W_ih,
-                       W_hh, dm, dh, V);
-    rc = launch_status("mpnn_gru_update_bwd_f32(dx, H=128, fp16 pieces)");
+    if (kSlicedDx) {
+        int64_t pblocks = 64;                               // x 4 slices = one block per CU
+        if (pblocks * 8 > tiles) pblocks = (tiles + 7) / 8;
+        pblocks = (pblocks + 7) / 8 * 8;
+        hipLaunchKernelGGL(gru_bwd_dx128_f16_kernel, dim3((unsigned)(pblocks * 4)), dim3(512), lds_dx, s, pieces, inv_scale,
+                           W_ih, W_hh, dm, dh, V);
+    } else {
+        constexpr int NS = H / 64;
+        const int64_t rounds = (V + 255) / 256;
+        int64_t pblocks = 256 / NS;
+        if (pblocks > rounds) pblocks = rounds;
+        pblocks = (pblocks + 7) / 8 * 8;
+        hipLaunchKernelGGL(gru_bwd_dx_stream_f16_kernel<H>, dim3((unsigned)(pblocks * NS)), dim3(512), lds_dx, s, pieces,
+                           inv_scale, W_ih, W_hh, dm, dh, V);
+    }
+    rc = launch_status("mpnn_gru_update_bwd_f32(dx, fp16 pieces)");
     if (rc) return rc;
 
-    int64_t gx = 128;                                       // x 2 matrices = one block per CU (128 KB of LDS)
+    constexpr int NY = H == 128 ? 2 : 6;                    // block types: matrix, or (matrix, gate)
+    int64_t gx = 256 / NY;                                  // one block per CU (128 KB of LDS)
     if (gx > tiles) gx = tiles;
-    hipLaunchKernelGGL(gru_bwd_dw128_f16_kernel, dim3((unsigned)gx, 2), dim3(512), lds_dw, s, m, h, pieces, inv_scale, dW_ih,
+    hipLaunchKernelGGL(gru_bwd_dw_f16_kernel<H>, dim3((unsigned)gx, NY), dim3(512), lds_dw, s, m, h, pieces, inv_scale, dW_ih,
                        dW_hh, V);
-    return launch_status("mpnn_gru_update_bwd_f32(dW, H=128, fp16 pieces)");
+    return launch_status("mpnn_gru_update_bwd_f32(dW, fp16 pieces)");
+}
+
+int launch_gru_bwd_f16_wide(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
+                            const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
+                            float* db_ih, float* db_hh, void* workspace, int64_t V, int H, hipStream_t s) {
+    if (H == 128)
+        return launch_gru_bwd_f16_t<128>(dout, m, h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, workspace, V, s);
+    return launch_gru_bwd_f16_t<256>(dout, m, h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, workspace, V, s);
 }
 
 }  // namespace mpnn

@@ -72,7 +72,7 @@ def mfma_per_product(kernel=None, hidden=64):
     if math_mode() == "fp32":
         return 0
     if kernel == "gru_update_bwd" and not os.environ.get("MPNN_GRU_BWD_BF16"):
-        if hidden == 128 or (hidden == 64 and not os.environ.get("MPNN_GRU_BWD_FP32TILE")
+        if hidden in (128, 256) or (hidden == 64 and not os.environ.get("MPNN_GRU_BWD_FP32TILE")
                              and not os.environ.get("MPNN_GRU_BWD_UNIFORM")):
             return 3
     if hidden == 64 and kernel == "gru_update" and os.environ.get("MPNN_GRU_FWD_FP16"):

@@ -79,10 +79,10 @@ def _gru_bwd_ref64(m, h, mask, dout, W1, W2, b1, b2):
     return m64.grad, h64.grad, W1d.grad, W2d.grad, b1d.grad, b2d.grad
 
 
-@pytest.mark.parametrize("H", [64, 128])
+@pytest.mark.parametrize("H", [64, 128, 256])
 @pytest.mark.parametrize("profile", ["unit", "x1e-6", "x1e-20", "x1e+8", "rising", "falling", "one_hot_tile", "small_x_tiles"])
 def test_gru_backward_range_guards(dev, profile, H):
-    """The width-64 and width-128 GRU backward run on two fp16 pieces per operand behind power-of-two range guards (per
+    """The width-64, -128 and -256 GRU backward run on two fp16 pieces per operand behind power-of-two range guards (per
     32-atom tile for the gate gradients, per block and running for m | h; csrc/gru_bwd_f16.hip, gru_bwd128_f16.hip).  Gradient magnitudes that sit far
     from 1, that climb or fall by 1e8 across the batch (the running scale of the dW accumulators changes on the way),
     or that differ by 1e6 between neighbouring tiles (and m | h rows that differ by 1e3) must keep the float32 bar, per tensor AND per row of dm / dh."""

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GRU forward/backward kernels alone at hidden 64 (c2 size) or 128 (c4 size): timing and float64 error.
+"""GRU forward/backward kernels alone at hidden 64 (c2 size), 128 (c4 size) or 256: timing and float64 error.
     python tools/bench_gru_bwd.py [128]                      (default: backward on two fp16 pieces, three MFMAs per product)
     MPNN_GRU_BWD_BF16=1 python tools/bench_gru_bwd.py [128]  (three bf16 pieces, six MFMAs per product)"""
 import os, sys, torch
@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mpnn_amd import ops
 dev = torch.device("cuda:0")
 H = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-V = {64: 2_997_659, 128: 3_749_258}[H]
+V = {64: 2_997_659, 128: 3_749_258, 256: 2_400_011}[H]
 g = torch.Generator(device=dev).manual_seed(0)
 m, h, dout = (torch.randn(V, H, device=dev, generator=g) for _ in range(3))
 mask = torch.ones(V, device=dev)
