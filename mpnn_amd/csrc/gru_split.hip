@@ -751,15 +751,17 @@ __global__ void __launch_bounds__(512) gru_update_stream_kernel(
     }
 }
 
-template <int H, bool HAS_MASK, bool SAVE>
+template <int H, bool HAS_MASK, bool SAVE, bool F16 = false>
 __global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
     const float* __restrict__ m, const float* __restrict__ h, const float* __restrict__ mask,
     const float* __restrict__ W_ih, const float* __restrict__ W_hh, const float* __restrict__ b_ih,
     const float* __restrict__ b_hh, float* __restrict__ out, float* __restrict__ saved, int64_t V) {
     constexpr int NS = H / 64, NCHUNK = H / 32, COLS = 192;
-    constexpr int IMGC = COLS * 64;            // bytes of one (matrix, piece) chunk image: 192 columns x 32 k bf16
-    constexpr int BUF = 6 * IMGC;              // 72 KB
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][2 matrices][3 pieces][192][32] bf16
+    constexpr int IMGC = COLS * 64;            // bytes of one (matrix, piece) chunk image: 192 columns x 32 k of 16 bits
+    constexpr int NP = F16 ? 2 : 3;            // pieces per operand
+    constexpr int BUF = 2 * NP * IMGC;         // 72 KB (bf16x6) / 48 KB (fp16x3)
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][2 matrices][NP pieces][192][32]
+    __shared__ float redw[8];
 
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
     const int slice = jb % NS;                                 // the NS slice blocks of a row group share an XCD
@@ -772,8 +774,27 @@ __global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
     if (pblock >= rounds_total) return;                        // block-uniform
     const int64_t nrounds = (rounds_total - pblock + pblocks - 1) / pblocks;
 
-
-
+    // F16: one power-of-two scale for the block's weights (its 64 features x 3 gates of both matrices land below 2^15)
+    float w_sc = 1.0f, w_inv = 1.0f;
+    if (F16) {
+        float mx = 0.f;
+        for (int idx = tid; idx < 2 * H * 48; idx += 512) {    // (matrix, k, 48 float4 of the slice's three gate blocks)
+            const int mat = idx / (H * 48), rem = idx % (H * 48);
+            const int kk = rem / 48, q = rem % 48;
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>((mat ? W_hh : W_ih) + (int64_t)kk * 3 * H + (q / 16) * H +
+                                                             64 * slice + 4 * (q % 16));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fabsf(w4[u]));
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if (lane == 0) redw[wv] = mx;
+        __syncthreads();
+        mx = redw[0];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) mx = fmaxf(mx, redw[u]);
+        pow2_scale_of(mx, w_sc, w_inv);
+    }
     // ---- weight staging: unit = (matrix, k-octet of the chunk, column); 1536 units, three per thread ----
     // per-thread constants of its three units: source pointer at chunk 0 and LDS byte offset
     const float* wsrc[3];
@@ -784,7 +805,7 @@ __global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
         const int mat = u / 768, rem = u % 768;
         const int o = rem / COLS, cl = rem % COLS;
         wsrc[j] = (mat ? W_hh : W_ih) + (int64_t)(8 * o) * 3 * H + (cl / 64) * H + 64 * slice + (cl % 64);
-        ldst[j] = mat * 3 * IMGC + cl * 64 + ((o ^ ((cl >> 2) & 3)) << 4);
+        ldst[j] = mat * NP * IMGC + cl * 64 + ((o ^ ((cl >> 2) & 3)) << 4);
     }
     // one staging unit at a time (8 registers live): loaded before a third of the chunk's MFMAs, written after it
     float raw[8];
@@ -796,19 +817,29 @@ __global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
     auto stage_write1 = [&](int buf, int j) {
         const f32x4 x0 = {raw[0], raw[1], raw[2], raw[3]};
         const f32x4 x1 = {raw[4], raw[5], raw[6], raw[7]};
-        bf16x8 ph, pm, pl;
-        split8(x0, x1, ph, pm, pl);
         char* base = smem + buf * BUF + ldst[j];
-        *reinterpret_cast<bf16x8*>(base) = ph;
-        *reinterpret_cast<bf16x8*>(base + IMGC) = pm;
-        *reinterpret_cast<bf16x8*>(base + 2 * IMGC) = pl;
+        if (F16) {
+            f16x8 ph, pl;
+            split8_f16(x0, x1, w_sc, ph, pl);
+            *reinterpret_cast<f16x8*>(base) = ph;
+            *reinterpret_cast<f16x8*>(base + IMGC) = pl;
+        } else {
+            bf16x8 ph, pm, pl;
+            split8(x0, x1, ph, pm, pl);
+            *reinterpret_cast<bf16x8*>(base) = ph;
+            *reinterpret_cast<bf16x8*>(base + IMGC) = pm;
+            *reinterpret_cast<bf16x8*>(base + 2 * IMGC) = pl;
+        }
     };
     // B fragment: column cl = gate*64 + 32*nb + r, k-octet 2*hi + st of the chunk
     auto bfrag = [&](int buf, int mat, int piece, int gate, int nb, int st) {
         const int cl = gate * 64 + 32 * nb + r;
         const int o = 2 * hi + st;
-        return *reinterpret_cast<const bf16x8*>(smem + buf * BUF + (mat * 3 + piece) * IMGC + cl * 64 +
+        return *reinterpret_cast<const bf16x8*>(smem + buf * BUF + (mat * NP + piece) * IMGC + cl * 64 +
                                                 ((o ^ ((cl >> 2) & 3)) << 4));
+    };
+    auto bfrag16 = [&](int buf, int mat, int piece, int gate, int nb, int st) {
+        return __builtin_bit_cast(f16x8, bfrag(buf, mat, piece, gate, nb, st));
     };
     // this lane's 16 floats of chunk c of operand X for row tile `tile`
     auto load_rows = [&](const float* __restrict__ X, int64_t tile, int c, f32x4 (&f)[4]) {
@@ -821,6 +852,40 @@ __global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
 
     f32x16 acc_r[2], acc_z[2], acc_ni[2], acc_nh[2];       // 32 rows x 64 features per wave
     f32x4 a0[4], a1[4];                                     // operand half-chunks: one multiplying, one in flight
+    // F16: the rows of a tile are range-guarded one by one (a row scale factors out of the product): row_sc = power of two
+    // that put the row's largest operand entry seen so far into [2^11, 2^12) when it was chosen -- eight-fold headroom,
+    // so later chunks rarely force a change; when one does, the row's accumulator entries are multiplied by the ratio.
+    float row_sc = 1.0f, row_inv = 1.0f;
+    auto rescale_rows = [&](float ratio) {                  // ratio of lane j (< 32) = factor for the tile's row j
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int dr = 8 * (i >> 2) + (i & 3);
+            const float f_lo = readlane_f(ratio, dr), f_hi = readlane_f(ratio, 4 + dr);
+            const float f = hi ? f_hi : f_lo;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                acc_r[nb][i] *= f; acc_z[nb][i] *= f; acc_ni[nb][i] *= f; acc_nh[nb][i] *= f;
+            }
+        }
+    };
+    auto guard_rows = [&](int hc, const f32x4 (&x)[4]) {
+        float mx = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fabsf(x[q][u]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));                 // both halves of the row
+        const bool grow = hc == 0 || mx * row_sc >= 32768.0f;
+        if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+            int e = (__float_as_int(mx) >> 23) & 0xff;
+            e = e < 87 ? 87 : e;
+            const float ns = grow ? __int_as_float((265 - e) << 23) : row_sc;    // mx * ns in [2^11, 2^12)
+            const float ni = grow ? __int_as_float((e - 11) << 23) : row_inv;
+            if (hc != 0) rescale_rows(ns * row_inv);
+            row_sc = ns;
+            row_inv = ni;
+        }
+    };
     int cur = 0;
     int64_t tile = ((int64_t)pblock) * 8 + wv;
 
@@ -833,8 +898,10 @@ __global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
         const int hn = (hc + 1) % (2 * NCHUNK);
         load_rows((hn & 1) ? h : m, hn == 0 ? tile_next : tile, hn >> 1, nx);
         const int cn = (c + 1) % NCHUNK;
+        if (F16) guard_rows(hc, x);
         __builtin_amdgcn_sched_barrier(0);
         bf16x8 a_h, a_m, a_l;
+        f16x8 f_h, f_l;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int st = i / 3, gate = i % 3;
@@ -843,13 +910,18 @@ __global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
                 if (mat == 0) stage_load1(cn, i / 3);
                 else if (i == 0) stage_load1(cn, 2);
                 __builtin_amdgcn_sched_barrier(0);
-                split8(x[2 * st], x[2 * st + 1], a_h, a_m, a_l);
+                if (F16) split8_f16(x[2 * st], x[2 * st + 1], row_sc, f_h, f_l);
+                else split8(x[2 * st], x[2 * st + 1], a_h, a_m, a_l);
             }
             {   // the two column blocks are independent accumulators: issued alternately (split_math.h)
                 f32x16(&acc)[2] = gate == 0 ? acc_r : gate == 1 ? acc_z : (mat == 0 ? acc_ni : acc_nh);
-                mma6x2_a(acc[0], acc[1], a_h, a_m, a_l, bfrag(cur, mat, 0, gate, 0, st), bfrag(cur, mat, 1, gate, 0, st),
-                         bfrag(cur, mat, 2, gate, 0, st), bfrag(cur, mat, 0, gate, 1, st), bfrag(cur, mat, 1, gate, 1, st),
-                         bfrag(cur, mat, 2, gate, 1, st));
+                if (F16)
+                    mma3x2_a(acc[0], acc[1], f_h, f_l, bfrag16(cur, mat, 0, gate, 0, st), bfrag16(cur, mat, 1, gate, 0, st),
+                             bfrag16(cur, mat, 0, gate, 1, st), bfrag16(cur, mat, 1, gate, 1, st));
+                else
+                    mma6x2_a(acc[0], acc[1], a_h, a_m, a_l, bfrag(cur, mat, 0, gate, 0, st), bfrag(cur, mat, 1, gate, 0, st),
+                             bfrag(cur, mat, 2, gate, 0, st), bfrag(cur, mat, 0, gate, 1, st), bfrag(cur, mat, 1, gate, 1, st),
+                             bfrag(cur, mat, 2, gate, 1, st));
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (i % 3 == 2) {
@@ -915,10 +987,15 @@ __global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
                         const float mk_lo = readlane_f(mkl, dr), mk_hi = readlane_f(mkl, 4 + dr);
                         mk = hi ? mk_hi : mk_lo;
                     }
-                    const float rg = sigmoid_fast(acc_r[nb][i] + br) * mk;
-                    const float zg = sigmoid_fast(acc_z[nb][i] + bz) * mk;
-                    const float nh = acc_nh[nb][i] + bnh;
-                    const float ng = tanh_fast(acc_ni[nb][i] + bni + rg * nh) * mk;
+                    float un = 1.0f;                       // F16: undo the row's and the weights' scale
+                    if (F16) {
+                        const float u_lo = readlane_f(row_inv, dr), u_hi = readlane_f(row_inv, 4 + dr);
+                        un = (hi ? u_hi : u_lo) * w_inv;
+                    }
+                    const float rg = sigmoid_fast(acc_r[nb][i] * un + br) * mk;
+                    const float zg = sigmoid_fast(acc_z[nb][i] * un + bz) * mk;
+                    const float nh = acc_nh[nb][i] * un + bnh;
+                    const float ng = tanh_fast(acc_ni[nb][i] * un + bni + rg * nh) * mk;
                     const float hval = FULL ? hv[nb][i] : (row0 + dr < V ? hb[dr * H + 32 * nb] : 0.f);
                     const float o = ((1.0f - zg) * ng + zg * hval) * mk;
                     if (FULL || row0 + dr < V) {
@@ -972,14 +1049,19 @@ template <int H>
 static int launch_stream_wide(const float* m, const float* h, const float* mask, const float* W_ih, const float* W_hh,
                          const float* b_ih, const float* b_hh, float* out, float* saved, int64_t V, hipStream_t s) {
     constexpr int NS = H / 64;
-    const size_t lds = (size_t)2 * 6 * 192 * 64;
+    const bool f16 = !switches().gru_fwd_bf16;               // default: two fp16 pieces per operand, row-wise range guards
+    const size_t lds = f16 ? (size_t)2 * 4 * 192 * 64 : (size_t)2 * 6 * 192 * 64;
     static const hipError_t attr_done = [&] {   // once per process, thread-safe (C++11 static initialisation)
         LdsOptIn opt_in_;
-        const int n = (int)lds;
+        const int n = (int)2 * 6 * 192 * 64, n16 = (int)2 * 4 * 192 * 64;
         opt_in_((const void*)gru_update_stream_wide_kernel<H, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
         opt_in_((const void*)gru_update_stream_wide_kernel<H, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
         opt_in_((const void*)gru_update_stream_wide_kernel<H, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
         opt_in_((const void*)gru_update_stream_wide_kernel<H, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
+        opt_in_((const void*)gru_update_stream_wide_kernel<H, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n16);
+        opt_in_((const void*)gru_update_stream_wide_kernel<H, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n16);
+        opt_in_((const void*)gru_update_stream_wide_kernel<H, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n16);
+        opt_in_((const void*)gru_update_stream_wide_kernel<H, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n16);
         return opt_in_.err;
     }();
     if (attr_done != hipSuccess) return lds_opt_in_failed(attr_done);
@@ -989,14 +1071,20 @@ static int launch_stream_wide(const float* m, const float* h, const float* mask,
     pblocks = (pblocks + 7) / 8 * 8;                        // XCD-aware numbering wants groups of 8 row blocks
     const dim3 grid((unsigned)(pblocks * NS)), block(512);
 #define MPNN_LAUNCH_WIDE(MASKED, SAVED)                                                                                  \
-    hipLaunchKernelGGL((gru_update_stream_wide_kernel<H, MASKED, SAVED>), grid, block, lds, s, m, h, mask, W_ih, W_hh, \
-                       b_ih, b_hh, out, saved, V)
+    do {                                                                                                                 \
+        if (f16)                                                                                                         \
+            hipLaunchKernelGGL((gru_update_stream_wide_kernel<H, MASKED, SAVED, true>), grid, block, lds, s, m, h, mask, \
+                               W_ih, W_hh, b_ih, b_hh, out, saved, V);                                                   \
+        else                                                                                                             \
+            hipLaunchKernelGGL((gru_update_stream_wide_kernel<H, MASKED, SAVED>), grid, block, lds, s, m, h, mask, W_ih, \
+                               W_hh, b_ih, b_hh, out, saved, V);                                                         \
+    } while (0)
     if (mask && saved) MPNN_LAUNCH_WIDE(true, true);
     else if (mask) MPNN_LAUNCH_WIDE(true, false);
     else if (saved) MPNN_LAUNCH_WIDE(false, true);
     else MPNN_LAUNCH_WIDE(false, false);
 #undef MPNN_LAUNCH_WIDE
-    return launch_status("mpnn_gru_update_f32(bf16x6, streamed weights, wide tile)");
+    return launch_status("mpnn_gru_update_f32(streamed weights, wide tile)");
 }
 
 // returns 1 when the width has no split-precision path

@@ -325,6 +325,72 @@ def test_att_gate_forward_backward(dev, V, F, K):
     assert max_err(q.grad, q64.grad) / max(1.0, float(q64.grad.abs().max())) < 1e-5
 
 
+@pytest.mark.parametrize("H", [128, 256])
+@pytest.mark.parametrize("profile", ["unit", "rows_1e-6_to_10", "growing_along_k", "h_much_larger", "tiny", "zero_rows"])
+def test_gru_forward_wide_row_guards(dev, H, profile):
+    """The width-128 / 256 GRU forward runs on two fp16 pieces per operand; each atom's m | h row is range-guarded by its own
+    power-of-two scale, chosen at the first K chunk with eight-fold headroom and lowered (the row's accumulator entries
+    rescaled) when a later chunk outgrows it (csrc/gru_split.hip, gru_update_stream_wide_kernel<.., F16>).  Rows of wildly
+    different magnitude in one tile, entries that grow along K, h rows far above m rows, tiny and all-zero rows must keep
+    the float32 bar on the gate PRE-activations' scale, i.e. on `out` and on the saved gates."""
+    from mpnn_amd import ops
+    V = 20_011
+    g = torch.Generator(device=dev).manual_seed(H + len(profile))
+    m = torch.randn(V, H, device=dev, generator=g)
+    h = torch.rand(V, H, device=dev, generator=g) * 2 - 1
+    mask = (torch.rand(V, device=dev, generator=g) > 0.1).float()
+    bound = (6.0 / (4 * H)) ** 0.5
+    W_ih, W_hh = ((torch.rand(H, 3 * H, device=dev, generator=g) * 2 - 1) * bound for _ in range(2))
+    b_ih, b_hh = (torch.rand(3 * H, device=dev, generator=g) * 0.2 - 0.1 for _ in range(2))
+    if profile == "rows_1e-6_to_10":                          # neighbouring rows 7 orders of magnitude apart (larger rows
+        f = torch.logspace(-6, 1, 8, device=dev)[torch.arange(V, device=dev) % 8].reshape(-1, 1)    # would only test
+        m = m * f                                             # float32 conditioning: pre-activations of 1e3)
+    elif profile == "growing_along_k":                        # later K chunks outgrow the first one 100-fold
+        m = m * torch.logspace(-2, 0.5, H, device=dev).reshape(1, -1)
+    elif profile == "h_much_larger":
+        m, h = m * 1e-3, h * 30.0
+        W_hh = W_hh * 0.03
+    elif profile == "tiny":
+        m, h = m * 1e-12, h * 1e-12
+    elif profile == "zero_rows":
+        m[::3] = 0.0
+        h[::3] = 0.0
+    m, h = m.contiguous(), h.contiguous()
+    out, saved = ops.gru_update_raw(m, h, mask, W_ih, W_hh, b_ih, b_hh, True)
+    gi = m.double() @ W_ih.double() + b_ih.double()
+    gh = h.double() @ W_hh.double() + b_hh.double()
+    mk = mask.double().reshape(-1, 1)
+    r = torch.sigmoid(gi[:, :H] + gh[:, :H]) * mk
+    z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H]) * mk
+    n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:]) * mk
+    ref = ((1 - z) * n + z * h.double()) * mk
+    scale = max(1.0, float(h.abs().max()))
+    assert float((out.double() - ref).abs().max()) < 1e-5 * scale, profile
+    sv = saved.double().reshape(V, 4, H)
+    assert float((sv[:, 0] - r).abs().max()) < 1e-5
+    assert float((sv[:, 1] - z).abs().max()) < 1e-5
+    assert float((sv[:, 2] - n).abs().max()) < 1e-5
+    nh_ref = gh[:, 2 * H:]
+    assert float((sv[:, 3] - nh_ref).abs().max()) < 1e-5 * max(1.0, float(nh_ref.abs().max()))
+    assert float(out[mask == 0].abs().max()) == 0.0
+
+
+def test_gru_forward_wide_bf16_alternate_holds_the_parity_bar():
+    """MPNN_GRU_FWD_BF16=1 (three bf16 pieces: round 1's kernel, the A/B alternate of the fp16 default at widths 128 / 256)
+    against float64; switches are read once per process, so it runs in a child (tools/bench_gru_fwd.py prints the error)."""
+    import os
+    import re
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = dict(os.environ, MPNN_GRU_FWD_BF16="1")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "bench_gru_fwd.py"), "128"], capture_output=True,
+                       text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    err = float(re.search(r"max \|out - float64\| over \d+ atoms = ([0-9.e+-]+)", r.stdout).group(1))
+    assert err < 2e-6
+
+
 def test_gru_forward_fp16_two_piece_variant_holds_the_parity_bar():
     """MPNN_GRU_FWD_FP16=1 (two fp16 pieces + power-of-two range guards, three MFMAs per product; an A/B alternate of the
     default three-way bf16 split, see DESIGN 'fp16 operand pieces') against float64 at the c2 size.  The switch is read

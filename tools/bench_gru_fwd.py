@@ -1,4 +1,4 @@
-"""GRU forward at hidden 64, c2 size: timing and float64 error of the running math mode.
+"""GRU forward at hidden 64 (c2 size; or 128 / 256 as argument): timing and float64 error of the running math mode.
     python tools/bench_gru_fwd.py            (default: three bf16 pieces, six MFMAs per product)
     MPNN_GRU_FWD_FP16=1 python tools/bench_gru_fwd.py   (two fp16 pieces, three MFMAs per product)"""
 import os
@@ -10,7 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mpnn_amd import ops            # noqa: E402
 
 dev = torch.device("cuda:0")
-V, H = 2_997_659, 64
+H = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+V = {64: 2_997_659, 128: 3_749_258, 256: 2_400_011}[H]
 gen = torch.Generator(device=dev).manual_seed(1)
 m = torch.randn(V, H, device=dev, generator=gen)
 h = torch.rand(V, H, device=dev, generator=gen) * 2 - 1
