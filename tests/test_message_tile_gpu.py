@@ -9,7 +9,9 @@ import torch
 
 from conftest import max_err
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("MPNN_GRU_MATH") == "fp32" or bool(os.environ.get("MPNN_UNFUSED_MESSAGE")),
+                                 reason="the tile kernel is switched off in this mode (ops.tile_kernel_applies)")]
 
 
 @pytest.fixture(scope="module")
