@@ -26,7 +26,6 @@ const Switches& switches() {
         s.gru256_narrow = getenv("MPNN_GRU256_NARROW") != nullptr;
         s.gru_bwd_uniform = getenv("MPNN_GRU_BWD_UNIFORM") != nullptr;
         s.gru_bwd_fp32tile = getenv("MPNN_GRU_BWD_FP32TILE") != nullptr;
-        s.gru_fwd_fp16 = getenv("MPNN_GRU_FWD_FP16") != nullptr;
         s.gru_fwd_bf16 = getenv("MPNN_GRU_FWD_BF16") != nullptr;
         s.gru_bwd_bf16 = getenv("MPNN_GRU_BWD_BF16") != nullptr;
         const char* v = getenv("MPNN_SEGSUM_VARIANT");

@@ -46,8 +46,7 @@ struct Switches {
     bool gru256_narrow;      // MPNN_GRU256_NARROW: 32-feature wave tiles in the streamed width-256 GRU
     bool gru_bwd_uniform;    // MPNN_GRU_BWD_UNIFORM: all-waves-identical GRU backward at width 64
     bool gru_bwd_fp32tile;   // MPNN_GRU_BWD_FP32TILE: fp32 LDS tile in the GRU backward at width 64
-    bool gru_fwd_fp16;       // MPNN_GRU_FWD_FP16: width-64 GRU forward with two fp16 pieces per operand (3 MFMAs per product)
-    bool gru_fwd_bf16;       // MPNN_GRU_FWD_BF16: width-128/256 GRU forward on three bf16 pieces instead of two row-guarded fp16 pieces
+    bool gru_fwd_bf16;       // MPNN_GRU_FWD_BF16: GRU forward (64 / 128 / 256) on three bf16 pieces instead of two row-guarded fp16 pieces
     bool gru_bwd_bf16;       // MPNN_GRU_BWD_BF16: width-64 GRU backward on three bf16 pieces (gru_bwd_presplit.hip) instead of two fp16 pieces (gru_bwd_f16.hip)
     int segsum_variant;      // MPNN_SEGSUM_VARIANT: 1 = one atom per lane group, 2 = cached loads/stores, 3 = default
 };

@@ -187,7 +187,6 @@ __global__ void __launch_bounds__(64 * NW) gru_update_split_kernel(
                                                ((chunk ^ col_swizzle<H>(col)) << 4));
     };
     load_frags(m, t, fa);
-    if (F16) load_frags(h, t, fb);                       // fp16 pieces need the tile's scale: both operands up front
     for (; t < tiles; t += stride) {
         f32x16 acc_r[NCS], acc_z[NCS], acc_ni[NCS], acc_nh[NCS];
 #pragma unroll
@@ -195,27 +194,32 @@ __global__ void __launch_bounds__(64 * NW) gru_update_split_kernel(
 #pragma unroll
             for (int i = 0; i < 16; ++i) { acc_r[s][i] = 0.f; acc_z[s][i] = 0.f; acc_ni[s][i] = 0.f; acc_nh[s][i] = 0.f; }
 
-        float t_sc = 1.0f, t_inv = 1.0f;
-        if (F16) {
+        // F16: every atom's m row and h row get their own power-of-two scale (a row scale factors out of the product; the
+        // whole row is in the registers of its two lanes).  r and z sum an m product and an h product: their accumulators
+        // are rescaled row by row from the m scale to the h scale between the two phases (exact: powers of two).
+        float m_inv = 1.0f, h_inv = 1.0f;
+        auto row_scale = [&](const f32x4 (&f)[NF4], float& sc, float& inv) {
             float mx = 0.f;
 #pragma unroll
             for (int q = 0; q < NF4; ++q)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fmaxf(fabsf(fa[q][u]), fabsf(fb[q][u])));
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-            pow2_scale_of(mx, t_sc, t_inv);
-            t_inv *= w_inv;
-        } else {
-            load_frags(h, t, fb);                        // in flight while the m-products run
-        }
+                for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fabsf(f[q][u]));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));          // the other half of the row
+            int e = (__float_as_int(mx) >> 23) & 0xff;
+            e = e < 87 ? 87 : e;
+            sc = __int_as_float((268 - e) << 23);        // row maximum in [2^14, 2^15)
+            inv = __int_as_float((e - 14) << 23);
+        };
+        load_frags(h, t, fb);                            // in flight while the m-products run
         __builtin_amdgcn_sched_barrier(0);
         if (F16) {
             static_assert(!F16 || NCS == 2, "the fp16 variant is written for two column slices per gate");
+            float m_sc;
+            row_scale(fa, m_sc, m_inv);
 #pragma unroll
             for (int st = 0; st < STEPS; ++st) {
                 f16x8 ah, al;
-                split8_f16(fa[2 * st], fa[2 * st + 1], t_sc, ah, al);
+                split8_f16(fa[2 * st], fa[2 * st + 1], m_sc, ah, al);
                 auto pair = [&](f32x16 (&acc)[NCS], int g) {
                     const int c0_ = g * CS + r, c1_ = g * CS + 32 + r;
                     mma3x2_a(acc[0], acc[NCS - 1], ah, al, bfrag16(0, 0, c0_, st), bfrag16(0, 1, c0_, st),
@@ -224,10 +228,23 @@ __global__ void __launch_bounds__(64 * NW) gru_update_split_kernel(
                 pair(acc_r, 0); pair(acc_z, 1); pair(acc_ni, 2);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            float h_sc;
+            row_scale(fb, h_sc, h_inv);
+            {
+                const float ratio = h_sc * m_inv;        // lane j (< 32): factor for the tile's row j
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int dr = 8 * (i >> 2) + (i & 3);
+                    const float f_lo = readlane_f(ratio, dr), f_hi = readlane_f(ratio, 4 + dr);
+                    const float f = hi ? f_hi : f_lo;
+#pragma unroll
+                    for (int s2 = 0; s2 < NCS; ++s2) { acc_r[s2][i] *= f; acc_z[s2][i] *= f; }
+                }
+            }
 #pragma unroll
             for (int st = 0; st < STEPS; ++st) {
                 f16x8 ah, al;
-                split8_f16(fb[2 * st], fb[2 * st + 1], t_sc, ah, al);
+                split8_f16(fb[2 * st], fb[2 * st + 1], h_sc, ah, al);
                 auto pair = [&](f32x16 (&acc)[NCS], int g) {
                     const int c0_ = g * CS + r, c1_ = g * CS + 32 + r;
                     mma3x2_a(acc[0], acc[NCS - 1], ah, al, bfrag16(1, 0, c0_, st), bfrag16(1, 1, c0_, st),
@@ -323,14 +340,9 @@ __global__ void __launch_bounds__(64 * NW) gru_update_split_kernel(
             // (unconditional, tile index clamped: under a condition the old fragments would stay live as the other arm)
             if (FULL) {
                 load_frags(m, t + stride < tiles ? t + stride : t, fa);
-                if (F16) load_frags(h, t + stride < tiles ? t + stride : t, fb);
             } else {
 #pragma unroll
                 for (int q = 0; q < NF4; ++q) fa[q] = f32x4{0.f, 0.f, 0.f, 0.f};   // last tile: defined, never used
-                if (F16) {
-#pragma unroll
-                    for (int q = 0; q < NF4; ++q) fb[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
             }
             __builtin_amdgcn_sched_barrier(0);
             float* ob = out + t * 32 * H + eo;
@@ -345,12 +357,19 @@ __global__ void __launch_bounds__(64 * NW) gru_update_split_kernel(
                     const float mk_hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mkl), 4 + dr));
                     mk = hi ? mk_hi : mk_lo;
                 }
+                float un_m = 1.0f, un_h = 1.0f;                    // F16: undo the row's and the weights' scales
+                if (F16) {
+                    const float a_lo = readlane_f(m_inv, dr), a_hi = readlane_f(m_inv, 4 + dr);
+                    const float b_lo = readlane_f(h_inv, dr), b_hi = readlane_f(h_inv, 4 + dr);
+                    un_m = (hi ? a_hi : a_lo) * w_inv;
+                    un_h = (hi ? b_hi : b_lo) * w_inv;
+                }
 #pragma unroll
                 for (int s = 0; s < NCS; ++s) {
-                    const float rg = sigmoid_fast((F16 ? acc_r[s][i] * t_inv : acc_r[s][i]) + br[s]) * mk;
-                    const float zg = sigmoid_fast((F16 ? acc_z[s][i] * t_inv : acc_z[s][i]) + bz[s]) * mk;
-                    const float nh = (F16 ? acc_nh[s][i] * t_inv : acc_nh[s][i]) + bnh[s];
-                    const float ng = tanh_fast((F16 ? acc_ni[s][i] * t_inv : acc_ni[s][i]) + bni[s] + rg * nh) * mk;
+                    const float rg = sigmoid_fast((F16 ? acc_r[s][i] * un_h : acc_r[s][i]) + br[s]) * mk;
+                    const float zg = sigmoid_fast((F16 ? acc_z[s][i] * un_h : acc_z[s][i]) + bz[s]) * mk;
+                    const float nh = (F16 ? acc_nh[s][i] * un_h : acc_nh[s][i]) + bnh[s];
+                    const float ng = tanh_fast((F16 ? acc_ni[s][i] * un_m : acc_ni[s][i]) + bni[s] + rg * nh) * mk;
                     const float hval = FULL ? hv[i][s] : (row0 + dr < V ? hb[dr * H + 32 * s] : 0.f);
                     const float o = ((1.0f - zg) * ng + zg * hval) * mk;
                     if (FULL || row0 + dr < V) {
@@ -396,7 +415,7 @@ static int launch_split(const float* m, const float* h, const float* mask, const
 #define MPNN_LAUNCH_SPLIT(MASKED, SAVED)                                                                                   \
     hipLaunchKernelGGL((gru_update_split_kernel<H, NCS, NW, MASKED, SAVED>), grid, block, lds, s, m, h, mask, W_ih, W_hh,  \
                        b_ih, b_hh, out, saved, V, slices)
-    if (H == 64 && NCS == 2 && switches().gru_fwd_fp16) {          // A/B: two fp16 pieces, three MFMAs per product
+    if (H == 64 && NCS == 2 && !switches().gru_fwd_bf16) {         // default: two row-guarded fp16 pieces, three MFMAs per product
         constexpr bool F = (H == 64 && NCS == 2);
         static const hipError_t attr16 = [&] {
             LdsOptIn opt_in_;
@@ -416,7 +435,7 @@ static int launch_split(const float* m, const float* h, const float* mask, const
         else if (saved) MPNN_LAUNCH_F16(false, true);
         else MPNN_LAUNCH_F16(false, false);
 #undef MPNN_LAUNCH_F16
-        return launch_status("mpnn_gru_update_f32(fp16x3)");
+        return launch_status("mpnn_gru_update_f32(fp16x3, row guards)");
     }
     if (mask && saved) MPNN_LAUNCH_SPLIT(true, true);
     else if (mask) MPNN_LAUNCH_SPLIT(true, false);

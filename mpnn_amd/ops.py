@@ -67,19 +67,17 @@ def math_mode():
 def mfma_per_product(kernel=None, hidden=64):
     """16-bit MFMAs issued per fp32 product by a contraction kernel (`kernel` = its KernelTimer label; 0 = the fp32
     matrix pipe itself).  Three-way bf16 splits issue six; the kernels on two fp16 pieces issue three: the fused
-    message + sum tile kernel, the width-64 and width-128 GRU backward (unless MPNN_GRU_BWD_BF16) and, with MPNN_GRU_FWD_FP16, the
-    width-64 GRU forward; the width-128 / 256 GRU forward (unless MPNN_GRU_FWD_BF16) issues three as well."""
+    message + sum tile kernel and, at widths 64 / 128 / 256, the GRU backward (unless MPNN_GRU_BWD_BF16) and the GRU
+    forward (unless MPNN_GRU_FWD_BF16)."""
     if math_mode() == "fp32":
         return 0
     if kernel == "gru_update_bwd" and not os.environ.get("MPNN_GRU_BWD_BF16"):
         if hidden in (128, 256) or (hidden == 64 and not os.environ.get("MPNN_GRU_BWD_FP32TILE")
                              and not os.environ.get("MPNN_GRU_BWD_UNIFORM")):
             return 3
-    if kernel == "gru_update":
-        if hidden == 64 and os.environ.get("MPNN_GRU_FWD_FP16"):
-            return 3
-        if hidden in (128, 256) and not os.environ.get("MPNN_GRU_FWD_BF16") and not os.environ.get("MPNN_GRU128_SLICED") \
-                and not os.environ.get("MPNN_GRU256_NARROW"):
+    if kernel == "gru_update" and not os.environ.get("MPNN_GRU_FWD_BF16"):
+        if hidden == 64 or (hidden in (128, 256) and not os.environ.get("MPNN_GRU128_SLICED")
+                            and not os.environ.get("MPNN_GRU256_NARROW")):
             return 3
     if kernel == "message_aggregate":
         return 3
@@ -89,8 +87,8 @@ def mfma_per_product(kernel=None, hidden=64):
 def math_description():
     return {"fp32": "fp32 matrix pipe (MPNN_GRU_MATH=fp32)",
             "bf16x6": "fp32 data and accumulation; dense contractions as three-way bf16 operand splits "
-                      "(six bf16 MFMAs per fp32 product) or, in the fused message+sum kernel, the GRU backward and the "
-                      "width-128/256 GRU forward, range-guarded two-way fp16 splits (three MFMAs per product); parity 1e-5 as the "
+                      "(six bf16 MFMAs per fp32 product) or, in the fused message+sum kernel and the GRU forward and "
+                      "backward at widths 64/128/256, range-guarded two-way fp16 splits (three MFMAs per product); parity 1e-5 as the "
                       "fp32 kernels"}[math_mode()]
 
 

@@ -115,11 +115,11 @@ def test_mfma_pricing_follows_the_math_switches(monkeypatch):
     product (ops.mfma_per_product): six for the three-way bf16 splits, three for the kernels on two fp16 pieces, zero
     (= the fp32 pipe itself) under MPNN_GRU_MATH=fp32.  The table must follow the same switches the library reads."""
     from mpnn_amd import ops
-    for k in ("MPNN_GRU_MATH", "MPNN_GRU_BWD_BF16", "MPNN_GRU_FWD_BF16", "MPNN_GRU_FWD_FP16", "MPNN_GRU_BWD_FP32TILE",
+    for k in ("MPNN_GRU_MATH", "MPNN_GRU_BWD_BF16", "MPNN_GRU_FWD_BF16", "MPNN_GRU_BWD_FP32TILE",
               "MPNN_GRU_BWD_UNIFORM", "MPNN_GRU128_SLICED", "MPNN_GRU256_NARROW"):
         monkeypatch.delenv(k, raising=False)
     assert [ops.mfma_per_product("gru_update_bwd", h) for h in (64, 128, 256)] == [3, 3, 3]
-    assert [ops.mfma_per_product("gru_update", h) for h in (64, 128, 256)] == [6, 3, 3]
+    assert [ops.mfma_per_product("gru_update", h) for h in (64, 128, 256)] == [3, 3, 3]
     assert ops.mfma_per_product("message_aggregate", 64) == 3 and ops.mfma_per_product("edge_message", 128) == 6
     monkeypatch.setenv("MPNN_GRU_BWD_BF16", "1")
     monkeypatch.setenv("MPNN_GRU_FWD_BF16", "1")

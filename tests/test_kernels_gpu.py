@@ -325,12 +325,14 @@ def test_att_gate_forward_backward(dev, V, F, K):
     assert max_err(q.grad, q64.grad) / max(1.0, float(q64.grad.abs().max())) < 1e-5
 
 
-@pytest.mark.parametrize("H", [128, 256])
+@pytest.mark.parametrize("H", [64, 128, 256])
 @pytest.mark.parametrize("profile", ["unit", "rows_1e-6_to_10", "growing_along_k", "h_much_larger", "tiny", "zero_rows"])
 def test_gru_forward_wide_row_guards(dev, H, profile):
-    """The width-128 / 256 GRU forward runs on two fp16 pieces per operand; each atom's m | h row is range-guarded by its own
-    power-of-two scale, chosen at the first K chunk with eight-fold headroom and lowered (the row's accumulator entries
-    rescaled) when a later chunk outgrows it (csrc/gru_split.hip, gru_update_stream_wide_kernel<.., F16>).  Rows of wildly
+    """The GRU forward runs on two fp16 pieces per operand; each atom's m | h row is range-guarded by its own power-of-two
+    scale.  Widths 128 / 256 (gru_update_stream_wide_kernel<.., F16>): chosen at the first K chunk with eight-fold headroom
+    and lowered (the row's accumulator entries rescaled) when a later chunk outgrows it.  Width 64
+    (gru_update_split_kernel<.., F16>): the whole row is in registers, m and h rows get separate scales and the r / z
+    accumulators are rescaled between the two products.  Rows of wildly
     different magnitude in one tile, entries that grow along K, h rows far above m rows, tiny and all-zero rows must keep
     the float32 bar on the gate PRE-activations' scale, i.e. on `out` and on the saved gates."""
     from mpnn_amd import ops
@@ -376,7 +378,7 @@ def test_gru_forward_wide_row_guards(dev, H, profile):
 
 
 def test_gru_forward_wide_bf16_alternate_holds_the_parity_bar():
-    """MPNN_GRU_FWD_BF16=1 (three bf16 pieces: round 1's kernel, the A/B alternate of the fp16 default at widths 128 / 256)
+    """MPNN_GRU_FWD_BF16=1 (three bf16 pieces: round 1's kernels, the A/B alternates of the fp16 default)
     against float64; switches are read once per process, so it runs in a child (tools/bench_gru_fwd.py prints the error)."""
     import os
     import re
@@ -384,25 +386,9 @@ def test_gru_forward_wide_bf16_alternate_holds_the_parity_bar():
     import sys
     from conftest import REPO
     env = dict(os.environ, MPNN_GRU_FWD_BF16="1")
-    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "bench_gru_fwd.py"), "128"], capture_output=True,
-                       text=True, timeout=600, env=env)
-    assert r.returncode == 0, r.stderr[-2000:]
-    err = float(re.search(r"max \|out - float64\| over \d+ atoms = ([0-9.e+-]+)", r.stdout).group(1))
-    assert err < 2e-6
-
-
-def test_gru_forward_fp16_two_piece_variant_holds_the_parity_bar():
-    """MPNN_GRU_FWD_FP16=1 (two fp16 pieces + power-of-two range guards, three MFMAs per product; an A/B alternate of the
-    default three-way bf16 split, see DESIGN 'fp16 operand pieces') against float64 at the c2 size.  The switch is read
-    once per process, so the variant runs in a child process (tools/bench_gru_fwd.py prints its error)."""
-    import os
-    import re
-    import subprocess
-    import sys
-    from conftest import REPO
-    env = dict(os.environ, MPNN_GRU_FWD_FP16="1")
-    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "bench_gru_fwd.py")], capture_output=True, text=True,
-                       timeout=600, env=env)
-    assert r.returncode == 0, r.stderr[-2000:]
-    err = float(re.search(r"max \|out - float64\| over \d+ atoms = ([0-9.e+-]+)", r.stdout).group(1))
-    assert err < 1e-5
+    for width in ("64", "128"):
+        r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "bench_gru_fwd.py"), width], capture_output=True,
+                           text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        err = float(re.search(r"max \|out - float64\| over \d+ atoms = ([0-9.e+-]+)", r.stdout).group(1))
+        assert err < 2e-6, (width, err)
