@@ -14,13 +14,15 @@
 // column-major; every lane supplies its own row address, so gathered rows cost nothing extra) and feed
 // v_mfma_f32_32x32x16_f16.  Wave w owns output quadrant w & 3 (32 x 32 of the 64 x 64) of ALL bond types for the blocks
 // 4 (w >> 2) .. + 3 of every tile: its accumulators live in registers for the whole kernel and leave through one float
-// atomic per element per wave at the end (128-byte segments, 32 MB in all).
+// atomic per element per wave at the end (128-byte segments, 64 MB in all).
 //
-// Math ("fp16x3", as the forward): one power-of-two scale per tile for the dagg rows and one for the h rows; x*s = hi +
-// lo with hi = fp16(x*s), lo = fp16(x*s - hi); three MFMAs per product (hi*hi, hi*lo, lo*hi) into ONE fp32 accumulator
-// per (type, quadrant) that is zeroed per tile and folded into the kernel-long fp32 sum with the tile's exact inverse
-// scale.  Error: normwise ~2^-22 of (tile max |dagg|) (tile max |h|) per term -- entries more than 2^18 below their
-// tile's maximum lose relative (not absolute) accuracy, which a sum over all atoms does not see.
+// Math ("fp16x3", as the forward): one power-of-two scale sd per tile for the dagg rows; the h rows are split behind
+// C / sd with C = the running minimum over the block's tiles of sd * (best scale of the tile's h rows), so that every
+// tile's products carry the same factor C and the kernel-long accumulators need no per-tile fold (gru_bwd_f16.hip has the
+// argument; when C drops they are multiplied by the ratio, a power of two).  x*s = hi + lo with hi = fp16(x*s),
+// lo = fp16(x*s - hi); three MFMAs per product (hi*hi, hi*lo, lo*hi).  Error: normwise ~2^-22 of (tile max |dagg|)
+// (tile max |h|) per term -- entries more than 2^18 below their tile's maximum lose relative (not absolute) accuracy,
+// which a sum over all atoms does not see.  Two blocks are resident per CU (75 KB of LDS, 128 VGPRs).
 #include "common.h"
 
 namespace mpnn {
@@ -39,9 +41,11 @@ __host__ __device__ constexpr int mb_lds_bytes() {
     return 4 * MB_HT + 8 * 16 * MB_RTMAX * 4 + MB_TV * 4 + (8 * MB_KMAX + 4) * 4 + 128;
 }
 
-__device__ __forceinline__ void mb_pow2_scale(float maxabs, float& scale, float& inv) {
+// power of two s with maxabs * s in [2^14, 2^15), and 1 / s; s is clamped to [2^-46, 2^SMAX] (gru_bwd_f16.hip)
+template <int SMAX>
+__device__ __forceinline__ void mb_guard_scale(float maxabs, float& scale, float& inv) {
     int e = (__float_as_int(maxabs) >> 23) & 0xff;
-    e = e < 20 ? 20 : e;
+    e = e < 141 - SMAX ? 141 - SMAX : (e > 187 ? 187 : e);
     scale = __int_as_float((268 - e) << 23);
     inv = __int_as_float((e - 14) << 23);
 }
@@ -56,7 +60,7 @@ __device__ __forceinline__ f16x8 mb_tr8(const char* a0, const char* a1) {
     return __builtin_bit_cast(f16x8, v);
 }
 
-__global__ void __launch_bounds__(512, 2) message_sum_tile_bwd_kernel(
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) message_sum_tile_bwd_kernel(
     const float* __restrict__ dagg, const float* __restrict__ h, const int32_t* __restrict__ tile_rec,
     const int32_t* __restrict__ tile_atom, const int32_t* __restrict__ tile_rtk, const int32_t* __restrict__ slots,
     float* __restrict__ dA, int num_tiles, int K) {
@@ -135,7 +139,8 @@ __global__ void __launch_bounds__(512, 2) message_sum_tile_bwd_kernel(
             red[8 + wv] = mx;
         }
     };
-    auto stage_write = [&](const Rec& r) -> float {     // returns 1 / (scale_d * scale_x)
+    float C_run = 3.0e38f, C_acc = 3.0e38f;             // min over the tiles so far of scale_d * (best scale_x); of `tot`
+    auto stage_write = [&](const Rec& r) {
         float md = 0.f, mx = 0.f;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -143,8 +148,12 @@ __global__ void __launch_bounds__(512, 2) message_sum_tile_bwd_kernel(
             mx = fmaxf(mx, red[8 + u]);
         }
         float scd, invd, scx, invx;
-        mb_pow2_scale(md, scd, invd);
-        mb_pow2_scale(mx, scx, invx);
+        mb_guard_scale<90>(md, scd, invd);
+        mb_guard_scale<30>(mx, scx, invx);
+        // every tile's products must carry the same factor: the h rows are split behind C / scale_d <= their best scale,
+        // C = the running minimum of scale_d * scale_x (gru_bwd_f16.hip has the argument); no per-tile accumulators
+        C_run = fminf(C_run, scd * scx);
+        scx = C_run * invd;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int row = srow + 32 * j;
@@ -169,7 +178,6 @@ __global__ void __launch_bounds__(512, 2) message_sum_tile_bwd_kernel(
             if (64 * j < nw) slw_all[wv * 16 * MB_RTMAX + 64 * j + lane] = slotreg[j];
         if (tid < MB_TV) atoms[tid] = atomreg;
         if (tid < nrk) rtk[tid] = rtkreg;
-        return invd * invx;
     };
 
     // transposed-read geometry of this lane (see the header): 16-lane group gg, position 4 q + p inside it
@@ -186,23 +194,24 @@ __global__ void __launch_bounds__(512, 2) message_sum_tile_bwd_kernel(
         for (int i = 0; i < 16; ++i) tot[k][i] = 0.f;
 
     const int G = gridDim.x;
-    int t = blockIdx.x;
-    Rec cur = load_rec(t < num_tiles ? t : 0);
-    Rec nxt = load_rec(t + G < num_tiles ? t + G : 0);
-    if (t < num_tiles) stage_load(cur, t);
-    for (; t < num_tiles; t += G) {
+    for (int t = blockIdx.x; t < num_tiles; t += G) {
+        // Two of these blocks are resident per CU (75 KB of LDS, 128 VGPRs each): one block's loads and staging sit under
+        // the other's row-tile loop, which does more than a register prefetch of the next tile did (0.70 ms with it and
+        // one block per CU)
+        const Rec cur = load_rec(t);
+        stage_load(cur, t);
         stage_max();
         __syncthreads();
-        const float inv = stage_write(cur);
+        stage_write(cur);
+        if (__builtin_amdgcn_readfirstlane(__float_as_int(C_run)) != __builtin_amdgcn_readfirstlane(__float_as_int(C_acc))) {
+            const float ratio = C_run / C_acc;          // < 1, a power of two (0 before the first tile: tot is zero)
+#pragma unroll
+            for (int k = 0; k < MB_KMAX; ++k)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) tot[k][i] *= ratio;
+            C_acc = C_run;
+        }
         __syncthreads();
-        const Rec nn = load_rec(t + 2 * G < num_tiles ? t + 2 * G : 0);
-        if (t + G < num_tiles) stage_load(nxt, t + G);
-
-        f32x16 acc[MB_KMAX];
-#pragma unroll
-        for (int k = 0; k < MB_KMAX; ++k)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
         // Block by block; inside a block its row-tiles in memory order (type-major), the type loop unrolled so that each
         // type has its own static accumulator.  The h fragments of row-tile i + 1 and the slot words of row-tile i + 2
         // are requested before the MFMAs of row-tile i, across the type boundaries (they do not depend on the type).
@@ -249,9 +258,9 @@ __global__ void __launch_bounds__(512, 2) message_sum_tile_bwd_kernel(
                         words(i + 2, wb0, wb1);
                         frags(wa0, wa1, bh_n, bl_n);                   // row-tile i + 1 (a harmless re-read at the end)
                         __builtin_amdgcn_sched_barrier(0);
-                        acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[k], 0, 0, 0);
-                        acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[k], 0, 0, 0);
-                        acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[k], 0, 0, 0);
+                        tot[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, tot[k], 0, 0, 0);
+                        tot[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, tot[k], 0, 0, 0);
+                        tot[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, tot[k], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
                         bh = bh_n;
                         bl = bl_n;
@@ -261,15 +270,10 @@ __global__ void __launch_bounds__(512, 2) message_sum_tile_bwd_kernel(
                 }
             }
         }
-#pragma unroll
-        for (int k = 0; k < MB_KMAX; ++k)
-            if (k < K)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) tot[k][i] += acc[k][i] * inv;
-        cur = nxt;
-        nxt = nn;
+        __syncthreads();                                // every wave is done with this tile's LDS
     }
     // ---- my quadrant of every type -> dA (accumulated across blocks with float atomics; 128-byte segments)
+    const float inv_C = C_acc < 1.0e38f ? 1.0f / C_acc : 0.f;
     const int col = lane & 31;
 #pragma unroll
     for (int k = 0; k < MB_KMAX; ++k) {
@@ -277,7 +281,7 @@ __global__ void __launch_bounds__(512, 2) message_sum_tile_bwd_kernel(
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-                atomicAdd(dA + ((int64_t)k * MB_F + 32 * nb + row) * MB_F + 32 * fb + col, tot[k][i]);
+                atomicAdd(dA + ((int64_t)k * MB_F + 32 * nb + row) * MB_F + 32 * fb + col, tot[k][i] * inv_C);
             }
         }
     }
@@ -302,7 +306,7 @@ extern "C" int mpnn_message_aggregate_bwd_da_f32(const float* dagg, const float*
         return opt_in_.err;
     }();
     if (attr != hipSuccess) return lds_opt_in_failed(attr);
-    int64_t blocks = 256;
+    int64_t blocks = 512;                                  // two resident blocks per CU
     if (blocks > num_tiles) blocks = num_tiles;
     hipLaunchKernelGGL(message_sum_tile_bwd_kernel, dim3((unsigned)blocks), dim3(512), mb_lds_bytes(), (hipStream_t)stream, dagg, h,
                        tile_rec, tile_atom, tile_rtk, slots, dA, (int)num_tiles, K);
