@@ -127,6 +127,31 @@ def test_gru_backward_range_guards(dev, profile, H):
         assert float(got[k][~live].abs().max()) == 0.0       # masked atoms: exact zeros
 
 
+@pytest.mark.parametrize("H", [64, 128, 256])
+@pytest.mark.parametrize("V", [1, 31, 32, 33, 255, 256, 257, 2049])
+def test_gru_forward_backward_at_tile_boundaries(dev, V, H):
+    """Atom counts around the kernels' granularities (32-atom tiles, 256-row rounds of the streamed kernels, fewer tiles
+    than blocks): forward and every gradient of the raw GRU calls against float64, the ragged tail rows included."""
+    from mpnn_amd import ops
+    g = torch.Generator(device=dev).manual_seed(1000 * H + V)
+    m, h, dout = (torch.randn(V, H, device=dev, generator=g) for _ in range(3))
+    mask = (torch.rand(V, device=dev, generator=g) > 0.2).float()
+    W1, W2 = (torch.randn(H, 3 * H, device=dev, generator=g) / (2 * H ** 0.5) for _ in range(2))
+    b1, b2 = (torch.randn(3 * H, device=dev, generator=g) / 8 for _ in range(2))
+    out, saved = ops.gru_update_raw(m, h, mask, W1, W2, b1, b2, True)
+    got = ops.gru_update_bwd_raw(dout, m, h, mask, W1, W2, saved)
+    want = _gru_bwd_ref64(m, h, mask, dout, W1, W2, b1, b2)
+    gi, gh = m.double() @ W1.double() + b1.double(), h.double() @ W2.double() + b2.double()
+    mk = mask.double().reshape(-1, 1)
+    r = torch.sigmoid(gi[:, :H] + gh[:, :H]) * mk
+    z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H]) * mk
+    n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:]) * mk
+    assert float((out.double() - ((1 - z) * n + z * h.double()) * mk).abs().max()) < 1e-5
+    for a, b, name in zip(got, want, ("dm", "dh", "dW_ih", "dW_hh", "db_ih", "db_hh")):
+        err = float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+        assert err < 2e-5, (name, err)
+
+
 def test_gru_backward_h64_bf16_alternate_holds_the_parity_bar():
     """MPNN_GRU_BWD_BF16=1 (three bf16 pieces, six MFMAs per product: round 1's kernel, kept as the A/B alternate of the
     fp16 default) against float64 at the c2 size.  Switches are read once per process, so it runs in a child
