@@ -504,23 +504,39 @@ def main():
         if rehearsal:
             out["rehearsal"] = ("%d ranks share %d GPU(s) over %s: exercises the multi-rank code path only, the rate is "
                                 "not a scaling measurement" % (world, ndev, backend))
-        # ---- the dense contractions against the pipe they run on: 16-bit MFMA peak divided by the MFMAs issued per fp32
-        # product (6 for the three-way bf16 split, 3 for the two-way fp16 split); the fp32-MFMA-peak ratio is a side figure
+        # ---- the dense contractions against BOTH roofs: the matrix pipe (16-bit MFMA peak divided by the MFMAs issued per fp32
+        # product: 6 for the three-way bf16 split, 3 for the two-way fp16 split; the fp32-MFMA-peak ratio is a side figure) and
+        # HBM (the bytes the operator must move: operands read once, results written once).  `bound` names the roof the
+        # kernel sits closer to; `frac` is the fraction of THAT roof.
+        saved_rows = 4 if args.mode == "train" else 0         # the GRU forward dumps (r, z, n, gh_n) for the backward
         rows = []
-        for key, name, flops in (("edge_message", "typed edge message (mpnn_edge_message_f32)", 2.0 * F * F * Eb),
-                                 ("gru_update", "masked GRU update forward (mpnn_gru_update_f32)", 12.0 * F * F * Vb),
-                                 ("gru_update_bwd", "masked GRU update backward (mpnn_gru_update_bwd_f32)", 24.0 * F * F * Vb)):
+        for key, name, flops, nbytes, what in (
+                ("edge_message", "typed edge message (mpnn_edge_message_f32)", 2.0 * F * F * Eb, 4.0 * F * 2 * Eb,
+                 "4*nf*E gathered + 4*mf*E written"),
+                ("gru_update", "masked GRU update forward (mpnn_gru_update_f32)", 12.0 * F * F * Vb,
+                 4.0 * F * (3 + saved_rows) * Vb, "m, h read, out%s written: 4*H*V each" % (" and 4 gate arrays" if saved_rows else "")),
+                ("gru_update_bwd", "masked GRU update backward (mpnn_gru_update_bwd_f32)", 24.0 * F * F * Vb, 4.0 * F * 9 * Vb,
+                 "dout, m, h, 4 gate arrays read, dm, dh written: 4*H*V each")):
             ms = timer.mean_ms(key)
             if ms is None:
                 continue
             per = ops.mfma_per_product(key, hidden)
             peak_eq = MFMA_16BIT_PEAK_TF / per if per else MFMA_F32_PEAK_TF
             tf = flops / (ms * 1e-3) / 1e12
-            rows.append({"kernel": name, "bound": "mfma", "unit": "TFLOP/s (fp32-equivalent)", "achieved": tf,
-                         "peak": peak_eq, "frac": tf / peak_eq, "avg_launch_ms": ms,
-                         "peak_note": "%.0f TF 16-bit dense MFMA peak / %d MFMAs per fp32 product" % (MFMA_16BIT_PEAK_TF, per) if per
-                                      else "fp32 MFMA peak",
-                         "side_figure_vs_fp32_mfma_peak": tf / MFMA_F32_PEAK_TF})
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            f_mfma, f_hbm = tf / peak_eq, gbs / HBM_PEAK_GBS
+            row = {"kernel": name, "avg_launch_ms": ms,
+                   "mfma": {"unit": "TFLOP/s (fp32-equivalent)", "achieved": tf, "peak": peak_eq, "frac": f_mfma,
+                            "peak_note": "%.0f TF 16-bit dense MFMA peak / %d MFMAs per fp32 product" % (MFMA_16BIT_PEAK_TF, per)
+                                         if per else "fp32 MFMA peak",
+                            "side_figure_vs_fp32_mfma_peak": tf / MFMA_F32_PEAK_TF},
+                   "hbm": {"unit": "GB/s", "achieved": gbs, "peak": HBM_PEAK_GBS, "frac": f_hbm,
+                           "algorithmic_bytes_per_launch": nbytes, "formula": what}}
+            if f_hbm >= f_mfma:
+                row.update({"bound": "hbm", "unit": "GB/s", "achieved": gbs, "peak": HBM_PEAK_GBS, "frac": f_hbm})
+            else:
+                row.update({"bound": "mfma", "unit": "TFLOP/s (fp32-equivalent)", "achieved": tf, "peak": peak_eq, "frac": f_mfma})
+            rows.append(row)
         out["roofline_contractions"] = rows
         if world == 1:
             out["roofline"]["stream_calibration"] = stream_calibration(dev, alg_bytes)
