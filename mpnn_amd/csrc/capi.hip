@@ -28,6 +28,7 @@ const Switches& switches() {
         s.gru_bwd_fp32tile = getenv("MPNN_GRU_BWD_FP32TILE") != nullptr;
         s.gru_fwd_bf16 = getenv("MPNN_GRU_FWD_BF16") != nullptr;
         s.gru_bwd_bf16 = getenv("MPNN_GRU_BWD_BF16") != nullptr;
+        s.gru_dx_slice64 = getenv("MPNN_GRU_DX_SLICE64") != nullptr;
         const char* v = getenv("MPNN_SEGSUM_VARIANT");
         s.segsum_variant = v ? atoi(v) : 3;
         return s;

@@ -559,6 +559,189 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_stream_f16_kernel(const char* 
     }
 }
 
+// ------------------------------------------------------------------ dm | dh, weights streamed, 128-column slices
+// The kernel above re-reads the piece workspace once per 64-column slice (2x at H = 128, 4x at H = 256: 80 GB on c5,
+// which is what its 15.8 ms are).  Here a block owns 128 output features of dm and of dh -- a wave 32 rows x 128 features
+// of both, eight accumulators -- so the pieces are read H / 128 times.  What pays for the registers: the contraction is
+// cut into 32-wide chunks (two K = 16 steps; A operand 16 registers per set instead of 32), and the third gate block is
+// walked twice, once as (dan, W_ih) -> dm and once as (dnh, W_hh) -> dh, so that no second operand set is ever live.
+template <int H>
+__global__ void __launch_bounds__(512) gru_bwd_dx_wide_f16_kernel(const char* __restrict__ pieces,
+                                                                  const float* __restrict__ inv_scale,
+                                                                  const float* __restrict__ W_ih,
+                                                                  const float* __restrict__ W_hh, float* __restrict__ dm,
+                                                                  float* __restrict__ dh, int64_t V) {
+    constexpr int NS = H / 128, CPS = H / 32, NCT = 4 * CPS;
+    constexpr int TILE_BYTES = 32 * 4 * H * 4;
+    constexpr int IMGC = 128 * 64;             // one (matrix, piece) chunk image: 128 output rows x 32 k fp16
+    constexpr int BUF = 4 * IMGC;              // 32 KB
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float redw[8];
+
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int slice = jb % NS;
+    const int pblock = (jb / NS) * 8 + xcd, pblocks = gridDim.x / NS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hi = lane >> 5;
+
+    const int64_t rounds_total = (V + 255) / 256;              // a round = 256 rows: every wave its own 32-row tile
+    if (pblock >= rounds_total) return;
+    const int64_t nrounds = (rounds_total - pblock + pblocks - 1) / pblocks;
+
+    // one scale for the block's weights: largest magnitude of its 128 rows of both matrices
+    float inv_sw, sw;
+    {
+        float mx = 0.f;
+        for (int idx = tid; idx < 2 * 128 * (3 * H / 4); idx += 512) {
+            const int mat = idx / (128 * (3 * H / 4)), rem = idx % (128 * (3 * H / 4));
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>((mat ? W_hh : W_ih) + (int64_t)(128 * slice) * 3 * H + 4 * rem);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fabsf(w4[u]));
+        }
+        mx = g_wave_max(mx);
+        if (lane == 0) redw[wv] = mx;
+        __syncthreads();
+        mx = redw[0];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) mx = fmaxf(mx, redw[u]);
+        g_guard_scale<30>(mx, sw, inv_sw);
+    }
+
+    // staging unit = (matrix, output row n, k-octet of the chunk): 1024 units, unit j of a thread belongs to matrix j
+    const float* wsrc[2];
+    int ldst[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = tid >> 2, o = tid & 3;
+        wsrc[j] = (j ? W_hh : W_ih) + (int64_t)(128 * slice + n) * 3 * H + 8 * o;
+        ldst[j] = j * 2 * IMGC + n * 64 + ((o ^ ((n >> 2) & 3)) << 4);
+    }
+    // chunk ct: gate blocks 0, 1 with both matrices, then block 2 as (dan, W_ih), then as (dnh, W_hh)
+    auto chunk_seg = [](int ct) { return ct < 2 * CPS ? ct / CPS : (ct < 3 * CPS ? 2 : 3); };
+    auto chunk_cc = [](int ct) { return ct % CPS; };
+    f32x4 raw[2][2];
+    auto stage_load = [&](int ct) {
+        const int seg = chunk_seg(ct);
+        const int off = (seg == 3 ? 2 : seg) * H + 32 * chunk_cc(ct);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (seg < 2 || seg - 2 == j) {
+                raw[j][0] = *reinterpret_cast<const f32x4*>(wsrc[j] + off);
+                raw[j][1] = *reinterpret_cast<const f32x4*>(wsrc[j] + off + 4);
+            }
+    };
+    auto stage_write = [&](int ct, int buf) {
+        const int seg = chunk_seg(ct);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (seg < 2 || seg - 2 == j) {
+                h16x8 ph, pl;
+                g_split8(raw[j][0], raw[j][1], sw, ph, pl);
+                char* base = smem + buf * BUF + ldst[j];
+                *reinterpret_cast<h16x8*>(base) = ph;
+                *reinterpret_cast<h16x8*>(base + IMGC) = pl;
+            }
+    };
+    auto bfrag = [&](int buf, int mat, int piece, int nb, int st) {
+        const int n = 32 * nb + r;
+        const int o = 2 * st + hi;
+        return *reinterpret_cast<const h16x8*>(smem + buf * BUF + (mat * 2 + piece) * IMGC + n * 64 + ((o ^ ((n >> 2) & 3)) << 4));
+    };
+    // this lane's two (hi, lo) fragment pairs of chunk ct for row tile `tile`
+    auto load_rows = [&](int64_t tile, int ct, h16x8 (&f)[4]) {
+        const char* p = pieces + tile * (int64_t)TILE_BYTES + (chunk_seg(ct) * (H / 16) + 2 * chunk_cc(ct)) * 2048 + r * 32 + hi * 16;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            f[2 * st] = *reinterpret_cast<const h16x8*>(p + st * 2048);
+            f[2 * st + 1] = *reinterpret_cast<const h16x8*>(p + st * 2048 + 1024);
+        }
+    };
+
+    f32x16 d_m[4], d_h[4];                                 // 32 rows x 128 features of dm and of dh per wave
+    h16x8 a0[4], a1[4];
+    int cur = 0;
+    int64_t tile = (int64_t)pblock * 8 + wv;
+    const int64_t tiles = (V + 31) / 32;
+
+    auto product = [&](f32x16 (&d)[4], int mat, int st, const h16x8& ah, const h16x8& al) {
+#pragma unroll
+        for (int nb = 0; nb < 4; nb += 2) {
+            const h16x8 w0h = bfrag(cur, mat, 0, nb, st), w0l = bfrag(cur, mat, 1, nb, st);
+            const h16x8 w1h = bfrag(cur, mat, 0, nb + 1, st), w1l = bfrag(cur, mat, 1, nb + 1, st);
+            d[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, w0h, d[nb], 0, 0, 0);
+            d[nb + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, w1h, d[nb + 1], 0, 0, 0);
+            d[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w0l, d[nb], 0, 0, 0);
+            d[nb + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w1l, d[nb + 1], 0, 0, 0);
+            d[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w0h, d[nb], 0, 0, 0);
+            d[nb + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w1h, d[nb + 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto chunk = [&](int ct, int64_t tile_next, h16x8 (&xa)[4], h16x8 (&na)[4]) {
+        __syncthreads();
+        const int cn = (ct + 1) % NCT;
+        stage_load(cn);
+        load_rows(cn == 0 ? tile_next : tile, cn, na);
+        __builtin_amdgcn_sched_barrier(0);
+        const int seg = chunk_seg(ct);                     // compile-time after unrolling? no: uniform, cheap branches
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            if (seg != 3) product(d_m, 0, st, xa[2 * st], xa[2 * st + 1]);
+            if (seg != 2) product(d_h, 1, st, xa[2 * st], xa[2 * st + 1]);
+        }
+        stage_write(cn, cur ^ 1);
+        cur ^= 1;
+    };
+
+    stage_load(0);
+    stage_write(0, 0);
+    if (tile >= tiles) tile = tiles - 1;                   // a wave past the end repeats the last tile and stores nothing
+    load_rows(tile, 0, a0);
+    for (int64_t rd = 0; rd < nrounds; ++rd) {
+        int64_t tile_next = rd + 1 < nrounds ? (int64_t)(pblock + (rd + 1) * pblocks) * 8 + wv : tile;
+        if (tile_next >= tiles) tile_next = tiles - 1;
+        const bool live_tile = (int64_t)(pblock + rd * pblocks) * 8 + wv < tiles;
+        const float un = inv_scale[tile] * inv_sw;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { d_m[nb][i] = 0.f; d_h[nb][i] = 0.f; }
+#pragma unroll 1
+        for (int ct = 0; ct < NCT; ct += 2) {
+            chunk(ct, tile_next, a0, a1);
+            chunk(ct + 1, tile_next, a1, a0);
+        }
+        if (live_tile) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const int fcol = 128 * slice + 32 * nb + r;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float prev[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        int64_t row = tile * 32 + 8 * g4 + 4 * hi + u;
+                        if (row >= V) row = V - 1;
+                        prev[u] = dh[row * H + fcol];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = 4 * g4 + u;
+                        const int64_t row = tile * 32 + 8 * g4 + 4 * hi + u;
+                        if (row < V) {
+                            dm[row * H + fcol] = d_m[nb][i] * un;
+                            dh[row * H + fcol] = d_h[nb][i] * un + prev[u];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        tile = tile_next;
+    }
+}
+
 // ----------------------------------------------------------------------------------------------------------- dW
 // H = 128: blockIdx.y = matrix: dW_ih = m^T [dar daz dan], dW_hh = h^T [dar daz dnh] (128 x 384 each = 4 x 12 tiles of
 //          32 x 32; wave = 2 a-tiles x 3 b-tiles); LDS images per buffer: three gate segments + X.
@@ -771,8 +954,8 @@ static int launch_gru_bwd_f16_t(const float* dout, const float* m, const float* 
     const int64_t tiles = (V + 31) / 32;
     char* pieces = (char*)workspace;
     float* inv_scale = (float*)(pieces + (size_t)tiles * (32 * 4 * H * 4));
-    // dm | dh: streamed weights, 64-column slices (H = 128: 3.85 ms on c4); MPNN_GRU128_SLICED_DX=1 selects the kernel
-    // with resident 32-column slices at H = 128 (4.06 ms)
+    // dm | dh: streamed weights, 128-column slices; MPNN_GRU_DX_SLICE64=1: 64-column slices (3.85 ms on c4);
+    // MPNN_GRU128_SLICED_DX=1: the kernel with resident 32-column slices at H = 128 (4.06 ms)
     const bool kSlicedDx = H == 128 && switches().gru128_sliced_dx;
     const size_t lds_sliced = (size_t)2 * 2 * 32 * (2 * 3 * GH), lds_stream = (size_t)2 * 4 * 64 * 128;
     const size_t lds_dx = kSlicedDx ? lds_sliced : lds_stream;
@@ -781,6 +964,7 @@ static int launch_gru_bwd_f16_t(const float* dout, const float* m, const float* 
         LdsOptIn opt_in_;
         if (H == 128) opt_in_((const void*)gru_bwd_dx128_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sliced);
         opt_in_((const void*)gru_bwd_dx_stream_f16_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_stream);
+        opt_in_((const void*)gru_bwd_dx_wide_f16_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64);
         opt_in_((const void*)gru_bwd_dw_f16_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dw);
         return opt_in_.err;
     }();
@@ -803,6 +987,14 @@ static int launch_gru_bwd_f16_t(const float* dout, const float* m, const float* 
         pblocks = (pblocks + 7) / 8 * 8;
         hipLaunchKernelGGL(gru_bwd_dx128_f16_kernel, dim3((unsigned)(pblocks * 4)), dim3(512), lds_dx, s, pieces, inv_scale,
                            W_ih, W_hh, dm, dh, V);
+    } else if (!switches().gru_dx_slice64) {               // default: 128-column slices (H=128: 10.3 vs 10.8 ms per backward)
+        constexpr int NS = H / 128;
+        const int64_t rounds = (V + 255) / 256;
+        int64_t pblocks = 256 / NS;
+        if (pblocks > rounds) pblocks = rounds;
+        pblocks = (pblocks + 7) / 8 * 8;
+        hipLaunchKernelGGL(gru_bwd_dx_wide_f16_kernel<H>, dim3((unsigned)(pblocks * NS)), dim3(512), (size_t)2 * 4 * 128 * 64, s,
+                           pieces, inv_scale, W_ih, W_hh, dm, dh, V);
     } else {
         constexpr int NS = H / 64;
         const int64_t rounds = (V + 255) / 256;
