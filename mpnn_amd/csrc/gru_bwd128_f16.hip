@@ -30,7 +30,6 @@ constexpr int GH = 128;
 constexpr int G_IMG = 32 * 256;                        // bytes of one [32 rows][128 x fp16] image
 constexpr int G_TILE_BYTES = 32 * 4 * GH * 4;          // one tile of the piece workspace: 64 KB
 
-__device__ __forceinline__ int g_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
 template <int SMAX>
 __device__ __forceinline__ void g_guard_scale(float maxabs, float& s, float& inv) {
@@ -71,7 +70,11 @@ __device__ __forceinline__ void g_barrier_lds() {
 __device__ __forceinline__ void g_copy_to_lds(const char* src, const char* lds_dst) {
     typedef __attribute__((address_space(3))) const char lds_char;
     const unsigned dst = (unsigned)(uintptr_t)(lds_char*)lds_dst;
-    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
+    unsigned keep;                                         // m0 is a reserved register: put back what was there
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(dst)
+                 : "memory");
 }
 
 __device__ __forceinline__ h16x8 g_tr8(const char* a0, const char* a1) {
