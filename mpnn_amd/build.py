@@ -4,8 +4,15 @@
 
 hipcc cross-compiles without a GPU, so this runs in the build container; the resulting
 .so travels to the GPU box with the source snapshot.
+
+An object is rebuilt when its source or any header is newer, or when it was compiled with other flags
+(MPNN_EXTRA_HIPCC_FLAGS: the hash of the flag list sits next to every object).  Objects and the library are written
+to a per-process temporary name and renamed into place, and the whole build holds a file lock, so several ranks
+that find the library missing at start-up build it once instead of over each other.
 """
+import fcntl
 import glob
+import hashlib
 import os
 import shutil
 import subprocess
@@ -18,26 +25,60 @@ LIB = os.path.join(LIBDIR, "libmpnn_amd.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
          "-fno-fast-math"] + os.environ.get("MPNN_EXTRA_HIPCC_FLAGS", "").split()
+FLAGS_HASH = hashlib.sha256(" ".join(FLAGS).encode()).hexdigest()[:16]
 
 
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def _headers():
+    return glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "mpnn_amd.h")]
+
+
+def _obj_of(src):
+    return os.path.join(LIBDIR, "obj", os.path.basename(src)[:-4] + ".o")
+
+
+def _obj_stale(src, t_hdr):
+    obj = _obj_of(src)
+    if not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), t_hdr):
+        return True
+    try:
+        with open(obj + ".flags") as f:
+            return f.read().strip() != FLAGS_HASH
+    except OSError:
+        return True
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "mpnn_amd.h")]
-    return any(os.path.getmtime(p) > t for p in deps)
+    if any(os.path.getmtime(p) > t for p in sources() + _headers()):
+        return True
+    # a library without objects (a snapshot on the GPU box carries only the .so) is taken as it is
+    objs = [_obj_of(s) for s in sources()]
+    if not any(os.path.exists(o) for o in objs):
+        return False
+    t_hdr = max(os.path.getmtime(p) for p in _headers())
+    return any(_obj_stale(s, t_hdr) for s in sources())
 
 
 def _compile_one(job):
     hipcc, src, obj, verbose = job
-    cmd = [hipcc] + [f for f in FLAGS if f != "-shared"] + ["-c", src, "-o", obj]
+    tmp = "%s.%d.tmp" % (obj, os.getpid())
+    cmd = [hipcc] + [f for f in FLAGS if f != "-shared"] + ["-c", src, "-o", tmp]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode == 0:
+        os.replace(tmp, obj)
+        with open(obj + ".flags.tmp%d" % os.getpid(), "w") as f:
+            f.write(FLAGS_HASH + "\n")
+        os.replace(obj + ".flags.tmp%d" % os.getpid(), obj + ".flags")
+    elif os.path.exists(tmp):
+        os.remove(tmp)
     return src, r.returncode, r.stdout + r.stderr
 
 
@@ -49,32 +90,33 @@ def build(force=False, verbose=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libmpnn_amd.so (and there is no CPU fallback)")
-    os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(LIBDIR, "obj")
-    os.makedirs(objdir, exist_ok=True)
-    headers = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "mpnn_amd.h")]
-    t_hdr = max(os.path.getmtime(p) for p in headers)
-    jobs, objs = [], []
-    for src in sources():
-        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
-        objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), t_hdr):
-            jobs.append((hipcc, src, obj, verbose))
-    if jobs:
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=min(len(jobs), int(os.environ.get("MPNN_BUILD_JOBS", "6")))) as ex:
-            for src, rc, log in ex.map(_compile_one, jobs):
-                if rc != 0:
-                    sys.stderr.write(log)
-                    raise RuntimeError("hipcc failed on %s" % src)
-                if verbose and log:
-                    sys.stderr.write(log)
-    tmp = LIB + ".tmp"
-    r = subprocess.run([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", tmp] + objs, capture_output=True, text=True)
-    if r.returncode != 0:
-        sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError("hipcc failed linking libmpnn_amd.so")
-    os.replace(tmp, LIB)
+    os.makedirs(os.path.join(LIBDIR, "obj"), exist_ok=True)
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not _stale():                    # another process built it while this one waited
+            return LIB
+        t_hdr = max(os.path.getmtime(p) for p in _headers())
+        jobs, objs = [], []
+        for src in sources():
+            objs.append(_obj_of(src))
+            if force or _obj_stale(src, t_hdr):
+                jobs.append((hipcc, src, _obj_of(src), verbose))
+        if jobs:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(len(jobs), int(os.environ.get("MPNN_BUILD_JOBS", "6")))) as ex:
+                for src, rc, log in ex.map(_compile_one, jobs):
+                    if rc != 0:
+                        sys.stderr.write(log)
+                        raise RuntimeError("hipcc failed on %s" % src)
+                    if verbose and log:
+                        sys.stderr.write(log)
+        tmp = "%s.%d.tmp" % (LIB, os.getpid())
+        r = subprocess.run([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", tmp] + objs, capture_output=True,
+                           text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError("hipcc failed linking libmpnn_amd.so")
+        os.replace(tmp, LIB)
     return LIB
 
 

@@ -58,7 +58,7 @@ __device__ __forceinline__ void g_split8(const f32x4& x0, const f32x4& x1, float
 
 // Block barrier that orders LDS traffic only.  __syncthreads() carries a workgroup fence over ALL address spaces, which
 // makes the compiler drain every outstanding global_load_lds copy (vmcnt(0)) -- the copies issued two tiles ahead are
-// waited for explicitly (s_waitcnt vmcnt(6)) where their buffer is needed.
+// waited for explicitly (s_waitcnt vmcnt(0), in body() where the buffers change hands) where their buffer is needed.
 __device__ __forceinline__ void g_barrier_lds() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
@@ -71,7 +71,9 @@ __device__ __forceinline__ void g_copy_to_lds(const char* src, const char* lds_d
     typedef __attribute__((address_space(3))) const char lds_char;
     const unsigned dst = (unsigned)(uintptr_t)(lds_char*)lds_dst;
     unsigned keep;                                         // m0 is a reserved register: put back what was there
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+    // s_nop 0: one wait state between the SALU write of M0 and the LDS-DMA that reads it (the compiler pads nothing
+    // inside an asm statement)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(src), "s"(dst)
                  : "memory");

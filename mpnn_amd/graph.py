@@ -87,7 +87,7 @@ class TilePlan:
         src = g.col_idx.to(torch.int64)
         et = g.edge_type.to(torch.int64)
         src_local = src - tp64[tile_of_atom[dst]]
-        if E and (int(src_local.min()) < 0 or int(src_local.max()) >= tv):
+        if E and bool((tile_of_atom[src] != tile_of_atom[dst]).any().item()):
             return None                                   # an edge leaves its tile: not a batch of separate molecules
         # ---- per-atom in-degree by type, and the sort of every tile's atoms by that pattern (high counts first)
         cnt = torch.bincount(dst * K + et, minlength=V * K).view(V, K)

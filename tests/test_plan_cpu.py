@@ -82,3 +82,29 @@ def test_plan_refuses_what_the_kernel_cannot_do():
     assert MolGraph.from_molbatch(big, torch.device("cpu")).tile_plan is None
     many = synth.make_molecules(20, 4, seed=6, edge_features=7)      # 7 bond types: more matrices than fit in LDS
     assert MolGraph.from_molbatch(many, torch.device("cpu")).tile_plan is None
+
+
+def test_plan_refuses_an_edge_into_the_next_tile():
+    """Two molecules of 100 atoms sit in two tiles (100 + 100 > 128).  One bond from the last atom of the first to the
+    first atom of the second stays within 128 rows of the destination's tile start, yet leaves the tile: the plan must
+    refuse (the ops then take the edge_message + segsum path) instead of gathering a row the tile does not hold."""
+    import numpy as np
+    n = 100
+    src, dst = [], []
+    for base in (0, n):
+        for i in range(n - 1):                                  # a chain per molecule, both directions
+            src += [base + i, base + i + 1]
+            dst += [base + i + 1, base + i]
+    def graph(extra):
+        s, d = np.array(src + [e[0] for e in extra]), np.array(dst + [e[1] for e in extra])
+        o = np.lexsort((s, d))
+        s, d = s[o], d[o]
+        row_ptr = np.zeros(2 * n + 1, np.int64)
+        np.add.at(row_ptr, d + 1, 1)
+        row_ptr = np.cumsum(row_ptr)
+        t = lambda a, dt: torch.from_numpy(np.asarray(a)).to(dt)
+        return MolGraph(t(row_ptr, torch.int32), t(s, torch.int32), None, torch.zeros(len(s), dtype=torch.int32),
+                        torch.eye(1, 4), t([0, n, 2 * n], torch.int32))
+    assert graph([]).tile_plan is not None
+    # destination = last atom of tile 0, source = atom 105: 105 - 0 < 128 passes a start-relative bound
+    assert graph([(n + 5, n - 1), (n - 1, n + 5)]).tile_plan is None
