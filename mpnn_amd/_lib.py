@@ -13,50 +13,41 @@ from . import build as _build
 
 _HEADER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", "mpnn_amd.h")
 
-c_f = ctypes.c_void_p     # const float* / float*
-c_i = ctypes.c_void_p     # const int32_t* / int32_t*
-c_v = ctypes.c_void_p
-i64 = ctypes.c_int64
-i32 = ctypes.c_int
-usz = ctypes.c_size_t
+_SCALARS = {"int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "size_t": ctypes.c_size_t,
+            "float": ctypes.c_float, "double": ctypes.c_double}
 
-_SIGNATURES = {
-    "mpnn_version": (ctypes.c_int, []),
-    "mpnn_last_error_string": (ctypes.c_char_p, []),
-    "mpnn_init": (ctypes.c_int, []),
-    "mpnn_csr_workspace_bytes": (usz, [i64]),
-    "mpnn_csr_count": (ctypes.c_int, [c_f, c_f, i64, i32, i32, c_i, c_v, usz, c_v]),
-    "mpnn_csr_fill": (ctypes.c_int, [c_f, c_f, i64, i32, i32, c_i, c_i, c_f, c_f, c_v]),
-    "mpnn_edge_message_f32": (ctypes.c_int, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, i64, i64, i32, i32, i32, c_v]),
-    "mpnn_edge_message_bwd_f32": (ctypes.c_int, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f,
-                                                 i64, i64, i32, i32, i32, c_v]),
-    "mpnn_edge_message_agg_bwd_da_f32": (ctypes.c_int, [c_f, c_f, c_i, c_i, c_f, c_i, c_i, c_f, c_f,
-                                                        i64, i64, i32, i32, i32, c_v]),
-    "mpnn_edge_message_agg_bwd_dgate_f32": (ctypes.c_int, [c_f, c_f, c_f, c_i, c_i, c_f, c_i, c_i, c_f,
-                                                           i64, i64, i32, i32, i32, c_v]),
-    "mpnn_att_gate_f32": (ctypes.c_int, [c_f, c_f, c_i, c_i, c_f, i64, i64, i32, i32, c_v]),
-    "mpnn_att_gate_bwd_f32": (ctypes.c_int, [c_f, c_f, c_i, c_i, c_f, c_f, i64, i64, i32, i32, c_v]),
-    "mpnn_tower_chain_f32": (ctypes.c_int, [c_f, c_f, c_f, i32, i32, i32, c_v]),
-    "mpnn_tower_chain_bwd_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, i32, i32, i32, c_v]),
-    "mpnn_masked_bn_workspace_bytes": (usz, [i32]),
-    "mpnn_masked_bn_fwd_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, ctypes.c_float, i32,
-                                              c_v, usz, c_v]),
-    "mpnn_masked_bn_bwd_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, ctypes.c_float,
-                                              i32, c_f, c_v, usz, c_v]),
-    "mpnn_plan_tiles_host": (i64, [c_v, i64, i32, c_v]),
-    "mpnn_message_aggregate_tile_atoms": (ctypes.c_int, []),
-    "mpnn_message_aggregate_max_types": (ctypes.c_int, []),
-    "mpnn_message_aggregate_max_row_tiles": (ctypes.c_int, []),
-    "mpnn_message_aggregate_f32": (ctypes.c_int, [c_f, c_f, c_i, c_i, c_i, c_f, i64, i64, i32, i32, i32, c_v]),
-    "mpnn_message_aggregate_bwd_da_f32": (ctypes.c_int, [c_f, c_f, c_i, c_i, c_i, c_i, c_f, i64, i64, i32, i32, i32, c_v]),
-    "mpnn_bilinear_message_f32": (ctypes.c_int, [c_f, c_f, c_f, i64, i32, i32, c_v]),
-    "mpnn_segsum_f32": (ctypes.c_int, [c_f, c_i, c_f, c_f, i64, i32, c_v]),
-    "mpnn_segsum_bwd_f32": (ctypes.c_int, [c_f, c_i, c_f, c_f, i64, i32, c_v]),
-    "mpnn_segsum_gather_f32": (ctypes.c_int, [c_f, c_i, c_i, c_f, c_f, i64, i32, c_v]),
-    "mpnn_gru_update_f32": (ctypes.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, c_v]),
-    "mpnn_gru_bwd_workspace_bytes": (usz, [i64, i32]),
-    "mpnn_gru_update_bwd_f32": (ctypes.c_int, [c_f] * 7 + [c_f] * 6 + [c_v, usz, i64, i32, c_v]),
-}
+
+def _ctype(decl, is_return=False):
+    """ctypes type of one C declaration of the header ("const float* h", "int64_t V", "void* stream" ...)."""
+    decl = decl.strip()
+    if "*" in decl:
+        if is_return and re.match(r"const\s+char\s*\*", decl):
+            return ctypes.c_char_p
+        return ctypes.c_void_p                         # every pointer argument: a device (or host) address
+    words = [w for w in re.split(r"\s+", decl) if w not in ("const", "unsigned")]
+    base = words[0]
+    if base not in _SCALARS:
+        raise RuntimeError("include/mpnn_amd.h: no ctypes mapping for %r" % decl)
+    return _SCALARS[base]
+
+
+def header_signatures():
+    """{name: (restype, [argtypes])} of every prototype in include/mpnn_amd.h -- the header is the single statement of
+    the ABI; the binding is derived from it, so an argument added, removed or retyped there cannot drift here."""
+    with open(_HEADER) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    text = re.sub(r"^\s*#[^\n]*", " ", text, flags=re.M)          # preprocessor lines
+    text = re.sub(r'extern\s+"C"\s*\{', " ", text)
+    sigs = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(mpnn_[a-z0-9_]+)\s*\(([^()]*)\)\s*;", text):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        ret = re.sub(r"\b(extern|static|inline)\b", " ", ret).strip()
+        argtypes = [] if args in ("", "void") else [_ctype(a) for a in args.split(",")]
+        sigs[name] = (_ctype(ret, is_return=True), argtypes)
+    return sigs
+
 
 _lib = None
 
@@ -67,9 +58,7 @@ class MpnnError(RuntimeError):
 
 def declared_symbols():
     """Every function name include/mpnn_amd.h declares (used by the CPU-side export test)."""
-    with open(_HEADER) as f:
-        text = f.read()
-    return sorted(set(re.findall(r"\b(mpnn_[a-z0-9_]+)\s*\(", text)))
+    return sorted(header_signatures())
 
 
 def library_path():
@@ -85,7 +74,7 @@ def load():
     if not os.path.exists(path):
         path = _build.build()          # raises when hipcc is absent
     lib = ctypes.CDLL(path)
-    for name, (res, args) in _SIGNATURES.items():
+    for name, (res, args) in header_signatures().items():
         fn = getattr(lib, name)        # AttributeError => the .so is out of date: fail loudly
         fn.restype = res
         fn.argtypes = args

@@ -89,6 +89,12 @@ def load_reference():
     R.lipo_basic_model = _load("ref_lipo_basic_model", "models/lipo_basic_model.py")
     R.graph_model_wrapper = _load("ref_graph_model_wrapper", "models/graph_model_wrapper.py")
     R.graph_norm_wrapper = _load("ref_graph_norm_wrapper", "models/graph_norm_wrapper.py")
+    # models/att_model.py:3-4 does `from mpnn_functions import *` (its constructor's default readout is the name
+    # Set2Vec, whose module needs rdkit) and `from batch_norm_graph_wrapper import MaskBatchNorm`
+    pkg.Set2Vec = R.GraphLevelOutput                  # placeholder for the default argument only: never constructed
+    pkg.__all__.append("Set2Vec")
+    _load("batch_norm_graph_wrapper", "models/batch_norm_graph_wrapper.py")
+    R.att_model = _load("ref_att_model", "models/att_model.py")
     return R
 
 
@@ -394,6 +400,33 @@ def fx_models(R):
              {"": out, "node_state": node_state, "state1": states[0]})
 
 
+def fx_att_models(R):
+    """(3) the configuration-3 model, models/att_model.py:55-59: one AttEdgeNetwork per step, AdjMsgAgg, GRU, the
+    parameter-free MaskBatchNorm, readout on cat[state, afm].  Its stock forward raises at HEAD (AttEdgeNetwork wants
+    the legacy 5-D edge_embed, att_edge_network.py:31, which _precompute_edge_embed no longer produces), so the loop
+    is driven with the model's own sub-modules mfs[i], ma, uf, bn, of -- each mf with its edge_embed set from its own
+    edge_map in the legacy layout and asked to reuse it, exactly as fx_att_edge_network does for the operator."""
+    for tag, H, ef, T, seed in (("h8_T3", 8, 4, 3, 111), ("h22_T5", 22, 7, 5, 112)):
+        torch.manual_seed(seed)
+        afm, bfm, adj, mask = ragged_batch(H, ef, seed)
+        B, N = afm.shape[:2]
+        am = R.att_model.BasicModel(H, ef, H, N, 6, message_opts={}, agg_opts={}, update_opts={},
+                                    readout_func=R.GraphLevelOutput, readout_opts={}, message_steps=T)
+        randomise(am, seed)
+        am.train()
+        afm.requires_grad_(True)
+        node_state = afm
+        states = []
+        for mf in am.mfs:
+            mf.edge_embed = mf.edge_map(bfm.view(-1, ef)).view(B, N, N, H, H)
+            pair = mf(afm, bfm, reuse_graph_tensors=True)
+            node_state = am.bn(am.uf(am.ma(pair, adj), node_state, mask), mask)
+            states.append(node_state)
+        out = am.of(torch.cat([node_state, afm], dim=-1), mask=mask)
+        save("model_att_" + tag, {"afm": afm, "bfm": bfm, "adj": adj, "mask": mask}, am,
+             {"": out, "node_state": node_state, "state1": states[0]})
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("reference not found at %s: golden vectors can only be regenerated in the build "
@@ -401,7 +434,7 @@ def main():
     torch.set_num_threads(1)
     R = load_reference()
     for fx in (fx_csr, fx_edge_network, fx_att_edge_network, fx_ggnn, fx_bilinear, fx_aggregators,
-               fx_gru, fx_mask_bn, fx_readout, fx_models):
+               fx_gru, fx_mask_bn, fx_readout, fx_models, fx_att_models):
         fx(R)
 
 

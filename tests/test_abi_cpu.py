@@ -16,8 +16,27 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 13
     for n in names:
         assert hasattr(lib, n), "libmpnn_amd.so lacks %s declared in include/mpnn_amd.h" % n
-    assert set(_lib._SIGNATURES) == set(names)
     assert _lib.load().mpnn_version() >= 100
+
+
+def test_binding_is_derived_from_the_header():
+    """The ctypes prototypes come from include/mpnn_amd.h itself (no second, hand-kept table): every pointer is an
+    address, scalars keep their C width, and the kernel entry points end with the stream."""
+    sigs = _lib.header_signatures()
+    assert len(sigs) >= 30
+    assert sigs["mpnn_last_error_string"] == (ctypes.c_char_p, [])
+    assert sigs["mpnn_csr_workspace_bytes"] == (ctypes.c_size_t, [ctypes.c_int64])
+    res, args = sigs["mpnn_segsum_f32"]                      # (msg, row_ptr, w, out, int64 rows, int F, stream)
+    assert res is ctypes.c_int and args == [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+    res, args = sigs["mpnn_masked_bn_fwd_f32"]
+    assert args.count(ctypes.c_float) == 1 and args[-3:] == [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    for name, (res, args) in sigs.items():
+        if name.endswith("_f32"):
+            assert res is ctypes.c_int and args[-1] is ctypes.c_void_p, name
+    lib = _lib.load()
+    for name, (res, args) in sigs.items():                   # what the loaded functions were given
+        fn = getattr(lib, name)
+        assert fn.restype is res and list(fn.argtypes) == args, name
 
 
 def test_no_cpu_fallback():

@@ -142,6 +142,24 @@ def test_basic_model(tag):
     _grad_check(out, f.cot, {"afm": afm}, {"afm": f.gin["afm"]})
 
 
+@pytest.mark.parametrize("tag,T", [("h8_T3", 3), ("h22_T5", 5)])
+def test_att_model(tag, T):
+    """The configuration-3 model (models/att_model.py:55-59) as the real reference modules compute it."""
+    f = Fixture("model_att_" + tag)
+    afm = _leaf(f.inputs["afm"])
+    p = {k: _leaf(v) for k, v in f.params.items()}
+    alias = str(f.raw["alias"])
+    for item in filter(None, alias.split(";")):
+        k, first = item.split("=")
+        p[k] = p[first]
+    out, h = O.att_model_forward(p, afm, f.inputs["bfm"], f.inputs["adj"], f.inputs["mask"], T, True)
+    assert max_err(h, f.out["node_state"]) < 1e-5          # T chained parameter-free norms
+    assert max_err(out, f.out[""]) < 1e-5
+    leaves = {"afm": afm}
+    leaves.update({k: v for k, v in p.items() if k in f.gp})
+    _grad_check(out, f.cot, leaves, dict(afm=f.gin["afm"], **f.gp), tol=5e-5)
+
+
 @pytest.mark.parametrize("T", [3, 6])
 @pytest.mark.parametrize("mode", ["train", "eval"])
 def test_lipo_model(T, mode):
