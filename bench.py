@@ -69,6 +69,8 @@ def parse():
                     help="strong = one global set of %d x the workload's molecules sharded over the ranks" % STRONG_CHUNKS)
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="budget of the CPU baseline leg (2/3 training, 1/3 forward)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-side", action="store_true",
+                    help="skip the side measurements that start child processes (the fp32-pipe step time)")
     return ap.parse_args()
 
 
@@ -107,7 +109,7 @@ def pmc_traffic(workload, kernel_substr):
     tools/pmc_summary.py are the only writers).  PMC collection needs the profiler, so it cannot happen inside this
     process; the figure is a property of (kernel, workload) and is reported with its source file, that file's hash and
     the commit it was measured at, so a stale figure is visible.  (None, None) when no pass exists."""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(REPO, "profiles", "%s_pmc_%s.json" % (rnd, workload))
         try:
             with open(path, "rb") as f:
@@ -145,7 +147,9 @@ def usable_cores():
             break
         except (OSError, ValueError, IndexError):
             continue
-    return min(n, int(os.environ.get("MPNN_CPU_THREADS", "16")))   # the GPU box's CPU share per GPU is 16
+    if os.environ.get("MPNN_CPU_THREADS"):                 # explicit override only; default = every core this process may use
+        n = min(n, int(os.environ["MPNN_CPU_THREADS"]))
+    return n
 
 
 def cpu_baseline_leg(mb, hidden, steps, mode, budget_s, first_batch=0):
@@ -200,13 +204,15 @@ def cpu_baseline_leg(mb, hidden, steps, mode, budget_s, first_batch=0):
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    return {"value": edges / dt, "unit": "edges/s", "cores": cores, "kind": "port", "sample_molecules": nmol,
-            "sample_seconds": dt,
+    return {"value": edges / dt, "unit": "edges/s", "cores": cores, "host_cpu_count": os.cpu_count(), "kind": "port",
+            "sample_molecules": nmol, "sample_seconds": dt,
+            "extrapolated_seconds_for_2k_molecules": dt * 2000.0 / max(nmol, 1),
             "sample": "%d molecules (%d batches of 16, the reference's batch size) of the same synthetic set%s, dense "
-                      "padded torch-CPU path, %s, %.1f s -- a time-budgeted sample (SURVEY 8d's 2k-molecule subsample "
-                      "would take minutes of CPU)"
+                      "padded torch-CPU path, %s, %.1f s on %d threads (os.cpu_count() = %s) -- a time-budgeted sample; "
+                      "SURVEY 8d's 2k-molecule subsample would take %.0f s at this rate"
                       % (nmol, nb, " (%d molecules too large for the dense path left out)" % dropped if dropped else "",
-                         "forward+backward" if mode == "train" else "forward", dt)}
+                         "forward+backward" if mode == "train" else "forward", dt, cores, os.cpu_count(),
+                         dt * 2000.0 / max(nmol, 1))}
 
 
 def cpu_baseline(mb, hidden, steps, mode, budget_s):
@@ -215,7 +221,8 @@ def cpu_baseline(mb, hidden, steps, mode, budget_s):
     if mode != "train":
         return fwd
     out = cpu_baseline_leg(mb, hidden, steps, "train", budget_s * 2.0 / 3.0)
-    out["forward"] = {k: fwd[k] for k in ("value", "unit", "sample_molecules", "sample_seconds")}
+    out["forward"] = {k: fwd[k] for k in ("value", "unit", "sample_molecules", "sample_seconds",
+                                          "extrapolated_seconds_for_2k_molecules")}
     return out
 
 
@@ -366,11 +373,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(step, timer):
-        """W untimed steps, then exactly K steps between barrier+synchronize fences; max over ranks."""
+    def timed(step):
+        """W untimed steps, then exactly K steps between barrier+synchronize fences; max over ranks.  Nothing but
+        the steps runs in the timed region (the per-kernel HIP events are a separate pass: kernel_pass)."""
         for _ in range(args.warmup):
             step()
-        ops.set_kernel_timer(timer)
         del ar_events[:]
         fence()
         t0 = time.perf_counter()
@@ -378,11 +385,21 @@ def main():
             step()
         fence()
         dt = time.perf_counter() - t0
-        ops.set_kernel_timer(None)
         t_max = torch.tensor([dt], device=dev, dtype=torch.float64)
         if dist is not None:
             dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         return float(t_max.item())
+
+    def kernel_pass(step, timer):
+        """The same steps once more with two HIP events around every hot-path launch, on the launch stream
+        (ops.KernelTimer): per-kernel average durations for the roofline lines, outside the headline's clock."""
+        ops.set_kernel_timer(timer)
+        saved = list(ar_events)
+        for _ in range(min(args.steps, 5)):
+            step()
+        torch.cuda.synchronize()
+        ops.set_kernel_timer(None)
+        ar_events[:] = saved
 
     def gather_stat(x):
         t = torch.zeros(world, device=dev, dtype=torch.float64)
@@ -397,15 +414,16 @@ def main():
     timer = ops.KernelTimer(["message_aggregate", "segsum", "edge_message", "gru_update", "gru_update_bwd",
                              "message_aggregate_bwd"])
     if args.mode == "train":
-        dt_fwd = timed(step_fwd, None)
-        dt = timed(step_train, timer)
+        dt_fwd = timed(step_fwd)
+        dt = timed(step_train)
     else:
         dt_fwd = None
-        dt = timed(step_fwd, timer)
+        dt = timed(step_fwd)
     ar_ms = None
     if ar_events:
         ar_ms = (sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events) if not isinstance(ar_events[0], float)
                  else 1e3 * sum(ar_events) / len(ar_events))
+    kernel_pass(step_train if args.mode == "train" else step_fwd, timer)
 
     batch16 = None
     if args.workload == "c1" and world == 1:
@@ -430,13 +448,53 @@ def main():
                 state, _ = model.message_passing(a, gs, gs, mk)
                 (state.sum() / 16).backward()
 
-        batch16 = (timed(epoch_fwd, None), timed(epoch_train, None))
+        batch16 = (timed(epoch_fwd), timed(epoch_train))
 
     hoisted = None
     if world == 1 and hasattr(model, "hoist_message"):
         model.hoist_message = True
-        hoisted = (timed(step_fwd, None), timed(step_train, None) if args.mode == "train" else float("nan"))
+        hoisted = (timed(step_fwd), timed(step_train) if args.mode == "train" else float("nan"))
         model.hoist_message = False
+
+    cold = None
+    if world == 1 and args.scaling == "weak":
+        # what a training loop that sees a NEW batch every step would pay on top of the resident-batch step time:
+        # upload of the compact batch + CSR-derived index arrays, and the tile plan of the fused message+sum kernel
+        def clock(fn):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = fn()
+            torch.cuda.synchronize()
+            return r, (time.perf_counter() - t0) * 1e3
+        g2, up_ms = clock(lambda: MolGraph.from_molbatch(mb, dev))
+        _, idx_ms = clock(lambda: g2.prepare(tile_plan=False))
+        _, plan_ms = clock(lambda: g2.tile_plan) if graph._tile_plan else (None, 0.0)
+        cold = {"upload_ms": up_ms, "index_arrays_ms": idx_ms, "tile_plan_ms": plan_ms,
+                "total_ms": up_ms + idx_ms + plan_ms,
+                "note": "per NEW batch, outside the timed steps (the headline keeps its batch resident in HBM): host -> "
+                        "device copy of the compact batch, type order / transposed graph / destination list, and the "
+                        "tile plan when the fused message+sum kernel runs"}
+        del g2
+
+    fp32_pipe = None
+    if world == 1 and rank == 0 and not args.no_side and ops.math_mode() != "fp32":
+        # the same step with every contraction on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32, MPNN_GRU_MATH=fp32): what
+        # the split arithmetic of the default path buys.  A child process (the switch is read once per process).
+        torch.cuda.empty_cache()
+        env = dict(os.environ, MPNN_GRU_MATH="fp32")
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--steps", str(min(args.steps, 5)),
+               "--warmup", "1", "--mode", args.mode, "--no-cpu", "--no-side"]
+        try:
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+            cj = json.loads(line)
+            fp32_pipe = {"ms_per_step": cj["ms_per_step"], "value": cj["value"], "unit": cj["unit"],
+                         "forward_ms_per_step": (cj.get("forward") or {}).get("ms_per_step"),
+                         "kernels_ms": cj.get("kernels_ms"),
+                         "note": "same workload and mode with MPNN_GRU_MATH=fp32 (strict fp32 MFMA, no operand splits), "
+                                 "child process, %d steps" % min(args.steps, 5)}
+        except Exception as e:                            # a side figure must not take the headline down
+            fp32_pipe = {"error": repr(e)[:200]}
 
     if rank == 0:
         F = hidden
@@ -489,6 +547,7 @@ def main():
             "kernels_ms": {k: timer.mean_ms(k) for k in sorted(timer.names)},
         }
         if min_bytes is not None:
+            out["roofline"]["frac_on_bytes_moved"] = min_bytes / (agg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             out["roofline"]["min_traffic"] = {
                 "formula": "4*nf*V + 4*mf*V + tile-plan words (h rows and out rows once each; gathers served from the LDS tile)",
                 "bytes": min_bytes, "GB/s": min_bytes / (agg_ms * 1e-3) / 1e9, "frac_of_peak": min_bytes / (agg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -551,6 +610,10 @@ def main():
                 "forward_edges_per_s": total_edges * T * args.steps / batch16[0],
                 "note": "same molecules stepped through as 64 batches of 16 (the reference driver's batch size); "
                         "one optimizer-sized step per batch, ~60 kernel launches each"}
+        if cold is not None:
+            out["cold_batch"] = cold
+        if fp32_pipe is not None:
+            out["fp32_pipe"] = fp32_pipe
         if hoisted is not None:
             out["hoisted_message"] = {
                 "train_ms_per_step": hoisted[1] / args.steps * 1e3, "forward_ms_per_step": hoisted[0] / args.steps * 1e3,
