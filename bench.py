@@ -316,7 +316,7 @@ def main():
         batches = [(torch.from_numpy(mb.atom_feat).to(dev), g, torch.ones(mb.num_atoms, 1, device=dev))]
         local_mols = mols
     for _, g, _ in batches:                              # index arrays built once, outside the timed region
-        g.prepare(tile_plan=(hidden == 64))
+        g.prepare(tile_plan=(hidden == 64), wide_plan=(hidden in (128, 256)))
     afm, graph, mask = batches[0]
     V = sum(g.num_nodes for _, g, _ in batches)
     E = sum(g.num_edges for _, g, _ in batches)
@@ -468,7 +468,8 @@ def main():
             return r, (time.perf_counter() - t0) * 1e3
         g2, up_ms = clock(lambda: MolGraph.from_molbatch(mb, dev))
         _, idx_ms = clock(lambda: g2.prepare(tile_plan=False))
-        _, plan_ms = clock(lambda: g2.tile_plan) if graph._tile_plan else (None, 0.0)
+        _, plan_ms = (clock(lambda: g2.tile_plan) if graph._tile_plan else
+                      clock(lambda: g2.wide_plan) if graph._wide_plan else (None, 0.0))
         cold = {"upload_ms": up_ms, "index_arrays_ms": idx_ms, "tile_plan_ms": plan_ms,
                 "total_ms": up_ms + idx_ms + plan_ms,
                 "note": "per NEW batch, outside the timed steps (the headline keeps its batch resident in HBM): host -> "
@@ -512,7 +513,10 @@ def main():
             # reported beside it as `min_traffic`, the figure to hold PMC `traffic` against.
             alg_bytes = 4.0 * F * Eb + 4.0 * Eb + 4.0 * (Vb + 1) + 4.0 * F * Vb
             min_bytes = 4.0 * F * Vb + 4.0 * F * Vb + float(graph.plan_bytes())
-            agg_ms, kname, ksub = fused_ms, "message_sum_tile_kernel (fused typed message + neighbour sum, mpnn_message_aggregate_f32)", "message_sum_tile"
+            if F == 64:
+                agg_ms, kname, ksub = fused_ms, "message_sum_tile_kernel (fused typed message + neighbour sum, mpnn_message_aggregate_f32)", "message_sum_tile"
+            else:
+                agg_ms, kname, ksub = fused_ms, "message_sum_wide_kernel (fused typed message + neighbour sum, aggregate-then-contract, mpnn_message_aggregate_wide_f32)", "message_sum_wide"
             formula = "SURVEY 8(d) fused-gather: 4*nf*E + 4*E + 4*(V+1) + 4*mf*V"
         else:
             alg_bytes = 4.0 * F * (Eb + Vb) + 4.0 * (Vb + 1) + (4.0 * Eb if weighted else 0.0)

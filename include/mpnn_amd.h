@@ -159,7 +159,35 @@ int mpnn_message_aggregate_f32(const float* h, const float* A, const int32_t* ti
                                int64_t V, int64_t num_tiles, int K, int nf, int mf, void* stream);
 
 /*
- * Weight gradient of the above, on the same tile plan and with dagg and h each read once:
+ * The same fused product at nf = mf in {128, 256} (and 64) for molecules of up to
+ * mpnn_message_aggregate_wide_tile_atoms() = 256 atoms: typed aggregate-then-contract,
+ *   out[i, :] = sum_k A[k] . S_k[i],   S_k[i] = sum_{e in row i, type(e) = k} h[src[e], :]
+ * replaces: mpnn_functions/message/edge_network.py:50-51 (edge_embed.bmm(...)), i.e. :40,52 composed with
+ *           mpnn_functions/message_aggregators/adjacent_message_agg.py:18, where neither the K matrices nor a tile's
+ *           h rows fit in LDS.  The h rows are read once and the out rows written once; no (E, mf) tensor exists.
+ * Work list (built once per batch, mpnn_amd/graph.py::WidePlan): molecule-aligned tiles of <= 256 atoms, their atoms
+ * sorted by bond-type pattern into blocks of 32 (one wave each);
+ *   tile_rec[T,4]     first atom, atoms, first slot row, slot rows (<= mpnn_message_aggregate_wide_max_rows())
+ *   tile_atom[T,256]  atom id of (block, row), -1 = none
+ *   blk_off[T,8K+1]   first slot row of every (block, type), relative to the tile's first; then the tile's count
+ *   slots[32 R]       16-bit words, row (block, type, rank): word m = source row of the rank-th type-k neighbour of the
+ *                     block's atom m, relative to the tile's first atom; 256 = none
+ * `workspace` (mpnn_message_aggregate_wide_workspace_bytes(K, nf) bytes) receives the K matrices as fp16 pieces in the
+ * kernel's chunk order on every call.  K <= mpnn_message_aggregate_wide_max_types(), unit edge weights, no gate
+ * (callers run mpnn_edge_message_f32 + mpnn_segsum_f32 otherwise).  Sum order inside an output row: types ascending,
+ * within a type the edge order -- deterministic.
+ */
+int mpnn_message_aggregate_wide_tile_atoms(void);
+int mpnn_message_aggregate_wide_max_types(void);
+int mpnn_message_aggregate_wide_max_rows(void);
+size_t mpnn_message_aggregate_wide_workspace_bytes(int K, int nf);
+int mpnn_message_aggregate_wide_f32(const float* h, const float* A, const int32_t* tile_rec, const int32_t* tile_atom,
+                                    const int32_t* blk_off, const int16_t* slots, float* out, void* workspace,
+                                    size_t workspace_bytes, int64_t V, int64_t num_tiles, int K, int nf, int mf,
+                                    void* stream);
+
+/*
+ * Weight gradient of mpnn_message_aggregate_f32 (the width-64 tile kernel), on its tile plan, dagg and h each read once:
  *   dA[k] += sum_{e of type k} dagg[dst[e], :] (x) h[src[e], :]        (K x mf x nf, zeroed by the caller)
  * replaces: the autograd of edge_network.py:50-51 with respect to the edge matrices (the dA part of
  * mpnn_edge_message_agg_bwd_da_f32, which gathers both rows per edge from HBM).

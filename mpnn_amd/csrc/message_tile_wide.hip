@@ -1,0 +1,342 @@
+// Typed edge message FUSED with the neighbour sum at nf = mf = 128 / 256 (and 64), molecules of up to 256 atoms:
+//   out[i] = sum_{e in row i} A[type e] . h[src e]  =  sum_k A_k . S_k[i],   S_k[i] = sum_{e in row i, type k} h[src e]
+// replaces: mpnn_functions/message/edge_network.py:40,52 (per-pair product) composed with
+//           mpnn_functions/message_aggregators/adjacent_message_agg.py:18 (the neighbour sum), i.e. what
+//           edge_network.py:50-51 computes as one bmm.  No (E, mf) message tensor exists in HBM: the h rows are read
+//           once, the out rows written once.
+//
+// At these widths neither the bond-type matrices (K x F x F: 1 MB at F = 256) nor a tile's h rows (256 x 1 KB) fit in
+// LDS, so the contraction dimension is cut into 32-wide chunks and the sum over neighbours is taken BEFORE the product
+// (typed aggregate-then-contract: the message is linear in h, so A_k . sum = sum A_k .):
+//   * a persistent 8-wave block walks molecule-aligned tiles of at most 256 atoms (graph.py::WidePlan); wave w owns
+//     block w of the tile = 32 atoms sorted next to each other by their bond-type pattern, and keeps their 32 x F output
+//     rows in MFMA accumulators for the whole tile;
+//   * per 32-column chunk kc of the h rows (128 bytes per row = one line, copied global -> LDS without touching
+//     registers, one chunk ahead) and per bond type k (the chunk of A_k as two fp16 pieces, 64 bytes per output column,
+//     copied the same way from the pre-split workspace, one phase ahead): a wave whose block has type-k edges sums,
+//     per atom, the chunk of its type-k neighbours' rows from the LDS image (slot words name the source rows; an atom
+//     without a rank-th neighbour reads a row of zeros), splits the 32 sums into two fp16 pieces behind a per-atom
+//     power-of-two scale, and contracts them with the A_k chunk: 3 x F / 32 x 2 v_mfma_f32_32x32x16_f16 per phase;
+//   * a (block, type) pair without edges skips its phase's work; one block barrier per phase;
+//   * sum order inside an output row: types ascending, within a type the CSR edge order -- deterministic, no atomics.
+//
+// Math ("fp16x3", as the GRU kernels): operands are split as x*s = hi + lo with hi = fp16(x*s), lo = fp16(x*s - hi);
+// three MFMAs per product (lo*hi, hi*lo, hi*hi), every partial product exact in fp32; dropped: lo*lo (2^-22 relative).
+// The matrices share one power-of-two scale (largest |A| in [2^14, 2^15)); every atom's sums have their own: a row
+// scale factors out of the product, it is chosen from the first non-zero fragment with eight-fold headroom and lowered
+// (accumulator entries multiplied by the ratio, a power of two) if a later fragment outgrows it.
+#include "common.h"
+
+namespace mpnn {
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+constexpr int MW_TV = 256;          // atoms per tile (upper bound); LDS image row MW_TV is all zeros
+constexpr int MW_NB = 8;            // blocks of 32 atoms = waves
+constexpr int MW_ROWS = 256;        // slot rows of a tile parked in LDS
+constexpr int MW_KMAX = 8;
+constexpr int MW_HB = (MW_TV + 1) * 128;       // one h chunk image: 257 rows x 128 bytes
+
+template <int F>
+__host__ __device__ constexpr int mw_lds_bytes() {
+    return 2 * MW_HB + 2 * F * 128 + MW_ROWS * 64 + MW_TV * 4 + (MW_NB * MW_KMAX + 1) * 4 + 64;
+}
+
+__device__ __forceinline__ void mw_barrier() {       // orders LDS traffic only (the copies are waited for by hand)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// One wave copies 1 KB: lane L's 16 bytes at `src` land at LDS byte lds_dst + 16 L (gru_bwd128_f16.hip has the why).
+__device__ __forceinline__ void mw_copy(const char* src, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(lds_dst)
+                 : "memory");
+}
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    typedef __attribute__((address_space(3))) const char lds_char;
+    return (unsigned)(uintptr_t)(lds_char*)p;
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ matrices -> pieces
+// workspace: [0, 64): float scale inverse (and padding); then chunk (kc, k) at 64 + (kc * K + k) * F * 128 bytes:
+// [piece hi | lo][output column n][32 halves] with the 16-byte slots of a column XOR-ed by (n >> 2) & 3 (the LDS image
+// the GRU kernels read conflict-free); halves 8 o + j of slot o = A_k[n][32 kc + 8 o + j].
+__global__ void __launch_bounds__(1024) mw_absmax_kernel(const float* __restrict__ A, int64_t n, float* __restrict__ ws) {
+    __shared__ float red[16];
+    float mx = 0.f;
+    for (int64_t i = threadIdx.x; i < n / 4; i += 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(A + 4 * i);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fabsf(v[u]));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int u = 1; u < 16; ++u) mx = fmaxf(mx, red[u]);
+        int e = (__float_as_int(mx) >> 23) & 0xff;
+        e = e < 20 ? 20 : (e > 250 ? 250 : e);
+        ws[0] = __int_as_float((268 - e) << 23);            // scale: largest |A| lands in [2^14, 2^15)
+        ws[1] = __int_as_float((e - 14) << 23);             // its inverse
+    }
+}
+
+template <int F>
+__global__ void __launch_bounds__(256) mw_split_kernel(const float* __restrict__ A, char* __restrict__ ws, int K) {
+    // one thread per (k, n, octet o): 8 consecutive input features of output column n
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int per_k = F * (F / 8);
+    if (idx >= (int64_t)K * per_k) return;
+    const int k = (int)(idx / per_k), rem = (int)(idx % per_k);
+    const int n = rem / (F / 8), oc = rem % (F / 8);         // oc = global octet: chunk kc = oc >> 2, slot o = oc & 3
+    const float sc = reinterpret_cast<const float*>(ws)[0];
+    const float* p = A + ((int64_t)k * F + n) * F + 8 * oc;
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(p), x1 = *reinterpret_cast<const f32x4*>(p + 4);
+    h16x8 ph, pl;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = x0[j] * sc, b = x1[j] * sc;
+        ph[j] = (_Float16)a;
+        pl[j] = (_Float16)(a - (float)ph[j]);
+        ph[4 + j] = (_Float16)b;
+        pl[4 + j] = (_Float16)(b - (float)ph[4 + j]);
+    }
+    const int kc = oc >> 2, o = oc & 3;
+    char* dst = ws + 64 + ((int64_t)kc * K + k) * (F * 128) + n * 64 + ((o ^ ((n >> 2) & 3)) << 4);
+    *reinterpret_cast<h16x8*>(dst) = ph;
+    *reinterpret_cast<h16x8*>(dst + F * 64) = pl;
+}
+
+// ------------------------------------------------------------------------------------------------------ the kernel
+template <int F>
+__global__ void __launch_bounds__(512) message_sum_wide_kernel(
+    const float* __restrict__ h, const char* __restrict__ ws, const int32_t* __restrict__ tile_rec,
+    const int32_t* __restrict__ tile_atom, const int32_t* __restrict__ blk_off, const int16_t* __restrict__ slots,
+    float* __restrict__ out, int num_tiles, int K) {
+    constexpr int NKC = F / 32, CT = F / 32, ABUF = F * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const HB = smem;                               // two h chunk images
+    char* const AB = smem + 2 * MW_HB;                   // two matrix chunk images
+    int16_t* const SL = reinterpret_cast<int16_t*>(AB + 2 * ABUF);
+    int* const AT = reinterpret_cast<int*>(reinterpret_cast<char*>(SL) + MW_ROWS * 64);
+    int* const OFF = AT + MW_TV;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hi = lane >> 5;
+    const float a_inv = reinterpret_cast<const float*>(ws)[1];
+    const char* const wsA = ws + 64;
+    const int nphase = NKC * K;
+
+    // the zero rows of the two h images: slot word MW_TV reads them
+    if (tid < 16) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(HB + MW_TV * 128 + 16 * (tid & 7) + (tid >> 3) * MW_HB) = z;
+    }
+
+    // copies: an h chunk = 256 rows x 128 bytes = 32 wave-instructions (8 rows each), four per wave; lane = (row, 16-byte
+    // slot c): the source is slot c ^ (row & 7) of the row's line, so a reader finds slot j at position j ^ (row & 7)
+    auto copy_h = [&](int a0, int n, int kc, int buf) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row8 = 4 * wv + it;                 // group of 8 rows
+            const int row = 8 * row8 + (lane >> 3), c = lane & 7;
+            const int rr = row < n ? row : n - 1;
+            const char* src = reinterpret_cast<const char*>(h + (int64_t)(a0 + rr) * F + 32 * kc) + ((c ^ (row & 7)) << 4);
+            mw_copy(src, lds_addr(HB + buf * MW_HB + row8 * 1024));
+        }
+    };
+    // a matrix chunk = F x 128 bytes, contiguous in the workspace: F / 8 wave-instructions, F / 64 per wave
+    auto copy_a = [&](int phase, int buf) {
+        const char* src = wsA + (int64_t)phase * ABUF + lane * 16;
+#pragma unroll
+        for (int it = 0; it < F / 64; ++it) {
+            const int blk = (F / 64) * wv + it;
+            mw_copy(src + blk * 1024, lds_addr(AB + buf * ABUF + blk * 1024));
+        }
+    };
+
+    for (int t = blockIdx.x; t < num_tiles; t += gridDim.x) {
+        const int a0 = tile_rec[4 * t], n = tile_rec[4 * t + 1], row0 = tile_rec[4 * t + 2], nrows = tile_rec[4 * t + 3];
+        mw_barrier();                                     // every wave is done with the previous tile's LDS data
+        // ---- the tile's index data: slot rows (64 bytes each), sorted-atom list, (block, type) offsets
+        {
+            const int4* sp = reinterpret_cast<const int4*>(slots + (int64_t)row0 * 32);
+            for (int i = tid; i < nrows * 4; i += 512) reinterpret_cast<int4*>(SL)[i] = sp[i];
+            if (tid < MW_TV) AT[tid] = tile_atom[(int64_t)t * MW_TV + tid];
+            if (tid < MW_NB * K + 1) OFF[tid] = blk_off[(int64_t)t * (MW_NB * K + 1) + tid];
+        }
+        copy_h(a0, n, 0, 0);
+        copy_a(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+        f32x16 acc[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+        float row_sc = 0.f, row_inv = 0.f;                // 0 = this atom has not seen a non-zero sum yet
+
+        for (int ph = 0; ph < nphase; ++ph) {
+            const int kc = ph / K, k = ph - kc * K;
+            mw_barrier();                                 // this phase's images are complete, last phase's are free
+            if (ph + 1 < nphase) copy_a(ph + 1, (ph + 1) & 1);
+            if (k == 0 && kc + 1 < NKC) copy_h(a0, n, kc + 1, (kc + 1) & 1);
+            const int base = __builtin_amdgcn_readfirstlane(OFF[wv * K + k]);
+            const int cnt = __builtin_amdgcn_readfirstlane(OFF[wv * K + k + 1]) - base;
+            if (cnt > 0) {
+                const char* hb = HB + (kc & 1) * MW_HB;
+                const char* ab = AB + (ph & 1) * ABUF;
+                // ---- S: per atom (lane r, both halves) the sum of its type-k neighbours' rows of this chunk
+                f32x4 s[2][2];                             // [K = 16 step][half of the lane's 8 columns]
+#pragma unroll
+                for (int st = 0; st < 2; ++st) s[st][0] = s[st][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                int w = SL[base * 32 + r];
+                for (int q = 0; q < cnt; ++q) {
+                    const int wn = SL[(base + (q + 1 < cnt ? q + 1 : q)) * 32 + r];
+                    const char* row = hb + w * 128;
+                    const int sw = w & 7;
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+                        const int c0 = 2 * (2 * st + hi);                   // 16-byte slots of columns 16 st + 8 hi ...
+                        s[st][0] += *reinterpret_cast<const f32x4*>(row + ((c0 ^ sw) << 4));
+                        s[st][1] += *reinterpret_cast<const f32x4*>(row + (((c0 + 1) ^ sw) << 4));
+                    }
+                    w = wn;
+                }
+                // ---- range guard: one power-of-two scale per atom, lowered when a fragment outgrows it
+                float mx = 0.f;
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fmaxf(fabsf(s[st][0][u]), fabsf(s[st][1][u])));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const bool unset = row_sc == 0.f;
+                const bool grow = unset ? mx > 0.f : mx * row_sc >= 32768.0f;
+                if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+                    int e = (__float_as_int(mx) >> 23) & 0xff;
+                    e = e < 40 ? 40 : (e > 240 ? 240 : e);
+                    const float ns = grow ? __int_as_float((265 - e) << 23) : row_sc;    // mx * ns in [2^11, 2^12)
+                    const float ni = grow ? __int_as_float((e - 11) << 23) : row_inv;
+                    if (__builtin_amdgcn_ballot_w64(grow && !unset) != 0) {
+                        const float ratio = unset ? 1.0f : ns * row_inv;   // lane j (< 32): factor of the block's atom j
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int dr = 8 * (i >> 2) + (i & 3);
+                            const float f_lo = readlane_f(ratio, dr), f_hi = readlane_f(ratio, 4 + dr);
+                            const float f = hi ? f_hi : f_lo;
+#pragma unroll
+                            for (int c = 0; c < CT; ++c) acc[c][i] *= f;
+                        }
+                    }
+                    row_sc = ns;
+                    row_inv = ni;
+                }
+                // ---- split and contract
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    h16x8 ah, al;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float a = s[st][0][j] * row_sc, b = s[st][1][j] * row_sc;
+                        ah[j] = (_Float16)a;
+                        al[j] = (_Float16)(a - (float)ah[j]);
+                        ah[4 + j] = (_Float16)b;
+                        al[4 + j] = (_Float16)(b - (float)ah[4 + j]);
+                    }
+                    const int o = 2 * st + hi;
+#pragma unroll
+                    for (int c = 0; c < CT; c += 2) {
+                        const int n0 = 32 * c + r, n1 = n0 + 32;
+                        const char* p0 = ab + n0 * 64 + ((o ^ ((n0 >> 2) & 3)) << 4);
+                        const char* p1 = ab + n1 * 64 + ((o ^ ((n1 >> 2) & 3)) << 4);
+                        const h16x8 b0h = *reinterpret_cast<const h16x8*>(p0), b0l = *reinterpret_cast<const h16x8*>(p0 + F * 64);
+                        const h16x8 b1h = *reinterpret_cast<const h16x8*>(p1), b1l = *reinterpret_cast<const h16x8*>(p1 + F * 64);
+                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b0h, acc[c], 0, 0, 0);
+                        acc[c + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b1h, acc[c + 1], 0, 0, 0);
+                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0l, acc[c], 0, 0, 0);
+                        acc[c + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1l, acc[c + 1], 0, 0, 0);
+                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0h, acc[c], 0, 0, 0);
+                        acc[c + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1h, acc[c + 1], 0, 0, 0);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my copies for the next phase have landed
+        }
+        // ---- out rows: accumulator (row 8 (i >> 2) + (i & 3) + 4 hi, column 32 c + r) scaled back, at the atom's place
+        int atom[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) atom[i] = AT[32 * wv + 8 * (i >> 2) + (i & 3) + 4 * hi];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int dr = 8 * (i >> 2) + (i & 3);
+            const float u_lo = readlane_f(row_inv, dr), u_hi = readlane_f(row_inv, 4 + dr);
+            const float un = (hi ? u_hi : u_lo) * a_inv;
+            if (atom[i] >= 0) {
+                float* o = out + (int64_t)atom[i] * F + r;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) __builtin_nontemporal_store(acc[c][i] * un, o + 32 * c);
+            }
+        }
+    }
+}
+
+size_t message_wide_workspace_bytes(int K, int F) { return 64 + (size_t)K * F * F * 4; }
+
+template <int F>
+static int launch_message_wide_t(const float* h, const float* A, const int32_t* tile_rec, const int32_t* tile_atom,
+                                 const int32_t* blk_off, const int16_t* slots, float* out, void* workspace,
+                                 int64_t num_tiles, int K, hipStream_t s) {
+    static const hipError_t attr = [] {
+        LdsOptIn opt_in_;
+        opt_in_((const void*)message_sum_wide_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize, mw_lds_bytes<F>());
+        return opt_in_.err;
+    }();
+    if (attr != hipSuccess) return lds_opt_in_failed(attr);
+    char* ws = (char*)workspace;
+    hipLaunchKernelGGL(mw_absmax_kernel, dim3(1), dim3(1024), 0, s, A, (int64_t)K * F * F, (float*)ws);
+    const int64_t units = (int64_t)K * F * (F / 8);
+    hipLaunchKernelGGL(mw_split_kernel<F>, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, A, ws, K);
+    int64_t blocks = 256;                                 // one block per CU
+    if (blocks > num_tiles) blocks = num_tiles;
+    hipLaunchKernelGGL(message_sum_wide_kernel<F>, dim3((unsigned)blocks), dim3(512), mw_lds_bytes<F>(), s, h, ws, tile_rec,
+                       tile_atom, blk_off, slots, out, (int)num_tiles, K);
+    return launch_status("mpnn_message_aggregate_wide_f32");
+}
+
+}  // namespace mpnn
+
+using namespace mpnn;
+
+extern "C" int mpnn_message_aggregate_wide_tile_atoms(void) { return MW_TV; }
+extern "C" int mpnn_message_aggregate_wide_max_types(void) { return MW_KMAX; }
+extern "C" int mpnn_message_aggregate_wide_max_rows(void) { return MW_ROWS; }
+extern "C" size_t mpnn_message_aggregate_wide_workspace_bytes(int K, int nf) {
+    return message_wide_workspace_bytes(K, nf);
+}
+
+extern "C" int mpnn_message_aggregate_wide_f32(const float* h, const float* A, const int32_t* tile_rec,
+                                               const int32_t* tile_atom, const int32_t* blk_off, const int16_t* slots,
+                                               float* out, void* workspace, size_t workspace_bytes, int64_t V,
+                                               int64_t num_tiles, int K, int nf, int mf, void* stream) {
+    MPNN_REQUIRE(nf == mf && (nf == 64 || nf == 128 || nf == 256),
+                 "mpnn_message_aggregate_wide_f32: nf = mf in {64, 128, 256} only (got %d, %d)", nf, mf);
+    MPNN_REQUIRE(K >= 1 && K <= MW_KMAX, "mpnn_message_aggregate_wide_f32: 1 <= K <= %d bond types (got %d)", MW_KMAX, K);
+    MPNN_REQUIRE(V >= 0 && num_tiles >= 0 && num_tiles < (1ll << 24), "mpnn_message_aggregate_wide_f32: bad sizes");
+    if (V == 0 || num_tiles == 0) return MPNN_OK;
+    MPNN_REQUIRE(h && A && tile_rec && tile_atom && blk_off && slots && out && workspace,
+                 "mpnn_message_aggregate_wide_f32: NULL buffer");
+    MPNN_REQUIRE(workspace_bytes >= message_wide_workspace_bytes(K, nf),
+                 "mpnn_message_aggregate_wide_f32: workspace of %zu bytes, need %zu", workspace_bytes,
+                 message_wide_workspace_bytes(K, nf));
+    hipStream_t s = (hipStream_t)stream;
+    if (nf == 64) return launch_message_wide_t<64>(h, A, tile_rec, tile_atom, blk_off, slots, out, workspace, num_tiles, K, s);
+    if (nf == 128) return launch_message_wide_t<128>(h, A, tile_rec, tile_atom, blk_off, slots, out, workspace, num_tiles, K, s);
+    return launch_message_wide_t<256>(h, A, tile_rec, tile_atom, blk_off, slots, out, workspace, num_tiles, K, s);
+}

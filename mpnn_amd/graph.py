@@ -143,6 +143,99 @@ class TilePlan:
         return cls(tile_ptr, _i32(tile_atom).view(nt, tv), _i32(rt_ptr64), _i32(slots), _i32(slot_eid), tv, rt_start, K)
 
 
+class WidePlan:
+    """Work list of the fused message+sum kernel at widths 128 / 256 (csrc/message_tile_wide.hip): typed
+    aggregate-then-contract on molecule-aligned tiles.
+
+    Atoms are cut into molecule-aligned TILES of at most `tile_atoms` (256) atoms -- a 200-atom molecule fits -- sorted
+    inside the tile by their per-type in-degree pattern and dealt in BLOCKS of 32 consecutive sorted atoms (one wave of
+    the kernel each).  For every (block, bond type k) the kernel first sums, per atom, the h rows of its type-k
+    neighbours (S_k, from the tile's rows staged in LDS), then contracts the 32 sums with A_k on the matrix cores into the
+    block's output accumulators.  A (block, type) pair without edges costs nothing; sorting keeps atoms with the same
+    types together.  What the kernel needs to find the neighbours is a SLOT ROW per (block, type, rank): 32 16-bit words,
+    word m = (rank-th type-k source of the block's atom m) - tile start, or `tile_atoms` = a row of zeros.
+
+        tile_rec[T,4]       first atom, atoms, first slot row (global), slot rows of the tile
+        tile_atom[T,256]    atom id of every (block, row) of the tile (index 32 * block + row), -1 = none
+        blk_off[T,8*K+1]    first slot row of every (block, type) relative to the tile's first, then the tile's count
+        slots[32*R] int16   slot rows in (tile, block, type, rank) order
+        slot_eid[32*R]      edge id of the slot (-1 = empty); tests use it
+    """
+    TILE_ATOMS = 256
+    BLOCK = 32
+    MAX_ROWS = 256           # slot rows of one tile parked in LDS (16 KB of 16-bit words)
+    MAX_TYPES = 8
+
+    def __init__(self, tile_ptr, tile_rec, tile_atom, blk_off, slots, slot_eid, num_types):
+        self.tile_ptr, self.tile_rec, self.tile_atom, self.blk_off = tile_ptr, tile_rec, tile_atom, blk_off
+        self.slots, self.slot_eid = slots, slot_eid
+        self.num_tiles = int(tile_rec.shape[0])
+        self.num_rows = int(slots.shape[0]) // self.BLOCK
+        self.num_types = num_types
+        self.nbytes = 4 * int(tile_rec.numel() + tile_atom.numel() + blk_off.numel()) + 2 * int(slots.numel())
+
+    @classmethod
+    def build(cls, g):
+        lib = _lib.load()
+        tv, nb32 = cls.TILE_ATOMS, cls.BLOCK
+        K, E, V = g.num_types, g.num_edges, g.num_nodes
+        if K > cls.MAX_TYPES or V == 0 or g.num_graphs == 0:
+            return None
+        import ctypes
+        gp = g.graph_ptr.to("cpu", torch.int32).contiguous()
+        tp = torch.empty(g.num_graphs + 2, dtype=torch.int32)
+        nt = lib.mpnn_plan_tiles_host(ctypes.c_void_p(gp.data_ptr()), g.num_graphs, tv, ctypes.c_void_p(tp.data_ptr()))
+        if nt <= 0:
+            return None                                   # a molecule larger than a tile
+        dev = g.device
+        tile_ptr = tp[:nt + 1].to(dev)
+        tp64 = tile_ptr.to(torch.int64)
+        n_t = tp64[1:] - tp64[:-1]
+        tile_of_atom = torch.repeat_interleave(torch.arange(nt, device=dev), n_t, output_size=V)
+        dst, src, et = g.edge_dst.to(torch.int64), g.col_idx.to(torch.int64), g.edge_type.to(torch.int64)
+        if E and bool((tile_of_atom[src] != tile_of_atom[dst]).any().item()):
+            return None                                   # an edge leaves its tile: not a batch of separate molecules
+        nblk = tv // nb32
+        cnt = torch.bincount(dst * K + et, minlength=V * K).view(V, K)
+        code = torch.zeros(V, dtype=torch.int64, device=dev)
+        for k in reversed(range(K)):                      # rare types (high ids) lead the key, high counts first
+            code = code * 256 + (255 - cnt[:, k].clamp(max=255))
+        perm = torch.sort(tile_of_atom * (256 ** K) + code, stable=True).indices      # sorted position -> atom
+        pos_in_tile = torch.empty(V, dtype=torch.int64, device=dev)
+        pos_in_tile[perm] = torch.arange(V, device=dev) - tp64[tile_of_atom[perm]]
+        blk_of_atom = tile_of_atom * nblk + pos_in_tile // nb32
+        row_of_atom = pos_in_tile % nb32
+        need = torch.zeros(nt * nblk * K, dtype=torch.int64, device=dev)
+        need.scatter_reduce_(0, (blk_of_atom.unsqueeze(1) * K + torch.arange(K, device=dev)).reshape(-1), cnt.reshape(-1),
+                             reduce="amax")
+        start = torch.zeros(need.numel() + 1, dtype=torch.int64, device=dev)
+        start[1:] = torch.cumsum(need, 0)
+        R = int(start[-1].item())
+        per = nblk * K
+        tile_row0 = start[::per][:nt]
+        rows_of_tile = start[per::per] - tile_row0
+        if int(rows_of_tile.max()) > cls.MAX_ROWS:
+            return None                                   # more slot rows than the kernel parks in LDS
+        idx = torch.arange(nt, device=dev).unsqueeze(1) * per + torch.arange(per + 1, device=dev)
+        blk_off = _i32(start[idx] - tile_row0.unsqueeze(1))
+        tile_rec = _i32(torch.stack([tp64[:-1], n_t, tile_row0, rows_of_tile], dim=1))
+        tile_atom = torch.full((nt * tv,), -1, dtype=torch.int64, device=dev)
+        tile_atom[blk_of_atom * nb32 + row_of_atom] = torch.arange(V, device=dev)
+        slots = torch.full((nb32 * R,), tv, dtype=torch.int16, device=dev)
+        slot_eid = torch.full((nb32 * R,), -1, dtype=torch.int64, device=dev)
+        if E:
+            key = dst * K + et
+            order = torch.sort(key, stable=True).indices
+            first = torch.zeros(V * K + 1, dtype=torch.int64, device=dev)
+            first[1:] = torch.cumsum(cnt.reshape(-1), 0)
+            rank = torch.empty(E, dtype=torch.int64, device=dev)
+            rank[order] = torch.arange(E, device=dev) - first[key[order]]
+            pos = (start[blk_of_atom[dst] * K + et] + rank) * nb32 + row_of_atom[dst]
+            slots[pos] = (src - tp64[tile_of_atom[dst]]).to(torch.int16)
+            slot_eid[pos] = torch.arange(E, device=dev)
+        return cls(tile_ptr, tile_rec, _i32(tile_atom).view(nt, tv), blk_off.contiguous(), slots, _i32(slot_eid), K)
+
+
 class MolGraph:
     def __init__(self, row_ptr, col_idx, edge_weight, edge_type, type_feat, graph_ptr, dense_shape=None,
                  edge_feat=None):
@@ -168,6 +261,7 @@ class MolGraph:
         self._unit_weights = None
         self._adj_ptr = None
         self._tile_plan = None
+        self._wide_plan = None
 
     def with_type_feat(self, type_feat):
         """The same graph with another (K, ef) table of bond-feature rows (index arrays and their caches shared)."""
@@ -177,19 +271,21 @@ class MolGraph:
         g.edge_feat = None
         return g
 
-    def prepare(self, tile_plan=True):
-        """Build every derived index array now (type order, transposed graph, destination list and, unless the caller
-        knows the width-64 tile kernels will not run, the tile plan), so that none of it lands inside a timed or
-        captured region."""
+    def prepare(self, tile_plan=True, wide_plan=False):
+        """Build every derived index array now (type order, transposed graph, destination list and the tile plans of
+        the fused message+sum kernels the caller will run: `tile_plan` for width 64, `wide_plan` for 128 / 256), so
+        that none of it lands inside a timed or captured region."""
         self.order, self.type_ptr, self.transpose, self.edge_dst, self.agg_weight
         if tile_plan:
             self.tile_plan
+        if wide_plan:
+            self.wide_plan
         return self
 
     def plan_bytes(self):
-        """Bytes of index data the fused message+sum kernel reads per launch (0 without a tile plan)."""
-        p = self.tile_plan
-        return 0 if p is None else p.nbytes
+        """Bytes of index data the fused message+sum kernel reads per launch (0 without a plan)."""
+        p = self._tile_plan or self._wide_plan
+        return p.nbytes if p else 0
 
     @property
     def tile_plan(self):
@@ -198,6 +294,13 @@ class MolGraph:
         if self._tile_plan is None:
             self._tile_plan = TilePlan.build(self) or False
         return self._tile_plan or None
+
+    @property
+    def wide_plan(self):
+        """WidePlan for the fused message+sum kernel at widths 128 / 256, or None when the batch does not fit it."""
+        if self._wide_plan is None:
+            self._wide_plan = WidePlan.build(self) or False
+        return self._wide_plan or None
 
     # ------------------------------------------------------------------ derived index arrays
     @property

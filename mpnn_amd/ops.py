@@ -169,6 +169,37 @@ def message_aggregate_tile_raw(h, A, graph):
     return out
 
 
+def wide_kernel_applies(A, gate, w, graph):
+    """The fused message+sum kernel at widths 128 / 256 (typed aggregate-then-contract on molecule tiles of up to 256
+    atoms, csrc/message_tile_wide.hip) covers: no gate, unit edge weights, nf = mf in {128, 256}, a batch of separate
+    molecules with at most 8 bond types (graph.wide_plan), default math.  MPNN_UNFUSED_MESSAGE=1 keeps the two-kernel
+    path; MPNN_WIDE_MESSAGE64=1 sends width 64 through this kernel too (A/B against the width-64 tile kernel)."""
+    K, mf, nf = (int(s) for s in A.shape)
+    widths = (64, 128, 256) if os.environ.get("MPNN_WIDE_MESSAGE64") else (128, 256)
+    if (gate is not None or w is not None or mf != nf or nf not in widths or math_mode() == "fp32"
+            or os.environ.get("MPNN_UNFUSED_MESSAGE")):
+        return False
+    plan = graph.wide_plan
+    return plan is not None and K == graph.num_types
+
+
+def message_aggregate_wide_raw(h, A, graph):
+    lib = _lib.load()
+    K, mf, nf = (int(s) for s in A.shape)
+    V = graph.num_nodes
+    plan = graph.wide_plan
+    if V == 0 or graph.num_edges == 0:                  # no bonds at all: every row is an empty sum
+        return torch.zeros(V, mf, dtype=torch.float32, device=h.device)
+    out = _empty((V, mf), h)
+    ws_bytes = lib.mpnn_message_aggregate_wide_workspace_bytes(K, nf)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=h.device)
+    _lib.check(_timed("message_aggregate", lambda: lib.mpnn_message_aggregate_wide_f32(
+        _lib.fptr(h), _lib.fptr(A), _lib.iptr(plan.tile_rec), _lib.iptr(plan.tile_atom), _lib.iptr(plan.blk_off),
+        _lib.ptr(plan.slots, torch.int16), _lib.fptr(out), _lib.ptr(ws), ws_bytes, V, plan.num_tiles, K, nf, mf,
+        _lib.stream())), "mpnn_message_aggregate_wide_f32")
+    return out
+
+
 def edge_message_bwd_raw(h, A, graph, gate, dmsg, need_dx=True, need_dA=True):
     lib = _lib.load()
     K, mf, nf = (int(s) for s in A.shape)
@@ -295,6 +326,8 @@ class MessageAggregate(torch.autograd.Function):
         gate = gate.contiguous() if gate is not None else None
         ctx.graph = graph
         ctx.save_for_backward(h, A, gate, w)
+        if wide_kernel_applies(A, gate, w, graph):
+            return message_aggregate_wide_raw(h, A, graph)
         if tile_kernel_applies(A, gate, w, graph):
             return message_aggregate_tile_raw(h, A, graph)
         msg = edge_message_raw(h, A, graph, gate)

@@ -108,3 +108,69 @@ def test_plan_refuses_an_edge_into_the_next_tile():
     assert graph([]).tile_plan is not None
     # destination = last atom of tile 0, source = atom 105: 105 - 0 < 128 passes a start-relative bound
     assert graph([(n + 5, n - 1), (n - 1, n + 5)]).tile_plan is None
+
+
+# ------------------------------------------------------------------------------------------ wide plan (widths 128 / 256)
+def _walk_wide(g, h, A):
+    """Walk graph.WidePlan exactly as csrc/message_tile_wide.hip does: per tile, per block of 32 sorted atoms, per bond
+    type: S = per-atom sum of the slot rows' source rows, then out[atom] += A_k . S."""
+    p = g.wide_plan
+    K = g.num_types
+    out = torch.zeros(g.num_nodes, h.shape[1], dtype=torch.float64)
+    rec, ta, bo = p.tile_rec.numpy(), p.tile_atom.numpy(), p.blk_off.numpy()
+    sl, se = p.slots.numpy().reshape(-1, 32), p.slot_eid.numpy().reshape(-1, 32)
+    seen = np.zeros(g.num_edges, int)
+    dst, typ = g.edge_dst.numpy(), g.edge_type.numpy()
+    for t in range(p.num_tiles):
+        a0, n, row0, nrows = rec[t]
+        assert 0 < n <= p.TILE_ATOMS and nrows <= p.MAX_ROWS and bo[t, 0] == 0 and bo[t, -1] == nrows
+        assert sorted(a for a in ta[t] if a >= 0) == list(range(a0, a0 + n))
+        for b in range(8):
+            for k in range(K):
+                lo, hi = bo[t, b * K + k], bo[t, b * K + k + 1]
+                S = torch.zeros(32, h.shape[1], dtype=torch.float64)
+                for rr in range(row0 + lo, row0 + hi):
+                    last = {}
+                    for m in range(32):
+                        w, e = sl[rr, m], se[rr, m]
+                        if e < 0:
+                            assert w == p.TILE_ATOMS
+                            continue
+                        d = ta[t, 32 * b + m]
+                        assert d == dst[e] and a0 + w == g.col_idx[e] and typ[e] == k
+                        seen[e] += 1
+                        S[m] += h[a0 + w]
+                for m in range(32):
+                    if ta[t, 32 * b + m] >= 0 and hi > lo:
+                        out[ta[t, 32 * b + m]] += A[k] @ S[m]
+    assert (seen == 1).all()
+    return out
+
+
+@pytest.mark.parametrize("n_mols,seed,dist", [(120, 1, "drug"), (3, 2, "drug"), (1, 3, "drug"), (30, 4, "skewed")])
+def test_wide_plan_walk_reproduces_the_neighbour_sum(n_mols, seed, dist):
+    mb = synth.make_molecules(n_mols, 8, seed=seed, dist=dist)
+    g = MolGraph.from_molbatch(mb, torch.device("cpu"))
+    assert g.wide_plan is not None                          # molecules of up to 200 atoms fit a 256-atom tile
+    h = torch.randn(g.num_nodes, 8, dtype=torch.float64)
+    A = torch.randn(g.num_types, 8, 8, dtype=torch.float64)
+    ref = torch.zeros(g.num_nodes, 8, dtype=torch.float64)
+    ref.index_add_(0, g.edge_dst.long(), torch.einsum("emn,en->em", A[g.edge_type.long()], h[g.col_idx.long()]))
+    assert float((_walk_wide(g, h, A) - ref).abs().max()) < 1e-12
+
+
+def test_wide_plan_rank_order_is_edge_order_and_limits():
+    mb = synth.make_molecules(40, 4, seed=8, dist="skewed")
+    g = MolGraph.from_molbatch(mb, torch.device("cpu"))
+    p = g.wide_plan
+    se = p.slot_eid.numpy().reshape(-1, 32)
+    last = {}
+    dst, typ = g.edge_dst.numpy(), g.edge_type.numpy()
+    for rr in range(se.shape[0]):
+        for e in se[rr]:
+            if e >= 0:
+                key = (dst[e], typ[e])
+                assert last.get(key, -1) < e                 # rank r of (atom, type) = its r-th edge in CSR order
+                last[key] = e
+    many = synth.make_molecules(20, 4, seed=6, edge_features=9)      # 9 bond types: more than the kernel's phases take
+    assert MolGraph.from_molbatch(many, torch.device("cpu")).wide_plan is None
