@@ -25,6 +25,8 @@
 // The matrices share one power-of-two scale (largest |A| in [2^14, 2^15)); every atom's sums have their own: a row
 // scale factors out of the product, it is chosen from the first non-zero fragment with eight-fold headroom and lowered
 // (accumulator entries multiplied by the ratio, a power of two) if a later fragment outgrows it.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace mpnn {
@@ -118,7 +120,7 @@ template <int F>
 __global__ void __launch_bounds__(512) message_sum_wide_kernel(
     const float* __restrict__ h, const char* __restrict__ ws, const int32_t* __restrict__ tile_rec,
     const int32_t* __restrict__ tile_atom, const int32_t* __restrict__ blk_off, const int16_t* __restrict__ slots,
-    float* __restrict__ out, int num_tiles, int K) {
+    float* __restrict__ out, int num_tiles, int K, int dbg) {
     constexpr int NKC = F / 32, CT = F / 32, ABUF = F * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const HB = smem;                               // two h chunk images
@@ -162,9 +164,60 @@ __global__ void __launch_bounds__(512) message_sum_wide_kernel(
         }
     };
 
-    for (int t = blockIdx.x; t < num_tiles; t += gridDim.x) {
-        const int a0 = tile_rec[4 * t], n = tile_rec[4 * t + 1], row0 = tile_rec[4 * t + 2], nrows = tile_rec[4 * t + 3];
-        mw_barrier();                                     // every wave is done with the previous tile's LDS data
+    // ---- per-wave pieces of a phase
+    // S: per atom (lane r, both halves) the sum of its type-k neighbours' rows of the chunk in `hb`.  The first ranks are
+    // straight-line code (slot words first, then every row read, then the adds: two LDS round trips in all; a missing
+    // rank reads the row of zeros), further ranks -- hubs -- run in a loop with the slot word fetched one rank ahead.
+    auto add_row = [&](const char* hb, int w, f32x4 (&s)[2][2]) {
+        const char* row = hb + w * 128;
+        const int sw = w & 7;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const int c0 = 2 * (2 * st + hi);             // 16-byte slots of columns 16 st + 8 hi ...
+            s[st][0] += *reinterpret_cast<const f32x4*>(row + ((c0 ^ sw) << 4));
+            s[st][1] += *reinterpret_cast<const f32x4*>(row + (((c0 + 1) ^ sw) << 4));
+        }
+    };
+    auto gather = [&](const char* hb, int base, int cnt, f32x4 (&s)[2][2]) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) s[st][0] = s[st][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int16_t* sl = SL + base * 32 + r;
+        int w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ww = sl[32 * (q < cnt ? q : 0)];
+            w[q] = q < cnt ? ww : MW_TV;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) add_row(hb, w[q], s);
+        if (cnt > 2) {
+#pragma unroll
+            for (int q = 2; q < 4; ++q) add_row(hb, w[q], s);
+            if (cnt > 4) {
+                int wq = sl[32 * 4];
+                for (int q = 4; q < cnt; ++q) {
+                    const int wn = sl[32 * (q + 1 < cnt ? q + 1 : q)];
+                    add_row(hb, wq, s);
+                    wq = wn;
+                }
+            }
+        }
+    };
+
+    int t = blockIdx.x;
+    int a0 = 0, n = 1;
+    if (t < num_tiles) {
+        a0 = tile_rec[4 * t];
+        n = tile_rec[4 * t + 1];
+        copy_h(a0, n, 0, 0);                              // the first tile's first images; later tiles' are requested
+        copy_a(0, 0);                                     // during the previous tile's last chunk
+    }
+    for (; t < num_tiles; t += gridDim.x) {
+        const int row0 = tile_rec[4 * t + 2], nrows = tile_rec[4 * t + 3];
+        const int tn = t + (int)gridDim.x;
+        const bool more = tn < num_tiles;
+        const int a0n = more ? tile_rec[4 * tn] : a0, nn = more ? tile_rec[4 * tn + 1] : n;
+        mw_barrier();                                     // every wave is done with the previous tile's index data
         // ---- the tile's index data: slot rows (64 bytes each), sorted-atom list, (block, type) offsets
         {
             const int4* sp = reinterpret_cast<const int4*>(slots + (int64_t)row0 * 32);
@@ -172,9 +225,13 @@ __global__ void __launch_bounds__(512) message_sum_wide_kernel(
             if (tid < MW_TV) AT[tid] = tile_atom[(int64_t)t * MW_TV + tid];
             if (tid < MW_NB * K + 1) OFF[tid] = blk_off[(int64_t)t * (MW_NB * K + 1) + tid];
         }
-        copy_h(a0, n, 0, 0);
-        copy_a(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        mw_barrier();
+        // which bond types my block has (wave-uniform bit mask)
+        int amask = 0;
+        for (int k = 0; k < K; ++k)
+            amask |= (__builtin_amdgcn_readfirstlane(OFF[wv * K + k + 1]) > __builtin_amdgcn_readfirstlane(OFF[wv * K + k])) << k;
+        if (dbg & 8) amask = 0;
 
         f32x16 acc[CT];
 #pragma unroll
@@ -182,89 +239,99 @@ __global__ void __launch_bounds__(512) message_sum_wide_kernel(
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
         float row_sc = 0.f, row_inv = 0.f;                // 0 = this atom has not seen a non-zero sum yet
+        f32x4 s[2][2];                                    // sums of the phase that multiplies next
+        bool have = false;                                // ... already gathered (during the previous phase's products)
+
+        // range guard + split of the sums in `s`: one power-of-two scale per atom, lowered when a fragment outgrows it
+        auto guard_split = [&](h16x8 (&ah)[2], h16x8 (&al)[2]) {
+            float mx = 0.f;
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fmaxf(fabsf(s[st][0][u]), fabsf(s[st][1][u])));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const bool unset = row_sc == 0.f;
+            const bool grow = unset ? mx > 0.f : mx * row_sc >= 32768.0f;
+            if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+                int e = (__float_as_int(mx) >> 23) & 0xff;
+                e = e < 40 ? 40 : (e > 240 ? 240 : e);
+                const float ns = grow ? __int_as_float((265 - e) << 23) : row_sc;    // mx * ns in [2^11, 2^12)
+                const float ni = grow ? __int_as_float((e - 11) << 23) : row_inv;
+                if (__builtin_amdgcn_ballot_w64(grow && !unset) != 0) {
+                    const float ratio = unset ? 1.0f : ns * row_inv;   // lane j (< 32): factor of the block's atom j
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int dr = 8 * (i >> 2) + (i & 3);
+                        const float f_lo = readlane_f(ratio, dr), f_hi = readlane_f(ratio, 4 + dr);
+                        const float f = hi ? f_hi : f_lo;
+#pragma unroll
+                        for (int c = 0; c < CT; ++c) acc[c][i] *= f;
+                    }
+                }
+                row_sc = ns;
+                row_inv = ni;
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = s[st][0][j] * row_sc, b = s[st][1][j] * row_sc;
+                    ah[st][j] = (_Float16)a;
+                    al[st][j] = (_Float16)(a - (float)ah[st][j]);
+                    ah[st][4 + j] = (_Float16)b;
+                    al[st][4 + j] = (_Float16)(b - (float)ah[st][4 + j]);
+                }
+        };
 
         for (int ph = 0; ph < nphase; ++ph) {
             const int kc = ph / K, k = ph - kc * K;
             mw_barrier();                                 // this phase's images are complete, last phase's are free
-            if (ph + 1 < nphase) copy_a(ph + 1, (ph + 1) & 1);
-            if (k == 0 && kc + 1 < NKC) copy_h(a0, n, kc + 1, (kc + 1) & 1);
-            const int base = __builtin_amdgcn_readfirstlane(OFF[wv * K + k]);
-            const int cnt = __builtin_amdgcn_readfirstlane(OFF[wv * K + k + 1]) - base;
-            if (cnt > 0) {
+            if (!(dbg & 4)) {
+                if (ph + 1 < nphase) copy_a(ph + 1, (ph + 1) & 1);
+                else if (more) copy_a(0, 0);              // next tile, first phase (NKC is even: buffer 0 is free)
+                if (k == 0) {
+                    if (kc + 1 < NKC) copy_h(a0, n, kc + 1, (kc + 1) & 1);
+                    else if (more) copy_h(a0n, nn, 0, 0);
+                }
+            }
+            if ((amask >> k) & 1) {
                 const char* hb = HB + (kc & 1) * MW_HB;
                 const char* ab = AB + (ph & 1) * ABUF;
-                // ---- S: per atom (lane r, both halves) the sum of its type-k neighbours' rows of this chunk
-                f32x4 s[2][2];                             // [K = 16 step][half of the lane's 8 columns]
-#pragma unroll
-                for (int st = 0; st < 2; ++st) s[st][0] = s[st][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-                int w = SL[base * 32 + r];
-                for (int q = 0; q < cnt; ++q) {
-                    const int wn = SL[(base + (q + 1 < cnt ? q + 1 : q)) * 32 + r];
-                    const char* row = hb + w * 128;
-                    const int sw = w & 7;
+                if (!have) {
+                    const int b0 = __builtin_amdgcn_readfirstlane(OFF[wv * K + k]);
+                    gather(hb, b0, __builtin_amdgcn_readfirstlane(OFF[wv * K + k + 1]) - b0, s);
+                }
+                h16x8 ah[2], al[2];
+                guard_split(ah, al);
+                // the next type of my block in this chunk: its sums are gathered while this phase's products run
+                const int rest = amask >> (k + 1);
+                have = rest != 0;
+                if (have) {
+                    const int kn = k + 1 + __builtin_ctz(rest);
+                    const int bn = __builtin_amdgcn_readfirstlane(OFF[wv * K + kn]);
+                    gather(hb, bn, __builtin_amdgcn_readfirstlane(OFF[wv * K + kn + 1]) - bn, s);
+                }
+                if (!(dbg & 2)) {
 #pragma unroll
                     for (int st = 0; st < 2; ++st) {
-                        const int c0 = 2 * (2 * st + hi);                   // 16-byte slots of columns 16 st + 8 hi ...
-                        s[st][0] += *reinterpret_cast<const f32x4*>(row + ((c0 ^ sw) << 4));
-                        s[st][1] += *reinterpret_cast<const f32x4*>(row + (((c0 + 1) ^ sw) << 4));
-                    }
-                    w = wn;
-                }
-                // ---- range guard: one power-of-two scale per atom, lowered when a fragment outgrows it
-                float mx = 0.f;
+                        const int o = 2 * st + hi;
 #pragma unroll
-                for (int st = 0; st < 2; ++st)
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fmaxf(fabsf(s[st][0][u]), fabsf(s[st][1][u])));
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
-                const bool unset = row_sc == 0.f;
-                const bool grow = unset ? mx > 0.f : mx * row_sc >= 32768.0f;
-                if (__builtin_amdgcn_ballot_w64(grow) != 0) {
-                    int e = (__float_as_int(mx) >> 23) & 0xff;
-                    e = e < 40 ? 40 : (e > 240 ? 240 : e);
-                    const float ns = grow ? __int_as_float((265 - e) << 23) : row_sc;    // mx * ns in [2^11, 2^12)
-                    const float ni = grow ? __int_as_float((e - 11) << 23) : row_inv;
-                    if (__builtin_amdgcn_ballot_w64(grow && !unset) != 0) {
-                        const float ratio = unset ? 1.0f : ns * row_inv;   // lane j (< 32): factor of the block's atom j
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const int dr = 8 * (i >> 2) + (i & 3);
-                            const float f_lo = readlane_f(ratio, dr), f_hi = readlane_f(ratio, 4 + dr);
-                            const float f = hi ? f_hi : f_lo;
-#pragma unroll
-                            for (int c = 0; c < CT; ++c) acc[c][i] *= f;
+                        for (int c = 0; c < CT; c += 2) {
+                            const int n0 = 32 * c + r, n1 = n0 + 32;
+                            const char* p0 = ab + n0 * 64 + ((o ^ ((n0 >> 2) & 3)) << 4);
+                            const char* p1 = ab + n1 * 64 + ((o ^ ((n1 >> 2) & 3)) << 4);
+                            const h16x8 b0h = *reinterpret_cast<const h16x8*>(p0), b0l = *reinterpret_cast<const h16x8*>(p0 + F * 64);
+                            const h16x8 b1h = *reinterpret_cast<const h16x8*>(p1), b1l = *reinterpret_cast<const h16x8*>(p1 + F * 64);
+                            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[st], b0h, acc[c], 0, 0, 0);
+                            acc[c + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[st], b1h, acc[c + 1], 0, 0, 0);
+                            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st], b0l, acc[c], 0, 0, 0);
+                            acc[c + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st], b1l, acc[c + 1], 0, 0, 0);
+                            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st], b0h, acc[c], 0, 0, 0);
+                            acc[c + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st], b1h, acc[c + 1], 0, 0, 0);
                         }
                     }
-                    row_sc = ns;
-                    row_inv = ni;
-                }
-                // ---- split and contract
-#pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    h16x8 ah, al;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float a = s[st][0][j] * row_sc, b = s[st][1][j] * row_sc;
-                        ah[j] = (_Float16)a;
-                        al[j] = (_Float16)(a - (float)ah[j]);
-                        ah[4 + j] = (_Float16)b;
-                        al[4 + j] = (_Float16)(b - (float)ah[4 + j]);
-                    }
-                    const int o = 2 * st + hi;
-#pragma unroll
-                    for (int c = 0; c < CT; c += 2) {
-                        const int n0 = 32 * c + r, n1 = n0 + 32;
-                        const char* p0 = ab + n0 * 64 + ((o ^ ((n0 >> 2) & 3)) << 4);
-                        const char* p1 = ab + n1 * 64 + ((o ^ ((n1 >> 2) & 3)) << 4);
-                        const h16x8 b0h = *reinterpret_cast<const h16x8*>(p0), b0l = *reinterpret_cast<const h16x8*>(p0 + F * 64);
-                        const h16x8 b1h = *reinterpret_cast<const h16x8*>(p1), b1l = *reinterpret_cast<const h16x8*>(p1 + F * 64);
-                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b0h, acc[c], 0, 0, 0);
-                        acc[c + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b1h, acc[c + 1], 0, 0, 0);
-                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0l, acc[c], 0, 0, 0);
-                        acc[c + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1l, acc[c + 1], 0, 0, 0);
-                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0h, acc[c], 0, 0, 0);
-                        acc[c + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1h, acc[c + 1], 0, 0, 0);
-                    }
+                } else {
+                    asm volatile("" ::"v"(ah[0]), "v"(al[0]), "v"(ah[1]), "v"(al[1]));
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my copies for the next phase have landed
@@ -284,6 +351,8 @@ __global__ void __launch_bounds__(512) message_sum_wide_kernel(
                 for (int c = 0; c < CT; ++c) __builtin_nontemporal_store(acc[c][i] * un, o + 32 * c);
             }
         }
+        a0 = a0n;
+        n = nn;
     }
 }
 
@@ -305,8 +374,9 @@ static int launch_message_wide_t(const float* h, const float* A, const int32_t* 
     hipLaunchKernelGGL(mw_split_kernel<F>, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, A, ws, K);
     int64_t blocks = 256;                                 // one block per CU
     if (blocks > num_tiles) blocks = num_tiles;
+    static const int dbg = getenv("MPNN_MW_DBG") ? atoi(getenv("MPNN_MW_DBG")) : 0;     // timing ablations only
     hipLaunchKernelGGL(message_sum_wide_kernel<F>, dim3((unsigned)blocks), dim3(512), mw_lds_bytes<F>(), s, h, ws, tile_rec,
-                       tile_atom, blk_off, slots, out, (int)num_tiles, K);
+                       tile_atom, blk_off, slots, out, (int)num_tiles, K, dbg);
     return launch_status("mpnn_message_aggregate_wide_f32");
 }
 
