@@ -249,10 +249,15 @@ int mpnn_segsum_gather_f32(const float* x, const int32_t* row_ptr, const int32_t
  * replaces: mpnn_functions/update/gru_update.py:26-35 and :66-68.
  *   m [V,H], h [V,H], mask [V], W_ih [H,3H], W_hh [H,3H], b_ih [3H], b_hh [3H], out [V,H]
  *   saved: optional [V,4H] = (r, z, n, gh_n) kept for the backward pass, may be NULL
+ *   workspace: optional, mpnn_gru_fwd_workspace_bytes(V, H) bytes (0 at most widths).  At H = 128 / 256 it receives the
+ *   two weight matrices as fp16 pieces in the kernel's chunk order, written once per call and copied global -> LDS by
+ *   the GRU kernel; with NULL the kernel splits its weight chunks itself (same results, more vector work).
  */
+size_t mpnn_gru_fwd_workspace_bytes(int64_t V, int H);
 int mpnn_gru_update_f32(const float* m, const float* h, const float* mask,
                         const float* W_ih, const float* W_hh, const float* b_ih, const float* b_hh,
-                        float* out, float* saved, int64_t V, int H, void* stream);
+                        float* out, float* saved, void* workspace, size_t workspace_bytes, int64_t V, int H,
+                        void* stream);
 /*
  * Backward: given dout [V,H] and `saved`, writes dm [V,H], dh [V,H] and ACCUMULATES into
  * dW_ih, dW_hh [H,3H], db_ih, db_hh [3H] (caller zeroes them).  `workspace`: mpnn_gru_bwd_workspace_bytes(V, H)

@@ -29,6 +29,7 @@ const Switches& switches() {
         s.gru_fwd_bf16 = getenv("MPNN_GRU_FWD_BF16") != nullptr;
         s.gru_bwd_bf16 = getenv("MPNN_GRU_BWD_BF16") != nullptr;
         s.gru_dx_slice64 = getenv("MPNN_GRU_DX_SLICE64") != nullptr;
+        s.gru_dx_insplit = getenv("MPNN_GRU_DX_INSPLIT") != nullptr;
         const char* v = getenv("MPNN_SEGSUM_VARIANT");
         s.segsum_variant = v ? atoi(v) : 3;
         return s;

@@ -49,6 +49,7 @@ struct Switches {
     bool gru_fwd_bf16;       // MPNN_GRU_FWD_BF16: GRU forward (64 / 128 / 256) on three bf16 pieces instead of two row-guarded fp16 pieces
     bool gru_bwd_bf16;       // MPNN_GRU_BWD_BF16: width-64 GRU backward on three bf16 pieces (gru_bwd_presplit.hip) instead of two fp16 pieces (gru_bwd_f16.hip)
     bool gru_dx_slice64;     // MPNN_GRU_DX_SLICE64: width-128/256 dm|dh on 64-column slices instead of 128-column ones
+    bool gru_dx_insplit;     // MPNN_GRU_DX_INSPLIT: the 128-column dm|dh kernel splits its weight chunks itself (no pre-split workspace)
     int segsum_variant;      // MPNN_SEGSUM_VARIANT: 1 = one atom per lane group, 2 = cached loads/stores, 3 = default
 };
 const Switches& switches();

@@ -326,15 +326,23 @@ static int launch_gru_resident(const float* m, const float* h, const float* mask
 
 // split-precision (bf16x6) forward, gru_split.hip; returns 1 when the width is not covered
 int launch_gru_split(const float* m, const float* h, const float* mask, const float* W_ih, const float* W_hh,
-                     const float* b_ih, const float* b_hh, float* out, float* saved, int64_t V, int H, hipStream_t s);
+                     const float* b_ih, const float* b_hh, float* out, float* saved, int64_t V, int H, void* workspace,
+                     hipStream_t s);
+size_t gru_fwd_workspace_bytes(int H);
 
 }  // namespace mpnn
 
 using namespace mpnn;
 
+extern "C" size_t mpnn_gru_fwd_workspace_bytes(int64_t V, int H) {
+    (void)V;
+    if (H <= 0 || switches().math_fp32) return 0;
+    return gru_fwd_workspace_bytes(H);
+}
+
 extern "C" int mpnn_gru_update_f32(const float* m, const float* h, const float* mask, const float* W_ih,
                                    const float* W_hh, const float* b_ih, const float* b_hh, float* out, float* saved,
-                                   int64_t V, int H, void* stream) {
+                                   void* workspace, size_t workspace_bytes, int64_t V, int H, void* stream) {
     MPNN_REQUIRE(V >= 0 && H > 0 && H <= MPNN_MAX_FEATURES, "mpnn_gru_update_f32: V=%lld H=%d out of range",
                  (long long)V, H);
     if (V == 0) return MPNN_OK;
@@ -349,7 +357,10 @@ extern "C" int mpnn_gru_update_f32(const float* m, const float* h, const float* 
     // splitting (fp32-equivalent accuracy, see gru_split.hip)
     const bool fp32_only = switches().math_fp32;
     if (!fp32_only) {
-        const int rc = launch_gru_split(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, H, st);
+        // the pre-split weight images of the streamed kernels live in the caller's workspace; without one (NULL or too
+        // small) the kernels split their weight chunks themselves
+        void* ws = (workspace && workspace_bytes >= gru_fwd_workspace_bytes(H) && gru_fwd_workspace_bytes(H)) ? workspace : nullptr;
+        const int rc = launch_gru_split(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, H, ws, st);
         if (rc != 1) return rc;
     }
     if (H == 64) return launch_gru_resident<64, 2, 8>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, st);

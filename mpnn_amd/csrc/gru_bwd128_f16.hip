@@ -570,12 +570,56 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_stream_f16_kernel(const char* 
 // of both, eight accumulators -- so the pieces are read H / 128 times.  What pays for the registers: the contraction is
 // cut into 32-wide chunks (two K = 16 steps; A operand 16 registers per set instead of 32), and the third gate block is
 // walked twice, once as (dan, W_ih) -> dm and once as (dnh, W_hh) -> dh, so that no second operand set is ever live.
+// ---- pre-split weights of the 128-column dm | dh kernel: one workspace region per launch ----
+// [0, 64): inverse weight scale of slice s at float s; then the LDS image of (slice, chunk ct) at 64 + (slice * NCT + ct) * 32 KB,
+// [matrix][piece][128 output rows][32 k] exactly as gru_bwd_dx_wide_f16_kernel reads it, so that a chunk is copied
+// global -> LDS verbatim (no vector work, no registers).  Chunks of the third gate block carry one matrix only.
 template <int H>
+__global__ void __launch_bounds__(512) gru_bwd_dx_presplit_kernel(const float* __restrict__ W_ih, const float* __restrict__ W_hh,
+                                                                  char* __restrict__ ws) {
+    constexpr int CPS = H / 32, NCT = 4 * CPS, IMGC = 128 * 64;
+    __shared__ float redw[8];
+    const int slice = blockIdx.x / NCT, ct = blockIdx.x % NCT;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float mx = 0.f;
+    for (int idx = tid; idx < 2 * 128 * (3 * H / 4); idx += 512) {
+        const int mat = idx / (128 * (3 * H / 4)), rem = idx % (128 * (3 * H / 4));
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>((mat ? W_hh : W_ih) + (int64_t)(128 * slice) * 3 * H + 4 * rem);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fabsf(w4[u]));
+    }
+    mx = g_wave_max(mx);
+    if (lane == 0) redw[wv] = mx;
+    __syncthreads();
+    mx = redw[0];
+#pragma unroll
+    for (int u = 1; u < 8; ++u) mx = fmaxf(mx, redw[u]);
+    float sw, inv_sw;
+    g_guard_scale<30>(mx, sw, inv_sw);
+    if (ct == 0 && tid == 0) reinterpret_cast<float*>(ws)[slice] = inv_sw;
+    const int seg = ct < 2 * CPS ? ct / CPS : (ct < 3 * CPS ? 2 : 3), cc = ct % CPS;
+    const int off = (seg == 3 ? 2 : seg) * H + 32 * cc;
+    char* img = ws + 64 + (int64_t)(slice * NCT + ct) * (4 * IMGC);
+    const int n = tid >> 2, o = tid & 3;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        if (seg < 2 || seg - 2 == j) {
+            const float* src = (j ? W_hh : W_ih) + (int64_t)(128 * slice + n) * 3 * H + 8 * o + off;
+            h16x8 ph, pl;
+            g_split8(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4), sw, ph, pl);
+            char* base = img + j * 2 * IMGC + n * 64 + ((o ^ ((n >> 2) & 3)) << 4);
+            *reinterpret_cast<h16x8*>(base) = ph;
+            *reinterpret_cast<h16x8*>(base + IMGC) = pl;
+        }
+}
+
+template <int H, bool WS = false>
 __global__ void __launch_bounds__(512) gru_bwd_dx_wide_f16_kernel(const char* __restrict__ pieces,
                                                                   const float* __restrict__ inv_scale,
                                                                   const float* __restrict__ W_ih,
                                                                   const float* __restrict__ W_hh, float* __restrict__ dm,
-                                                                  float* __restrict__ dh, int64_t V) {
+                                                                  float* __restrict__ dh, int64_t V,
+                                                                  const char* __restrict__ wws) {
     constexpr int NS = H / 128, CPS = H / 32, NCT = 4 * CPS;
     constexpr int TILE_BYTES = 32 * 4 * H * 4;
     constexpr int IMGC = 128 * 64;             // one (matrix, piece) chunk image: 128 output rows x 32 k fp16
@@ -595,8 +639,10 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_wide_f16_kernel(const char* __
     const int64_t nrounds = (rounds_total - pblock + pblocks - 1) / pblocks;
 
     // one scale for the block's weights: largest magnitude of its 128 rows of both matrices
-    float inv_sw, sw;
-    {
+    float inv_sw = 1.0f, sw = 1.0f;
+    if (WS) {
+        inv_sw = reinterpret_cast<const float*>(wws)[slice];
+    } else {
         float mx = 0.f;
         for (int idx = tid; idx < 2 * 128 * (3 * H / 4); idx += 512) {
             const int mat = idx / (128 * (3 * H / 4)), rem = idx % (128 * (3 * H / 4));
@@ -683,10 +729,20 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_wide_f16_kernel(const char* __
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    // WS: chunk ct's image comes verbatim from the pre-split workspace (32 x 1 KB; chunks of the third gate block: the 16
+    // of their one matrix)
+    auto stage_copy = [&](int ct, int buf) {
+        const int seg = chunk_seg(ct);
+        const char* src = wws + 64 + (int64_t)(slice * NCT + ct) * BUF + lane * 16;
+        const char* dst = smem + buf * BUF;
+        const int first = seg == 3 ? 16 : 0, count = seg < 2 ? 32 : 16;
+        for (int i = first + wv; i < first + count; i += 8) g_copy_to_lds(src + i * 1024, dst + i * 1024);
+    };
     auto chunk = [&](int ct, int64_t tile_next, h16x8 (&xa)[4], h16x8 (&na)[4]) {
         __syncthreads();
         const int cn = (ct + 1) % NCT;
-        stage_load(cn);
+        if (WS) stage_copy(cn, cur ^ 1);
+        else stage_load(cn);
         load_rows(cn == 0 ? tile_next : tile, cn, na);
         __builtin_amdgcn_sched_barrier(0);
         const int seg = chunk_seg(ct);                     // compile-time after unrolling? no: uniform, cheap branches
@@ -695,12 +751,18 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_wide_f16_kernel(const char* __
             if (seg != 3) product(d_m, 0, st, xa[2 * st], xa[2 * st + 1]);
             if (seg != 2) product(d_h, 1, st, xa[2 * st], xa[2 * st + 1]);
         }
-        stage_write(cn, cur ^ 1);
+        if (WS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my part of the next chunk's image has landed
+        else stage_write(cn, cur ^ 1);
         cur ^= 1;
     };
 
-    stage_load(0);
-    stage_write(0, 0);
+    if (WS) {
+        stage_copy(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        stage_load(0);
+        stage_write(0, 0);
+    }
     if (tile >= tiles) tile = tiles - 1;                   // a wave past the end repeats the last tile and stores nothing
     load_rows(tile, 0, a0);
     for (int64_t rd = 0; rd < nrounds; ++rd) {
@@ -947,9 +1009,11 @@ __global__ void __launch_bounds__(512) gru_bwd_dw_f16_kernel(const float* __rest
         }
 }
 
+// pieces | tile scales | pre-split weight images of the dm | dh kernel
+static size_t gru_bwd_f16_dxw_bytes(int H) { return 64 + (size_t)(H / 128) * (4 * H / 32) * (4 * 128 * 64); }
 size_t gru_bwd_f16_workspace_bytes(int64_t V, int H) {
     const int64_t tiles = (V + 31) / 32;
-    return (size_t)tiles * (32 * 4 * H * 4) + (size_t)((tiles + 63) / 64 * 64) * sizeof(float);
+    return (size_t)tiles * (32 * 4 * H * 4) + (size_t)((tiles + 63) / 64 * 64) * sizeof(float) + gru_bwd_f16_dxw_bytes(H);
 }
 
 template <int H>
@@ -959,6 +1023,7 @@ static int launch_gru_bwd_f16_t(const float* dout, const float* m, const float* 
     const int64_t tiles = (V + 31) / 32;
     char* pieces = (char*)workspace;
     float* inv_scale = (float*)(pieces + (size_t)tiles * (32 * 4 * H * 4));
+    char* dxw = (char*)(inv_scale + (tiles + 63) / 64 * 64);             // pre-split weights of the dm | dh kernel
     // dm | dh: streamed weights, 128-column slices; MPNN_GRU_DX_SLICE64=1: 64-column slices (3.85 ms on c4);
     // MPNN_GRU128_SLICED_DX=1: the kernel with resident 32-column slices at H = 128 (4.06 ms)
     const bool kSlicedDx = H == 128 && switches().gru128_sliced_dx;
@@ -969,7 +1034,8 @@ static int launch_gru_bwd_f16_t(const float* dout, const float* m, const float* 
         LdsOptIn opt_in_;
         if (H == 128) opt_in_((const void*)gru_bwd_dx128_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sliced);
         opt_in_((const void*)gru_bwd_dx_stream_f16_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_stream);
-        opt_in_((const void*)gru_bwd_dx_wide_f16_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64);
+        opt_in_((const void*)gru_bwd_dx_wide_f16_kernel<H, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64);
+        opt_in_((const void*)gru_bwd_dx_wide_f16_kernel<H, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64);
         opt_in_((const void*)gru_bwd_dw_f16_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dw);
         return opt_in_.err;
     }();
@@ -998,8 +1064,14 @@ static int launch_gru_bwd_f16_t(const float* dout, const float* m, const float* 
         int64_t pblocks = 256 / NS;
         if (pblocks > rounds) pblocks = rounds;
         pblocks = (pblocks + 7) / 8 * 8;
-        hipLaunchKernelGGL(gru_bwd_dx_wide_f16_kernel<H>, dim3((unsigned)(pblocks * NS)), dim3(512), (size_t)2 * 4 * 128 * 64, s,
-                           pieces, inv_scale, W_ih, W_hh, dm, dh, V);
+        if (!switches().gru_dx_insplit) {                   // default: weights split once per launch, copied global -> LDS
+            hipLaunchKernelGGL(gru_bwd_dx_presplit_kernel<H>, dim3((unsigned)(NS * 4 * (H / 32))), dim3(512), 0, s, W_ih, W_hh, dxw);
+            hipLaunchKernelGGL((gru_bwd_dx_wide_f16_kernel<H, true>), dim3((unsigned)(pblocks * NS)), dim3(512),
+                               (size_t)2 * 4 * 128 * 64, s, pieces, inv_scale, W_ih, W_hh, dm, dh, V, (const char*)dxw);
+        } else {
+            hipLaunchKernelGGL((gru_bwd_dx_wide_f16_kernel<H, false>), dim3((unsigned)(pblocks * NS)), dim3(512),
+                               (size_t)2 * 4 * 128 * 64, s, pieces, inv_scale, W_ih, W_hh, dm, dh, V, (const char*)nullptr);
+        }
     } else {
         constexpr int NS = H / 64;
         const int64_t rounds = (V + 255) / 256;

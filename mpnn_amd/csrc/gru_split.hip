@@ -770,17 +770,79 @@ __global__ void __launch_bounds__(512) gru_update_stream_kernel(
     }
 }
 
-template <int H, bool HAS_MASK, bool SAVE, bool F16 = false>
+// ---- pre-split weights for the streamed wide kernel (fp16 pieces), one workspace per launch ----
+// [0, 64): inverse weight scale of slice s at float s; then the LDS image of (slice, chunk c) at 64 + (slice * H / 32 + c) * 48 KB:
+// [matrix][piece][192 columns = (gate, column of the slice)][32 k] exactly as gru_update_stream_wide_kernel reads it, so a
+// chunk is copied global -> LDS verbatim (global_load_lds_dwordx4), with no vector work and no registers in the kernel.
+template <int H>
+__global__ void __launch_bounds__(512) gru_fwd_presplit_kernel(const float* __restrict__ W_ih, const float* __restrict__ W_hh,
+                                                               char* __restrict__ ws) {
+    constexpr int NCHUNK = H / 32, COLS = 192, IMGC = COLS * 64;
+    __shared__ float redw[8];
+    const int slice = blockIdx.x / NCHUNK, c = blockIdx.x % NCHUNK;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float mx = 0.f;
+    for (int idx = tid; idx < 2 * H * 48; idx += 512) {
+        const int mat = idx / (H * 48), rem = idx % (H * 48);
+        const int kk = rem / 48, q = rem % 48;
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>((mat ? W_hh : W_ih) + (int64_t)kk * 3 * H + (q / 16) * H +
+                                                         64 * slice + 4 * (q % 16));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fabsf(w4[u]));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) redw[wv] = mx;
+    __syncthreads();
+    mx = redw[0];
+#pragma unroll
+    for (int u = 1; u < 8; ++u) mx = fmaxf(mx, redw[u]);
+    float w_sc, w_inv;
+    pow2_scale_of(mx, w_sc, w_inv);
+    if (c == 0 && tid == 0) reinterpret_cast<float*>(ws)[slice] = w_inv;
+    char* img = ws + 64 + (int64_t)(slice * NCHUNK + c) * (4 * IMGC);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int u = tid + 512 * j;
+        const int mat = u / 768, rem = u % 768;
+        const int o = rem / COLS, cl = rem % COLS;
+        const float* W = (mat ? W_hh : W_ih) + (int64_t)(32 * c + 8 * o) * 3 * H + (cl / 64) * H + 64 * slice + (cl % 64);
+        f32x4 x0, x1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x0[i] = W[(int64_t)i * 3 * H]; x1[i] = W[(int64_t)(4 + i) * 3 * H]; }
+        f16x8 ph, pl;
+        split8_f16(x0, x1, w_sc, ph, pl);
+        char* base = img + mat * 2 * IMGC + cl * 64 + ((o ^ ((cl >> 2) & 3)) << 4);
+        *reinterpret_cast<f16x8*>(base) = ph;
+        *reinterpret_cast<f16x8*>(base + IMGC) = pl;
+    }
+}
+
+// one wave copies 1 KB global -> LDS (lane L's 16 bytes land at lds_dst + 16 L); inline assembly so that the compiler
+// neither drains the copy before the next LDS read nor counts it (gru_bwd128_f16.hip has the details)
+__device__ __forceinline__ void w_copy_to_lds(const char* src, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(lds_dst)
+                 : "memory");
+}
+
+template <int H, bool HAS_MASK, bool SAVE, bool F16 = false, bool WS = false>
 __global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
     const float* __restrict__ m, const float* __restrict__ h, const float* __restrict__ mask,
     const float* __restrict__ W_ih, const float* __restrict__ W_hh, const float* __restrict__ b_ih,
-    const float* __restrict__ b_hh, float* __restrict__ out, float* __restrict__ saved, int64_t V) {
+    const float* __restrict__ b_hh, float* __restrict__ out, float* __restrict__ saved, int64_t V,
+    const char* __restrict__ wws) {
+    static_assert(!WS || F16, "pre-split weights are fp16 pieces");
     constexpr int NS = H / 64, NCHUNK = H / 32, COLS = 192;
     constexpr int IMGC = COLS * 64;            // bytes of one (matrix, piece) chunk image: 192 columns x 32 k of 16 bits
     constexpr int NP = F16 ? 2 : 3;            // pieces per operand
     constexpr int BUF = 2 * NP * IMGC;         // 72 KB (bf16x6) / 48 KB (fp16x3)
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][2 matrices][NP pieces][192][32]
     __shared__ float redw[8];
+    __shared__ float bias_s[4][64];            // the slice's gate biases (b_r, b_z, b_in, b_hn): read per tile from LDS --
+                                               // as per-lane global pointers they were loop invariants that got spilled
 
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
     const int slice = jb % NS;                                 // the NS slice blocks of a row group share an XCD
@@ -792,10 +854,19 @@ __global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
     const int64_t rounds_total = (V + 255) / 256;              // a round = 256 rows: every wave its own 32-row tile
     if (pblock >= rounds_total) return;                        // block-uniform
     const int64_t nrounds = (rounds_total - pblock + pblocks - 1) / pblocks;
+    if (tid < 64) {
+        const int fc = 64 * slice + tid;
+        bias_s[0][tid] = b_ih[fc] + b_hh[fc];
+        bias_s[1][tid] = b_ih[H + fc] + b_hh[H + fc];
+        bias_s[2][tid] = b_ih[2 * H + fc];
+        bias_s[3][tid] = b_hh[2 * H + fc];
+    }                                                          // (the first chunk's barrier publishes them)
 
     // F16: one power-of-two scale for the block's weights (its 64 features x 3 gates of both matrices land below 2^15)
     float w_sc = 1.0f, w_inv = 1.0f;
-    if (F16) {
+    if (WS) {
+        w_inv = reinterpret_cast<const float*>(wws)[slice];
+    } else if (F16) {
         float mx = 0.f;
         for (int idx = tid; idx < 2 * H * 48; idx += 512) {    // (matrix, k, 48 float4 of the slice's three gate blocks)
             const int mat = idx / (H * 48), rem = idx % (H * 48);
@@ -848,6 +919,17 @@ __global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
             *reinterpret_cast<bf16x8*>(base) = ph;
             *reinterpret_cast<bf16x8*>(base + IMGC) = pm;
             *reinterpret_cast<bf16x8*>(base + 2 * IMGC) = pl;
+        }
+    };
+    // WS: the chunk's image is copied verbatim from the pre-split workspace, 48 x 1 KB, six per wave
+    auto stage_copy = [&](int c, int buf) {
+        typedef __attribute__((address_space(3))) const char lds_char;
+        const char* src = wws + 64 + (int64_t)(slice * NCHUNK + c) * BUF + lane * 16;
+        const unsigned dst = (unsigned)(uintptr_t)(lds_char*)(smem + buf * BUF);
+#pragma unroll
+        for (int it = 0; it < BUF / 8192; ++it) {
+            const int blk = (BUF / 8192) * wv + it;
+            w_copy_to_lds(src + blk * 1024, dst + blk * 1024);
         }
     };
     // B fragment: column cl = gate*64 + 32*nb + r, k-octet 2*hi + st of the chunk
@@ -914,6 +996,7 @@ __global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
     auto half = [&](int hc, int64_t tile_next, f32x4 (&x)[4], f32x4 (&nx)[4]) {
         const int c = hc >> 1, mat = hc & 1;
         if (mat == 0) __syncthreads();                     // buffer `cur` is complete, `cur ^ 1` is free
+        if (WS && mat == 0) stage_copy((c + 1) % NCHUNK, cur ^ 1);   // lands while this chunk multiplies
         const int hn = (hc + 1) % (2 * NCHUNK);
         load_rows((hn & 1) ? h : m, hn == 0 ? tile_next : tile, hn >> 1, nx);
         const int cn = (c + 1) % NCHUNK;
@@ -926,8 +1009,10 @@ __global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
             const int st = i / 3, gate = i % 3;
             if (i % 3 == 0) {
                 // staging units: 0 and 1 ride on the m half, 2 on the h half
-                if (mat == 0) stage_load1(cn, i / 3);
-                else if (i == 0) stage_load1(cn, 2);
+                if (!WS) {
+                    if (mat == 0) stage_load1(cn, i / 3);
+                    else if (i == 0) stage_load1(cn, 2);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if (F16) split8_f16(x[2 * st], x[2 * st + 1], row_sc, f_h, f_l);
                 else split8(x[2 * st], x[2 * st + 1], a_h, a_m, a_l);
@@ -943,19 +1028,27 @@ __global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
                              bfrag(cur, mat, 2, gate, 1, st));
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (i % 3 == 2) {
+            if (!WS && i % 3 == 2) {
                 if (mat == 0) stage_write1(cur ^ 1, i / 3);
                 else if (i == 2) stage_write1(cur ^ 1, 2);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (mat == 1) cur ^= 1;
+        if (mat == 1) {
+            if (WS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my part of the next chunk's image has landed
+            cur ^= 1;
+        }
     };
 
+    if (WS) {
+        stage_copy(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        stage_load1(0, j);
-        stage_write1(0, j);
+        for (int j = 0; j < 3; ++j) {
+            stage_load1(0, j);
+            stage_write1(0, j);
+        }
     }
     load_rows(m, tile, 0, a0);
     for (int64_t rd = 0; rd < nrounds; ++rd) {
@@ -976,8 +1069,14 @@ __global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
         auto epilogue = [&](auto full_tag) {
             constexpr bool FULL = decltype(full_tag)::value;
             __builtin_amdgcn_sched_barrier(0);
-            const int64_t row0 = tile * 32 + 4 * hi;                   // + 8*(i>>2) + (i&3)
-            const unsigned eo = (unsigned)(4 * hi * H + 64 * slice + r);
+            // the lane offsets are recomputed per tile behind an opaque move: as loop invariants the compiler folded them
+            // into per-lane 64-bit pointers (h + offset, out + offset, mask + lane, ...) that it kept across the K loop and
+            // spilled -- and a reload in here is a scratch access whose s_waitcnt vmcnt(0) drains every load just issued
+            unsigned ln = (unsigned)lane;
+            asm volatile("" : "+v"(ln));
+            const unsigned lr = ln & 31u, h4 = (ln >> 5) << 2;
+            const unsigned eo = h4 * H + 64 * slice + lr, so = h4 * 4 * H + 64 * slice + lr;
+            const int64_t row0 = tile * 32 + h4;                       // + 8*(i>>2) + (i&3)
             const float* hb = h + tile * 32 * H + eo;
             float hv[2][16];
 #pragma unroll
@@ -988,16 +1087,15 @@ __global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
             float mkl = 1.0f;
             if (HAS_MASK) {
                 const int left = FULL ? 32 : (int)(V - tile * 32);
-                mkl = (mask + tile * 32)[(unsigned)(r < left ? r : left - 1)];   // lane j (< 32): mask of the tile's row j
+                mkl = (mask + tile * 32)[lr < (unsigned)left ? lr : (unsigned)(left - 1)];   // lane j (< 32): mask of the tile's row j
             }
             __builtin_amdgcn_sched_barrier(0);
             float* ob = out + tile * 32 * H + eo;
-            float* sb = saved + tile * 32 * 4 * H + (unsigned)(4 * hi * 4 * H + 64 * slice + r);
+            float* sb = saved + tile * 32 * 4 * H + so;
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
-                const int fcol = 64 * slice + 32 * nb + r;             // this lane's output feature
-                const float br = b_ih[fcol] + b_hh[fcol], bz = b_ih[H + fcol] + b_hh[H + fcol];
-                const float bni = b_ih[2 * H + fcol], bnh = b_hh[2 * H + fcol];
+                const float br = bias_s[0][32 * nb + r], bz = bias_s[1][32 * nb + r];      // this lane's output feature
+                const float bni = bias_s[2][32 * nb + r], bnh = bias_s[3][32 * nb + r];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int dr = 8 * (i >> 2) + (i & 3);
@@ -1064,11 +1162,17 @@ static int launch_stream(const float* m, const float* h, const float* mask, cons
     return launch_status("mpnn_gru_update_f32(bf16x6, streamed weights)");
 }
 
+size_t gru_fwd_workspace_bytes(int H) {
+    return (H == 128 || H == 256) ? 64 + (size_t)(H / 64) * (H / 32) * (2 * 4 * 192 * 64 / 2) : 0;
+}
+
 template <int H>
 static int launch_stream_wide(const float* m, const float* h, const float* mask, const float* W_ih, const float* W_hh,
-                         const float* b_ih, const float* b_hh, float* out, float* saved, int64_t V, hipStream_t s) {
+                         const float* b_ih, const float* b_hh, float* out, float* saved, int64_t V, void* workspace,
+                         hipStream_t s) {
     constexpr int NS = H / 64;
     const bool f16 = !switches().gru_fwd_bf16;               // default: two fp16 pieces per operand, row-wise range guards
+    const bool presplit = f16 && workspace != nullptr;       // weights split once per launch, copied global -> LDS
     const size_t lds = f16 ? (size_t)2 * 4 * 192 * 64 : (size_t)2 * 6 * 192 * 64;
     static const hipError_t attr_done = [&] {   // once per process, thread-safe (C++11 static initialisation)
         LdsOptIn opt_in_;
@@ -1081,6 +1185,10 @@ static int launch_stream_wide(const float* m, const float* h, const float* mask,
         opt_in_((const void*)gru_update_stream_wide_kernel<H, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n16);
         opt_in_((const void*)gru_update_stream_wide_kernel<H, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n16);
         opt_in_((const void*)gru_update_stream_wide_kernel<H, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n16);
+        opt_in_((const void*)gru_update_stream_wide_kernel<H, true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n16);
+        opt_in_((const void*)gru_update_stream_wide_kernel<H, true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n16);
+        opt_in_((const void*)gru_update_stream_wide_kernel<H, false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n16);
+        opt_in_((const void*)gru_update_stream_wide_kernel<H, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n16);
         return opt_in_.err;
     }();
     if (attr_done != hipSuccess) return lds_opt_in_failed(attr_done);
@@ -1089,14 +1197,20 @@ static int launch_stream_wide(const float* m, const float* h, const float* mask,
     if (pblocks > rounds) pblocks = rounds;
     pblocks = (pblocks + 7) / 8 * 8;                        // XCD-aware numbering wants groups of 8 row blocks
     const dim3 grid((unsigned)(pblocks * NS)), block(512);
+    const char* wws = (const char*)workspace;
+    if (presplit)
+        hipLaunchKernelGGL(gru_fwd_presplit_kernel<H>, dim3(NS * (H / 32)), dim3(512), 0, s, W_ih, W_hh, (char*)workspace);
 #define MPNN_LAUNCH_WIDE(MASKED, SAVED)                                                                                  \
     do {                                                                                                                 \
-        if (f16)                                                                                                         \
+        if (presplit)                                                                                                    \
+            hipLaunchKernelGGL((gru_update_stream_wide_kernel<H, MASKED, SAVED, true, true>), grid, block, lds, s, m, h, \
+                               mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, wws);                                        \
+        else if (f16)                                                                                                    \
             hipLaunchKernelGGL((gru_update_stream_wide_kernel<H, MASKED, SAVED, true>), grid, block, lds, s, m, h, mask, \
-                               W_ih, W_hh, b_ih, b_hh, out, saved, V);                                                   \
+                               W_ih, W_hh, b_ih, b_hh, out, saved, V, wws);                                              \
         else                                                                                                             \
             hipLaunchKernelGGL((gru_update_stream_wide_kernel<H, MASKED, SAVED>), grid, block, lds, s, m, h, mask, W_ih, \
-                               W_hh, b_ih, b_hh, out, saved, V);                                                         \
+                               W_hh, b_ih, b_hh, out, saved, V, wws);                                                    \
     } while (0)
     if (mask && saved) MPNN_LAUNCH_WIDE(true, true);
     else if (mask) MPNN_LAUNCH_WIDE(true, false);
@@ -1108,15 +1222,16 @@ static int launch_stream_wide(const float* m, const float* h, const float* mask,
 
 // returns 1 when the width has no split-precision path
 int launch_gru_split(const float* m, const float* h, const float* mask, const float* W_ih, const float* W_hh,
-                     const float* b_ih, const float* b_hh, float* out, float* saved, int64_t V, int H, hipStream_t s) {
+                     const float* b_ih, const float* b_hh, float* out, float* saved, int64_t V, int H, void* workspace,
+                     hipStream_t s) {
     if (H == 64) return launch_split<64, 2, 8>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, s);
     // hidden 128: streamed weights with the wide tile (2 output slices) is ~1.5 % ahead of the resident-slice kernel
     // (4 slices) on c4; MPNN_GRU128_SLICED=1 selects the latter
     const bool stream128 = !switches().gru128_sliced;
-    if (H == 128 && stream128) return launch_stream_wide<128>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, s);
+    if (H == 128 && stream128) return launch_stream_wide<128>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, workspace, s);
     if (H == 128) return launch_split128(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, s);
     const bool narrow256 = switches().gru256_narrow;
-    if (H == 256 && !narrow256) return launch_stream_wide<256>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, s);
+    if (H == 256 && !narrow256) return launch_stream_wide<256>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, workspace, s);
     if (H == 256) return launch_stream<256>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, s);
     return 1;
 }

@@ -221,9 +221,12 @@ def gru_update_raw(m, h, mask, W_ih, W_hh, b_ih, b_hh, save):
     V, H = int(h.shape[0]), int(h.shape[1])
     out = _empty((V, H), h)
     saved = _empty((V, 4 * H), h) if save else None
+    ws_bytes = 0 if os.environ.get("MPNN_GRU_FWD_NOWS") else lib.mpnn_gru_fwd_workspace_bytes(V, H)   # A/B: in-kernel weight split
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=h.device) if ws_bytes else None
     _lib.check(_timed("gru_update", lambda: lib.mpnn_gru_update_f32(
         _lib.fptr(m), _lib.fptr(h), _lib.fptr(mask), _lib.fptr(W_ih), _lib.fptr(W_hh), _lib.fptr(b_ih),
-        _lib.fptr(b_hh), _lib.fptr(out), _lib.fptr(saved), V, H, _lib.stream())), "mpnn_gru_update_f32")
+        _lib.fptr(b_hh), _lib.fptr(out), _lib.fptr(saved), _lib.ptr(ws), ws_bytes, V, H, _lib.stream())),
+        "mpnn_gru_update_f32")
     return out, saved
 
 

@@ -53,7 +53,7 @@ def test_rejected_calls_report_an_error_string():
     lib = _lib.load()
     rc = lib.mpnn_segsum_f32(None, None, None, None, 4, 8, None)
     assert rc == -1 and b"mpnn_segsum_f32" in lib.mpnn_last_error_string()
-    rc = lib.mpnn_gru_update_f32(None, None, None, None, None, None, None, None, None, 4, 100000, None)
+    rc = lib.mpnn_gru_update_f32(None, None, None, None, None, None, None, None, None, None, 0, 4, 100000, None)
     assert rc == -1
     assert lib.mpnn_edge_message_f32(None, None, None, None, None, None, None, 0, 0, 0, 8, 8, None) == 0   # empty
 
