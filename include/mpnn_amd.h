@@ -159,7 +159,7 @@ int mpnn_message_aggregate_f32(const float* h, const float* A, const int32_t* ti
                                int64_t V, int64_t num_tiles, int K, int nf, int mf, void* stream);
 
 /*
- * The same fused product at nf = mf in {128, 256} (and 64) for molecules of up to
+ * The same fused product at nf = mf in {128, 256} for molecules of up to
  * mpnn_message_aggregate_wide_tile_atoms() = 256 atoms: typed aggregate-then-contract,
  *   out[i, :] = sum_k A[k] . S_k[i],   S_k[i] = sum_{e in row i, type(e) = k} h[src[e], :]
  * replaces: mpnn_functions/message/edge_network.py:50-51 (edge_embed.bmm(...)), i.e. :40,52 composed with
@@ -185,18 +185,6 @@ int mpnn_message_aggregate_wide_f32(const float* h, const float* A, const int32_
                                     const int32_t* blk_off, const int16_t* slots, float* out, void* workspace,
                                     size_t workspace_bytes, int64_t V, int64_t num_tiles, int K, int nf, int mf,
                                     void* stream);
-
-/*
- * Weight gradient of mpnn_message_aggregate_f32 (the width-64 tile kernel), on its tile plan, dagg and h each read once:
- *   dA[k] += sum_{e of type k} dagg[dst[e], :] (x) h[src[e], :]        (K x mf x nf, zeroed by the caller)
- * replaces: the autograd of edge_network.py:50-51 with respect to the edge matrices (the dA part of
- * mpnn_edge_message_agg_bwd_da_f32, which gathers both rows per edge from HBM).
- *   tile_rtk[T][8K+1]  first row-tile of every (block, type) of the tile, then the tile's end
- * Same limits as mpnn_message_aggregate_f32 (nf = mf = 64, K <= 4, unit weights, no gate).
- */
-int mpnn_message_aggregate_bwd_da_f32(const float* dagg, const float* h, const int32_t* tile_rec, const int32_t* tile_atom,
-                                      const int32_t* tile_rtk, const int32_t* slots, float* dA,
-                                      int64_t V, int64_t num_tiles, int K, int nf, int mf, void* stream);
 
 /*
  * BiLiniearEdgeNetwork message on the dense padded batch: out[b,i,j,k] = sum_{a,c} afm[b,j,a] T[b,i,j][a,k,c] afm[b,i,c]

@@ -556,11 +556,6 @@ __global__ void __launch_bounds__(256) gru_gate_grad_kernel(const float* __restr
 // resident-matrix dx path (edge_message.hip); returns 1 when the shape is not covered
 int launch_message_dx_resident(const float* dmsg, const float* A, const int32_t* order, const int32_t* type_ptr,
                                float* dx, int64_t E, int K, int nf, int mf, hipStream_t s);
-// H = 128: dm / dh on the bf16x6 column-sliced kernel (gru_bwd128.hip)
-int launch_gru_bwd_dx128(const float* ws, const float* W_ih, const float* W_hh, float* dm, float* dh, int64_t V,
-                         hipStream_t s);
-int launch_gru_bwd_dw128(const float* m, const float* h, const float* ws, float* dW_ih, float* dW_hh, float* db_ih,
-                         float* db_hh, int64_t V, hipStream_t s);
 // nf = mf = 128 weight gradient on the bf16x6 pipe (edge_da128.hip)
 int launch_edge_da_split128(const float* Y, const float* h, const int32_t* src, const int32_t* dst, const float* w,
                             const int32_t* order, const int32_t* type_ptr, const float* gate, float* dA, int64_t E,
@@ -571,20 +566,10 @@ int launch_edge_da_split256(const float* Y, const float* h, const int32_t* src, 
 int launch_edge_da_split64(const float* Y, const float* h, const int32_t* src, const int32_t* dst, const float* w,
                            const int32_t* order, const int32_t* type_ptr, const float* gate, float* dA, int64_t E,
                            int K, hipStream_t s);
-static bool da64_split() {     // default since the index pipeline; MPNN_DA64_DIRECT=1 selects the fp32 register-direct kernel
-    const bool v = !switches().da64_direct;
-    return v;
-}
 static bool math_fp32_only() {
     const bool v = switches().math_fp32;
     return v;
 }
-int launch_gru_bwd_dx_stream256(const float* ws, const float* W_ih, const float* W_hh, float* dm, float* dh, int64_t V,
-                                hipStream_t s);
-int launch_gru_bwd_dx_stream128(const float* ws, const float* W_ih, const float* W_hh, float* dm, float* dh, int64_t V,
-                                hipStream_t s);
-int launch_gru_bwd_dw256(const float* m, const float* h, const float* ws, float* dW_ih, float* dW_hh, float* db_ih,
-                         float* db_hh, int64_t V, hipStream_t s);
 int launch_edge_pertype(int mode, const float* h, const float* A, const int32_t* src, const int32_t* order,
                         const int32_t* type_ptr, const float* gate, const float* dmsg, float* out, float* dA, int K,
                         int nf, int mf, hipStream_t s);
@@ -623,7 +608,7 @@ extern "C" int mpnn_edge_message_bwd_f32(const float* h, const float* A, const i
                                            nf, s, "mpnn_edge_message_bwd_f32(dx)");
         if (rc) return rc;
     }
-    if (dA && mf == 64 && nf == 64 && K <= 64 && da64_split() && !math_fp32_only()) {
+    if (dA && mf == 64 && nf == 64 && K <= 64 && !math_fp32_only()) {
         rc = launch_edge_da_split64(dmsg, h, src, nullptr, nullptr, order, type_ptr, gate, dA, E, K, s);
     } else if (dA && mf == 64 && nf == 64 && K <= 64) {
         int64_t gx = 512;                               // 2 blocks of 8 waves per CU
@@ -668,10 +653,8 @@ int launch_gru_bwd_f16_wide(const float* dout, const float* m, const float* h, c
 extern "C" size_t mpnn_gru_bwd_workspace_bytes(int64_t V, int H) {
     if (V < 0 || H <= 0) return 0;
     if (H == 64) return 16;                                               // one kernel, gate gradients stay in LDS
-    if ((H == 128 || H == 256) && !switches().math_fp32) {                // fp16 pieces per 32-atom tile + tile scales
-        const size_t a = (size_t)V * 4 * H * sizeof(float), b = gru_bwd_f16_workspace_bytes(V, H);
-        return a > b ? a : b;                                              // (a: the compact float layout of MPNN_GRU_BWD_BF16)
-    }
+    if ((H == 128 || H == 256) && !switches().math_fp32)                  // fp16 pieces per 32-atom tile, tile scales,
+        return gru_bwd_f16_workspace_bytes(V, H);                         // pre-split weights of the dm | dh kernel
     return (size_t)V * 6 * H * sizeof(float);                            // generic widths: (dgi | dgh)
 }
 
@@ -697,26 +680,11 @@ extern "C" int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const 
     if (g > 256 * 16) g = 256 * 16;
     const bool fp32_only = switches().math_fp32;
     int rc;
-    // hidden 128 / 256: gate gradients as fp16 pieces, split once (gru_bwd128_f16.hip); MPNN_GRU_BWD_BF16=1 keeps the three
-    // bf16x6 kernels below
-    if ((H == 128 || H == 256) && !fp32_only && !switches().gru_bwd_bf16)
+    // hidden 128 / 256: gate gradients as fp16 pieces, split once (gru_bwd128_f16.hip); MPNN_GRU_MATH=fp32 and other
+    // widths: elementwise gate gradients into a (V, 6H) workspace + generic fp32 contractions below
+    if ((H == 128 || H == 256) && !fp32_only)
         return launch_gru_bwd_f16_wide(dout, m, h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, workspace, V, H,
                                        s);
-    if ((H == 128 || H == 256) && !fp32_only) {
-        hipLaunchKernelGGL(gru_gate_grad_kernel<true>, dim3((unsigned)g), dim3(256), 0, s, dout, h, mask, saved, ws, dh, V,
-                           H);
-        rc = launch_status("mpnn_gru_update_bwd_f32(gates)");
-        if (rc) return rc;
-        // hidden 128: the streamed kernel (2 output slices, 32 x 64 tile per wave) beats the resident-slice one
-        // (4 slices) by ~1 ms on c4; MPNN_GRU128_SLICED_DX=1 selects the latter
-        const bool sliced_dx = switches().gru128_sliced_dx;
-        if (H == 256) rc = launch_gru_bwd_dx_stream256(ws, W_ih, W_hh, dm, dh, V, s);
-        else if (!sliced_dx) rc = launch_gru_bwd_dx_stream128(ws, W_ih, W_hh, dm, dh, V, s);
-        else rc = launch_gru_bwd_dx128(ws, W_ih, W_hh, dm, dh, V, s);
-        if (rc) return rc;
-        if (H == 256) return launch_gru_bwd_dw256(m, h, ws, dW_ih, dW_hh, db_ih, db_hh, V, s);
-        return launch_gru_bwd_dw128(m, h, ws, dW_ih, dW_hh, db_ih, db_hh, V, s);
-    }
     hipLaunchKernelGGL(gru_gate_grad_kernel<false>, dim3((unsigned)g), dim3(256), 0, s, dout, h, mask, saved, ws, dh, V,
                        H);
     rc = launch_status("mpnn_gru_update_bwd_f32(gates)");
@@ -790,7 +758,7 @@ extern "C" int mpnn_edge_message_agg_bwd_da_f32(const float* dagg, const float* 
                            h, nf, order, type_ptr, K, src, dst, w, gate, dA, (float*)nullptr, E);
         return launch_status("mpnn_edge_message_agg_bwd_da_f32(128)");
     }
-    if (da64_split() && !math_fp32_only())
+    if (!math_fp32_only())
         return launch_edge_da_split64(dagg, h, src, dst, w, order, type_ptr, gate, dA, E, K, (hipStream_t)stream);
     int64_t gx = 512;
     const int64_t need = ceil_div(ceil_div(E, 32) + K, 8);

@@ -20,18 +20,6 @@ const Switches& switches() {
         Switches s;
         const char* m = getenv("MPNN_GRU_MATH");
         s.math_fp32 = m && !strcmp(m, "fp32");
-        s.da64_direct = getenv("MPNN_DA64_DIRECT") != nullptr;
-        s.gru128_sliced = getenv("MPNN_GRU128_SLICED") != nullptr;
-        s.gru128_sliced_dx = getenv("MPNN_GRU128_SLICED_DX") != nullptr;
-        s.gru256_narrow = getenv("MPNN_GRU256_NARROW") != nullptr;
-        s.gru_bwd_uniform = getenv("MPNN_GRU_BWD_UNIFORM") != nullptr;
-        s.gru_bwd_fp32tile = getenv("MPNN_GRU_BWD_FP32TILE") != nullptr;
-        s.gru_fwd_bf16 = getenv("MPNN_GRU_FWD_BF16") != nullptr;
-        s.gru_bwd_bf16 = getenv("MPNN_GRU_BWD_BF16") != nullptr;
-        s.gru_dx_slice64 = getenv("MPNN_GRU_DX_SLICE64") != nullptr;
-        s.gru_dx_insplit = getenv("MPNN_GRU_DX_INSPLIT") != nullptr;
-        const char* v = getenv("MPNN_SEGSUM_VARIANT");
-        s.segsum_variant = v ? atoi(v) : 3;
         return s;
     }();
     return sw;

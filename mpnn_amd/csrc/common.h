@@ -36,21 +36,10 @@ inline int lds_opt_in_failed(hipError_t e) {
     return MPNN_ELAUNCH;
 }
 
-// Environment switches (A/B alternates of the default kernels; README "Switches"), read ONCE per process by
+// Environment switch (README "Switches"), read ONCE per process by
 // mpnn_init() or by the first call that needs one (thread-safe static initialisation in capi.hip).
 struct Switches {
-    bool math_fp32;          // MPNN_GRU_MATH=fp32: dense contractions on the fp32 matrix pipe
-    bool da64_direct;        // MPNN_DA64_DIRECT: fp32 register-direct dA kernel at width 64
-    bool gru128_sliced;      // MPNN_GRU128_SLICED: resident-slice GRU forward at width 128
-    bool gru128_sliced_dx;   // MPNN_GRU128_SLICED_DX: resident-slice dm/dh kernel at width 128
-    bool gru256_narrow;      // MPNN_GRU256_NARROW: 32-feature wave tiles in the streamed width-256 GRU
-    bool gru_bwd_uniform;    // MPNN_GRU_BWD_UNIFORM: all-waves-identical GRU backward at width 64
-    bool gru_bwd_fp32tile;   // MPNN_GRU_BWD_FP32TILE: fp32 LDS tile in the GRU backward at width 64
-    bool gru_fwd_bf16;       // MPNN_GRU_FWD_BF16: GRU forward (64 / 128 / 256) on three bf16 pieces instead of two row-guarded fp16 pieces
-    bool gru_bwd_bf16;       // MPNN_GRU_BWD_BF16: width-64 GRU backward on three bf16 pieces (gru_bwd_presplit.hip) instead of two fp16 pieces (gru_bwd_f16.hip)
-    bool gru_dx_slice64;     // MPNN_GRU_DX_SLICE64: width-128/256 dm|dh on 64-column slices instead of 128-column ones
-    bool gru_dx_insplit;     // MPNN_GRU_DX_INSPLIT: the 128-column dm|dh kernel splits its weight chunks itself (no pre-split workspace)
-    int segsum_variant;      // MPNN_SEGSUM_VARIANT: 1 = one atom per lane group, 2 = cached loads/stores, 3 = default
+    bool math_fp32;          // MPNN_GRU_MATH=fp32: dense contractions on the fp32 matrix pipe (strict fp32 MFMA, no operand splits)
 };
 const Switches& switches();
 

@@ -28,7 +28,6 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 namespace {
 constexpr int GH = 128;
 constexpr int G_IMG = 32 * 256;                        // bytes of one [32 rows][128 x fp16] image
-constexpr int G_TILE_BYTES = 32 * 4 * GH * 4;          // one tile of the piece workspace: 64 KB
 
 
 template <int SMAX>
@@ -206,368 +205,10 @@ __global__ void __launch_bounds__(512) gru_gate_f16_kernel(const float* __restri
     }
 }
 
-// ------------------------------------------------------------------------------------------------------ dm | dh
-// Column-sliced like gru_bwd_dx128_kernel: a block keeps the two fp16 images of 32 rows of W_ih and of W_hh in LDS
-// (image[mat][piece][n][k], 16-byte chunks XOR-swizzled by the row), four blocks per row tile on one XCD; a wave walks
-// 32-atom tiles and streams the tile's 32 x 2 pre-split A fragments through a register ring.
-__global__ void __launch_bounds__(512) gru_bwd_dx128_f16_kernel(const char* __restrict__ pieces,
-                                                                const float* __restrict__ inv_scale,
-                                                                const float* __restrict__ W_ih,
-                                                                const float* __restrict__ W_hh, float* __restrict__ dm,
-                                                                float* __restrict__ dh, int64_t V) {
-    constexpr int H = GH, KC = 3 * H;
-    constexpr int ROWB = 2 * KC;               // one image row = one weight row (3H gate columns) in fp16
-    constexpr int IMG = 32 * ROWB;             // one (matrix, piece) image: 32 output columns
-    constexpr int NW = 8;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 matrices][2 pieces][32][384] fp16
-    __shared__ float redw[NW];
-
-    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    const int slice = jb & 3;
-    const int pblock = (jb >> 2) * 8 + xcd, pblocks = gridDim.x >> 2;
-    const int c0 = slice * 32;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-
-    float mx = 0.f;
-    for (int idx = tid; idx < 2 * 32 * (KC / 4); idx += 64 * NW) {
-        const int mat = idx / (32 * (KC / 4));
-        const int rem = idx % (32 * (KC / 4));
-        const int n = rem / (KC / 4), q = rem % (KC / 4);
-        const float* W = mat == 0 ? W_ih : W_hh;
-        const f32x4 w4 = *reinterpret_cast<const f32x4*>(W + (int64_t)(c0 + n) * KC + 4 * q);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fabsf(w4[u]));
-    }
-    mx = g_wave_max(mx);
-    if (lane == 0) redw[wv] = mx;
-    __syncthreads();
-    mx = redw[0];
-#pragma unroll
-    for (int u = 1; u < NW; ++u) mx = fmaxf(mx, redw[u]);
-    float sw, inv_sw;
-    g_guard_scale<30>(mx, sw, inv_sw);
-    for (int idx = tid; idx < 2 * 32 * (KC / 4); idx += 64 * NW) {
-        const int mat = idx / (32 * (KC / 4));
-        const int rem = idx % (32 * (KC / 4));
-        const int n = rem / (KC / 4), q = rem % (KC / 4);
-        const float* W = mat == 0 ? W_ih : W_hh;
-        const f32x4 w4 = *reinterpret_cast<const f32x4*>(W + (int64_t)(c0 + n) * KC + 4 * q);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = 4 * q + u;
-            const float a = w4[u] * sw;
-            const _Float16 ph = (_Float16)a;
-            const _Float16 pl = (_Float16)(a - (float)ph);
-            const int off = n * ROWB + (((k >> 3) ^ (n & 15)) << 4) + ((k & 7) << 1);
-            *reinterpret_cast<_Float16*>(smem + (mat * 2 + 0) * IMG + off) = ph;
-            *reinterpret_cast<_Float16*>(smem + (mat * 2 + 1) * IMG + off) = pl;
-        }
-    }
-    __syncthreads();
-
-    const int r = lane & 31, hi = lane >> 5;
-    const int64_t tiles = (V + 31) / 32;
-    const int64_t stride = (int64_t)pblocks * NW;
-    int64_t t = (int64_t)pblock * NW + wv;
-    if (t >= tiles) return;
-
-    auto bfrag = [&](int mat, int piece, int chunk) {
-        return *reinterpret_cast<const h16x8*>(smem + (mat * 2 + piece) * IMG + r * ROWB + ((chunk ^ (r & 15)) << 4));
-    };
-    // the tile's A fragments: (kstep, piece) at 1 KB steps, this lane's 16 bytes
-    constexpr int AHEAD = 8;                   // ring slots: ksteps are fetched six to seven ahead (12-14 KB per wave in flight)
-    h16x8 ring[AHEAD][2];
-    auto load_step = [&](int64_t tile, int ks, h16x8 (&f)[2]) {
-        const char* p = pieces + tile * (int64_t)G_TILE_BYTES + ks * 2048 + r * 32 + hi * 16;
-        f[0] = *reinterpret_cast<const h16x8*>(p);
-        f[1] = *reinterpret_cast<const h16x8*>(p + 1024);
-    };
-    // weight fragments of a PAIR of ksteps (2 pp, 2 pp + 1), fetched from LDS one pair ahead of the MFMAs that use them:
-    // segments dar, daz feed both products (4 fragments per kstep), dan only dm, dnh only dh (2 per kstep)
-    h16x8 Bf[2][8];
-    auto load_b = [&](int pp, h16x8 (&B)[8]) {
-        const int g = pp >> 2;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int ks = 2 * pp + e;
-            const int chunk = 16 * (g == 3 ? 2 : g) + 2 * (ks & 7) + hi;
-            if (g < 2) {
-                B[4 * e + 0] = bfrag(0, 0, chunk);
-                B[4 * e + 1] = bfrag(0, 1, chunk);
-                B[4 * e + 2] = bfrag(1, 0, chunk);
-                B[4 * e + 3] = bfrag(1, 1, chunk);
-            } else {
-                B[4 * e + 0] = bfrag(g - 2, 0, chunk);
-                B[4 * e + 1] = bfrag(g - 2, 1, chunk);
-            }
-        }
-    };
-#pragma unroll
-    for (int ks = 0; ks < AHEAD - 2; ++ks) load_step(t, ks, ring[ks]);
-    load_b(0, Bf[0]);
-    for (; t < tiles; t += stride) {
-        const int64_t tn = t + stride < tiles ? t + stride : t;
-        const float un = inv_scale[t] * inv_sw;
-        // even / odd ksteps of a pair go to different accumulators: no MFMA accumulates into its predecessor
-        f32x16 d_m, d_h, e_m, e_h;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { d_m[i] = 0.f; d_h[i] = 0.f; e_m[i] = 0.f; e_h[i] = 0.f; }
-#pragma unroll
-        for (int pp = 0; pp < 16; ++pp) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int kl = 2 * pp + e + AHEAD - 2;
-                if (kl < 32) load_step(t, kl, ring[kl % AHEAD]);
-                else load_step(tn, kl - 32, ring[kl % AHEAD]);
-            }
-            load_b((pp + 1) & 15, Bf[(pp + 1) & 1]);       // pair 0 of the next tile at pp = 15: same weights
-            __builtin_amdgcn_sched_barrier(0);
-            const int g = pp >> 2;
-            const h16x8(&B)[8] = Bf[pp & 1];
-            const h16x8 a0h = ring[(2 * pp) % AHEAD][0], a0l = ring[(2 * pp) % AHEAD][1];
-            const h16x8 a1h = ring[(2 * pp + 1) % AHEAD][0], a1l = ring[(2 * pp + 1) % AHEAD][1];
-            if (g < 2) {
-                d_m = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, B[0], d_m, 0, 0, 0);
-                d_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, B[2], d_h, 0, 0, 0);
-                e_m = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, B[4], e_m, 0, 0, 0);
-                e_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, B[6], e_h, 0, 0, 0);
-                d_m = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, B[1], d_m, 0, 0, 0);
-                d_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, B[3], d_h, 0, 0, 0);
-                e_m = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, B[5], e_m, 0, 0, 0);
-                e_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, B[7], e_h, 0, 0, 0);
-                d_m = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, B[0], d_m, 0, 0, 0);
-                d_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, B[2], d_h, 0, 0, 0);
-                e_m = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, B[4], e_m, 0, 0, 0);
-                e_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, B[6], e_h, 0, 0, 0);
-            } else {
-                f32x16& d = g == 2 ? d_m : d_h;
-                f32x16& ee = g == 2 ? e_m : e_h;
-                d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, B[0], d, 0, 0, 0);
-                ee = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, B[4], ee, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, B[1], d, 0, 0, 0);
-                ee = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, B[5], ee, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, B[0], d, 0, 0, 0);
-                ee = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, B[4], ee, 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        const int col = c0 + r;
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            float prev[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int64_t row = t * 32 + 8 * g4 + 4 * hi + u;
-                if (row >= V) row = V - 1;
-                prev[u] = dh[row * H + col];                      // dout*mask*z from the gate-gradient kernel
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = 4 * g4 + u;
-                const int64_t row = t * 32 + 8 * g4 + 4 * hi + u;
-                if (row < V) {
-                    dm[row * H + col] = (d_m[i] + e_m[i]) * un;
-                    dh[row * H + col] = (d_h[i] + e_h[i]) * un + prev[u];
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------- dm | dh, weights streamed
-// gru_bwd_dx_stream_kernel (gru_bwd128.hip) on fp16 pieces: a block owns 64 output features of dm and of dh (H / 64
-// slice blocks per row group instead of H / 32), a round = 256 rows (every wave its own 32-row tile, 32 x 64 of dm and
-// of dh in registers), the contraction runs over 64-wide chunks of one gate block; all threads split the NEXT chunk of
-// the block's W_ih / W_hh rows (two fp16 pieces behind one scale per block) into a double-buffered LDS image while the
-// waves multiply the current one.  The A operand is the pre-split workspace: four (kstep, piece) fragment pairs per
-// chunk, fetched one chunk ahead, no vector work.
-template <int H>
-__global__ void __launch_bounds__(512) gru_bwd_dx_stream_f16_kernel(const char* __restrict__ pieces,
-                                                                    const float* __restrict__ inv_scale,
-                                                                    const float* __restrict__ W_ih,
-                                                                    const float* __restrict__ W_hh, float* __restrict__ dm,
-                                                                    float* __restrict__ dh, int64_t V) {
-    constexpr int NS = H / 64, CPS = H / 64, NCT = 3 * CPS;
-    constexpr int TILE_BYTES = 32 * 4 * H * 4;
-    constexpr int IMGC = 64 * 128;             // one (matrix, piece) chunk image: 64 output rows x 64 k fp16
-    constexpr int BUF = 4 * IMGC;              // 32 KB
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ float redw[8];
-
-    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    const int slice = jb % NS;
-    const int pblock = (jb / NS) * 8 + xcd, pblocks = gridDim.x / NS;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, hi = lane >> 5;
-
-    const int64_t rounds_total = (V + 255) / 256;              // a round = 256 rows: every wave its own 32-row tile
-    if (pblock >= rounds_total) return;
-    const int64_t nrounds = (rounds_total - pblock + pblocks - 1) / pblocks;
-
-    // one scale for the block's weights: largest magnitude of its 64 rows of both matrices
-    float inv_sw, sw;
-    {
-        float mx = 0.f;
-        for (int idx = tid; idx < 2 * 64 * (3 * H / 4); idx += 512) {
-            const int mat = idx / (64 * (3 * H / 4)), rem = idx % (64 * (3 * H / 4));
-            const f32x4 w4 = *reinterpret_cast<const f32x4*>((mat ? W_hh : W_ih) + (int64_t)(64 * slice) * 3 * H + 4 * rem);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fabsf(w4[u]));
-        }
-        mx = g_wave_max(mx);
-        if (lane == 0) redw[wv] = mx;
-        __syncthreads();
-        mx = redw[0];
-#pragma unroll
-        for (int u = 1; u < 8; ++u) mx = fmaxf(mx, redw[u]);
-        g_guard_scale<30>(mx, sw, inv_sw);
-    }
-
-    // staging unit = (matrix, output row n, k-octet): 1024 units, two per thread, 32 contiguous bytes each
-    const float* wsrc[2];
-    int ldst[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int u = tid + 512 * j;
-        const int mat = u / 512, rem = u % 512;
-        const int n = rem / 8, o = rem % 8;
-        wsrc[j] = (mat ? W_hh : W_ih) + (int64_t)(64 * slice + n) * 3 * H + 8 * o;
-        ldst[j] = mat * 2 * IMGC + n * 128 + ((o ^ ((n >> 1) & 7)) << 4);
-    }
-    f32x4 raw[2][2];
-    auto stage_load = [&](int ct) {                        // chunk ct = gate block ct / CPS, 64 columns at 64*(ct % CPS)
-        const int off = (ct / CPS) * H + 64 * (ct % CPS);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            raw[j][0] = *reinterpret_cast<const f32x4*>(wsrc[j] + off);
-            raw[j][1] = *reinterpret_cast<const f32x4*>(wsrc[j] + off + 4);
-        }
-    };
-    auto stage_write = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            h16x8 ph, pl;
-            g_split8(raw[j][0], raw[j][1], sw, ph, pl);
-            char* base = smem + buf * BUF + ldst[j];
-            *reinterpret_cast<h16x8*>(base) = ph;
-            *reinterpret_cast<h16x8*>(base + IMGC) = pl;
-        }
-    };
-    // k-octet of the chunk that step st of lane half hi multiplies: columns 16 st + 8 hi ... of the chunk
-    auto bfrag = [&](int buf, int mat, int piece, int nb, int st) {
-        const int n = 32 * nb + r;
-        const int o = 2 * st + hi;
-        return *reinterpret_cast<const h16x8*>(smem + buf * BUF + (mat * 2 + piece) * IMGC + n * 128 +
-                                               ((o ^ ((n >> 1) & 7)) << 4));
-    };
-    // this lane's four (hi, lo) fragment pairs of chunk cc of gradient segment `seg` for row tile `tile`
-    auto load_rows = [&](int64_t tile, int seg, int cc, h16x8 (&f)[8]) {
-        const char* p = pieces + tile * (int64_t)TILE_BYTES + (seg * (H / 16) + 4 * cc) * 2048 + r * 32 + hi * 16;
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            f[2 * st] = *reinterpret_cast<const h16x8*>(p + st * 2048);
-            f[2 * st + 1] = *reinterpret_cast<const h16x8*>(p + st * 2048 + 1024);
-        }
-    };
-
-    f32x16 d_m[2], d_h[2];                                 // 32 rows x 64 features of dm and of dh per wave
-    h16x8 a0[8], a1[8], b0[8], b1[8];                      // operand of dm (a*) and of dh (b*, only in the n block)
-    int cur = 0;
-    int64_t tile = (int64_t)pblock * 8 + wv;
-    const int64_t tiles = (V + 31) / 32;
-
-    auto chunk = [&](int ct, int64_t tile_next, h16x8 (&xa)[8], h16x8 (&xb)[8], h16x8 (&na)[8], h16x8 (&nb_)[8]) {
-        __syncthreads();
-        const int cn = (ct + 1) % NCT;
-        const int gn = cn / CPS;
-        stage_load(cn);
-        load_rows(cn == 0 ? tile_next : tile, gn, cn % CPS, na);
-        if (gn == 2) load_rows(tile, 3, cn % CPS, nb_);    // dnh (never the first chunk of a round)
-        __builtin_amdgcn_sched_barrier(0);
-        const bool shared = ct / CPS < 2;
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            const h16x8 ah = xa[2 * st], al = xa[2 * st + 1];
-            const h16x8 bh = shared ? ah : xb[2 * st], bl = shared ? al : xb[2 * st + 1];
-            {
-                const h16x8 w0h = bfrag(cur, 0, 0, 0, st), w0l = bfrag(cur, 0, 1, 0, st);
-                const h16x8 w1h = bfrag(cur, 0, 0, 1, st), w1l = bfrag(cur, 0, 1, 1, st);
-                d_m[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, w0h, d_m[0], 0, 0, 0);
-                d_m[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, w1h, d_m[1], 0, 0, 0);
-                d_m[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w0l, d_m[0], 0, 0, 0);
-                d_m[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w1l, d_m[1], 0, 0, 0);
-                d_m[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w0h, d_m[0], 0, 0, 0);
-                d_m[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w1h, d_m[1], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                const h16x8 w0h = bfrag(cur, 1, 0, 0, st), w0l = bfrag(cur, 1, 1, 0, st);
-                const h16x8 w1h = bfrag(cur, 1, 0, 1, st), w1l = bfrag(cur, 1, 1, 1, st);
-                d_h[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, w0h, d_h[0], 0, 0, 0);
-                d_h[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, w1h, d_h[1], 0, 0, 0);
-                d_h[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, w0l, d_h[0], 0, 0, 0);
-                d_h[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, w1l, d_h[1], 0, 0, 0);
-                d_h[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, w0h, d_h[0], 0, 0, 0);
-                d_h[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, w1h, d_h[1], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        stage_write(cur ^ 1);
-        cur ^= 1;
-    };
-
-    stage_load(0);
-    stage_write(0);
-    if (tile >= tiles) tile = tiles - 1;                   // a wave past the end repeats the last tile and stores nothing
-    load_rows(tile, 0, 0, a0);
-    for (int64_t rd = 0; rd < nrounds; ++rd) {
-        int64_t tile_next = rd + 1 < nrounds ? (int64_t)(pblock + (rd + 1) * pblocks) * 8 + wv : tile;
-        if (tile_next >= tiles) tile_next = tiles - 1;
-        const bool live_tile = (int64_t)(pblock + rd * pblocks) * 8 + wv < tiles;
-        const float un = inv_scale[tile] * inv_sw;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { d_m[0][i] = 0.f; d_m[1][i] = 0.f; d_h[0][i] = 0.f; d_h[1][i] = 0.f; }
-#pragma unroll 1
-        for (int ct = 0; ct < NCT; ct += 2) {
-            chunk(ct, tile_next, a0, b0, a1, b1);
-            chunk(ct + 1, tile_next, a1, b1, a0, b0);
-        }
-        if (live_tile) {
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                const int fcol = 64 * slice + 32 * nb + r;
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    float prev[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        int64_t row = tile * 32 + 8 * g4 + 4 * hi + u;
-                        if (row >= V) row = V - 1;
-                        prev[u] = dh[row * H + fcol];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int i = 4 * g4 + u;
-                        const int64_t row = tile * 32 + 8 * g4 + 4 * hi + u;
-                        if (row < V) {
-                            dm[row * H + fcol] = d_m[nb][i] * un;
-                            dh[row * H + fcol] = d_h[nb][i] * un + prev[u];
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        tile = tile_next;
-    }
-}
-
 // ------------------------------------------------------------------ dm | dh, weights streamed, 128-column slices
-// The kernel above re-reads the piece workspace once per 64-column slice (2x at H = 128, 4x at H = 256: 80 GB on c5,
-// which is what its 15.8 ms are).  Here a block owns 128 output features of dm and of dh -- a wave 32 rows x 128 features
-// of both, eight accumulators -- so the pieces are read H / 128 times.  What pays for the registers: the contraction is
+// A block owns 128 output features of dm and of dh -- a wave 32 rows x 128 features of both, eight accumulators -- so the
+// piece workspace is read H / 128 times (a 64-column variant read it twice as often: 80 GB on c5, 15.8 ms; removed in
+// round 3 together with a resident 32-column-slice variant).  What pays for the registers: the contraction is
 // cut into 32-wide chunks (two K = 16 steps; A operand 16 registers per set instead of 32), and the third gate block is
 // walked twice, once as (dan, W_ih) -> dm and once as (dnh, W_hh) -> dh, so that no second operand set is ever live.
 // ---- pre-split weights of the 128-column dm | dh kernel: one workspace region per launch ----
@@ -1024,17 +665,9 @@ static int launch_gru_bwd_f16_t(const float* dout, const float* m, const float* 
     char* pieces = (char*)workspace;
     float* inv_scale = (float*)(pieces + (size_t)tiles * (32 * 4 * H * 4));
     char* dxw = (char*)(inv_scale + (tiles + 63) / 64 * 64);             // pre-split weights of the dm | dh kernel
-    // dm | dh: streamed weights, 128-column slices; MPNN_GRU_DX_SLICE64=1: 64-column slices (3.85 ms on c4);
-    // MPNN_GRU128_SLICED_DX=1: the kernel with resident 32-column slices at H = 128 (4.06 ms)
-    const bool kSlicedDx = H == 128 && switches().gru128_sliced_dx;
-    const size_t lds_sliced = (size_t)2 * 2 * 32 * (2 * 3 * GH), lds_stream = (size_t)2 * 4 * 64 * 128;
-    const size_t lds_dx = kSlicedDx ? lds_sliced : lds_stream;
     const size_t lds_dw = (size_t)2 * 8 * G_IMG + 64;
     static const hipError_t attr_done = [&] {   // once per process, thread-safe (C++11 static initialisation)
         LdsOptIn opt_in_;
-        if (H == 128) opt_in_((const void*)gru_bwd_dx128_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sliced);
-        opt_in_((const void*)gru_bwd_dx_stream_f16_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_stream);
-        opt_in_((const void*)gru_bwd_dx_wide_f16_kernel<H, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64);
         opt_in_((const void*)gru_bwd_dx_wide_f16_kernel<H, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64);
         opt_in_((const void*)gru_bwd_dw_f16_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dw);
         return opt_in_.err;
@@ -1052,34 +685,15 @@ static int launch_gru_bwd_f16_t(const float* dout, const float* m, const float* 
     int rc = launch_status("mpnn_gru_update_bwd_f32(gates, fp16 pieces)");
     if (rc) return rc;
 
-    if (kSlicedDx) {
-        int64_t pblocks = 64;                               // x 4 slices = one block per CU
-        if (pblocks * 8 > tiles) pblocks = (tiles + 7) / 8;
-        pblocks = (pblocks + 7) / 8 * 8;
-        hipLaunchKernelGGL(gru_bwd_dx128_f16_kernel, dim3((unsigned)(pblocks * 4)), dim3(512), lds_dx, s, pieces, inv_scale,
-                           W_ih, W_hh, dm, dh, V);
-    } else if (!switches().gru_dx_slice64) {               // default: 128-column slices (H=128: 10.3 vs 10.8 ms per backward)
+    {   // dm | dh: streamed pre-split weights, 128-column slices
         constexpr int NS = H / 128;
         const int64_t rounds = (V + 255) / 256;
         int64_t pblocks = 256 / NS;
         if (pblocks > rounds) pblocks = rounds;
         pblocks = (pblocks + 7) / 8 * 8;
-        if (!switches().gru_dx_insplit) {                   // default: weights split once per launch, copied global -> LDS
-            hipLaunchKernelGGL(gru_bwd_dx_presplit_kernel<H>, dim3((unsigned)(NS * 4 * (H / 32))), dim3(512), 0, s, W_ih, W_hh, dxw);
-            hipLaunchKernelGGL((gru_bwd_dx_wide_f16_kernel<H, true>), dim3((unsigned)(pblocks * NS)), dim3(512),
-                               (size_t)2 * 4 * 128 * 64, s, pieces, inv_scale, W_ih, W_hh, dm, dh, V, (const char*)dxw);
-        } else {
-            hipLaunchKernelGGL((gru_bwd_dx_wide_f16_kernel<H, false>), dim3((unsigned)(pblocks * NS)), dim3(512),
-                               (size_t)2 * 4 * 128 * 64, s, pieces, inv_scale, W_ih, W_hh, dm, dh, V, (const char*)nullptr);
-        }
-    } else {
-        constexpr int NS = H / 64;
-        const int64_t rounds = (V + 255) / 256;
-        int64_t pblocks = 256 / NS;
-        if (pblocks > rounds) pblocks = rounds;
-        pblocks = (pblocks + 7) / 8 * 8;
-        hipLaunchKernelGGL(gru_bwd_dx_stream_f16_kernel<H>, dim3((unsigned)(pblocks * NS)), dim3(512), lds_dx, s, pieces,
-                           inv_scale, W_ih, W_hh, dm, dh, V);
+        hipLaunchKernelGGL(gru_bwd_dx_presplit_kernel<H>, dim3((unsigned)(NS * 4 * (H / 32))), dim3(512), 0, s, W_ih, W_hh, dxw);
+        hipLaunchKernelGGL((gru_bwd_dx_wide_f16_kernel<H, true>), dim3((unsigned)(pblocks * NS)), dim3(512),
+                           (size_t)2 * 4 * 128 * 64, s, pieces, inv_scale, W_ih, W_hh, dm, dh, V, (const char*)dxw);
     }
     rc = launch_status("mpnn_gru_update_bwd_f32(dx, fp16 pieces)");
     if (rc) return rc;

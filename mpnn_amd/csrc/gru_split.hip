@@ -397,13 +397,15 @@ static int launch_split(const float* m, const float* h, const float* mask, const
     constexpr int CS = 32 * NCS;
     constexpr int slices = H / CS;
     const size_t lds = (size_t)2 * 3 * (3 * CS) * (2 * H) + 16 * CS;    // weight images + gate biases
+    // two row-guarded fp16 pieces per operand, three MFMAs per product (the F16 = false arm of the kernel template, three
+    // bf16 pieces and six MFMAs, was the default of round 1 and is no longer instantiated)
     static const hipError_t attr_done = [&] {   // once per process, thread-safe (C++11 static initialisation)
         LdsOptIn opt_in_;
         const int n = (int)lds;
-        opt_in_((const void*)gru_update_split_kernel<H, NCS, NW, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
-        opt_in_((const void*)gru_update_split_kernel<H, NCS, NW, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
-        opt_in_((const void*)gru_update_split_kernel<H, NCS, NW, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
-        opt_in_((const void*)gru_update_split_kernel<H, NCS, NW, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
+        opt_in_((const void*)gru_update_split_kernel<H, NCS, NW, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
+        opt_in_((const void*)gru_update_split_kernel<H, NCS, NW, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
+        opt_in_((const void*)gru_update_split_kernel<H, NCS, NW, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
+        opt_in_((const void*)gru_update_split_kernel<H, NCS, NW, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
         return opt_in_.err;
     }();
     if (attr_done != hipSuccess) return lds_opt_in_failed(attr_done);
@@ -412,364 +414,25 @@ static int launch_split(const float* m, const float* h, const float* mask, const
     if (pblocks * NW > tiles) pblocks = (tiles + NW - 1) / NW;
     if (pblocks < 1) pblocks = 1;
     const dim3 grid((unsigned)(pblocks * slices)), block(64 * NW);
-#define MPNN_LAUNCH_SPLIT(MASKED, SAVED)                                                                                   \
-    hipLaunchKernelGGL((gru_update_split_kernel<H, NCS, NW, MASKED, SAVED>), grid, block, lds, s, m, h, mask, W_ih, W_hh,  \
-                       b_ih, b_hh, out, saved, V, slices)
-    if (H == 64 && NCS == 2 && !switches().gru_fwd_bf16) {         // default: two row-guarded fp16 pieces, three MFMAs per product
-        constexpr bool F = (H == 64 && NCS == 2);
-        static const hipError_t attr16 = [&] {
-            LdsOptIn opt_in_;
-            const int n = (int)lds;
-            opt_in_((const void*)gru_update_split_kernel<H, NCS, NW, true, true, F>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
-            opt_in_((const void*)gru_update_split_kernel<H, NCS, NW, true, false, F>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
-            opt_in_((const void*)gru_update_split_kernel<H, NCS, NW, false, true, F>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
-            opt_in_((const void*)gru_update_split_kernel<H, NCS, NW, false, false, F>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
-            return opt_in_.err;
-        }();
-        if (attr16 != hipSuccess) return lds_opt_in_failed(attr16);
 #define MPNN_LAUNCH_F16(MASKED, SAVED)                                                                                     \
-    hipLaunchKernelGGL((gru_update_split_kernel<H, NCS, NW, MASKED, SAVED, F>), grid, block, lds, s, m, h, mask, W_ih, W_hh, \
+    hipLaunchKernelGGL((gru_update_split_kernel<H, NCS, NW, MASKED, SAVED, true>), grid, block, lds, s, m, h, mask, W_ih, W_hh, \
                        b_ih, b_hh, out, saved, V, slices)
-        if (mask && saved) MPNN_LAUNCH_F16(true, true);
-        else if (mask) MPNN_LAUNCH_F16(true, false);
-        else if (saved) MPNN_LAUNCH_F16(false, true);
-        else MPNN_LAUNCH_F16(false, false);
+    if (mask && saved) MPNN_LAUNCH_F16(true, true);
+    else if (mask) MPNN_LAUNCH_F16(true, false);
+    else if (saved) MPNN_LAUNCH_F16(false, true);
+    else MPNN_LAUNCH_F16(false, false);
 #undef MPNN_LAUNCH_F16
-        return launch_status("mpnn_gru_update_f32(fp16x3, row guards)");
-    }
-    if (mask && saved) MPNN_LAUNCH_SPLIT(true, true);
-    else if (mask) MPNN_LAUNCH_SPLIT(true, false);
-    else if (saved) MPNN_LAUNCH_SPLIT(false, true);
-    else MPNN_LAUNCH_SPLIT(false, false);
-#undef MPNN_LAUNCH_SPLIT
-    return launch_status("mpnn_gru_update_f32(bf16x6)");
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------
-// H = 128.  The three bf16 images of both matrices are 590 KB, so a block keeps one 32-feature column slice
-// (r|z|n columns of both matrices = 144 KB) and four blocks cover a row tile.  The four blocks of one row tile
-// are numbered to land on the same XCD (blockIdx % 8), so the tile's m/h rows come out of one L2.
-// A lane's half-row is 64 floats per operand: holding both operands plus a prefetched pair is 256 registers on
-// its own, so the rows move through a RING of four 16-float chunks (two K=16 steps each), fetched three chunks
-// ahead (~3.4k matrix-pipe cycles of cover); scheduling barriers pin that order, otherwise the compiler renames
-// the ring away and hoists every LDS read (558 spilled registers).
-template <bool HAS_MASK>
-__global__ void __launch_bounds__(512) gru_update_split128_kernel(
-    const float* __restrict__ m, const float* __restrict__ h, const float* __restrict__ mask,
-    const float* __restrict__ W_ih, const float* __restrict__ W_hh, const float* __restrict__ b_ih,
-    const float* __restrict__ b_hh, float* __restrict__ out, float* __restrict__ saved, int64_t V) {
-    constexpr int H = 128, CS = 32, NCOL = 96, ROWB = 2 * H, NCH = H / 8, IMG = NCOL * ROWB, NW = 8;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 matrices][3 pieces][96][128] bf16
-
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int slice = j & 3;
-    const int pblock = (j >> 2) * 8 + xcd, pblocks = gridDim.x >> 2;
-    const int c0 = slice * CS;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-
-    for (int idx = tid; idx < 2 * H * (NCOL / 4); idx += 64 * NW) {
-        const int mat = idx / (H * (NCOL / 4));
-        const int rem = idx % (H * (NCOL / 4));
-        const int k = rem / (NCOL / 4), q = rem % (NCOL / 4);
-        const int g = (4 * q) / CS, cc = (4 * q) % CS;
-        const float* W = mat == 0 ? W_ih : W_hh;
-        const f32x4 w4 = *reinterpret_cast<const f32x4*>(W + (int64_t)k * 3 * H + g * H + c0 + cc);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int col = g * CS + cc + u;
-            __bf16 ph, pm, pl;
-            split3(w4[u], ph, pm, pl);
-            const int off = col * ROWB + (((k >> 3) ^ col_swizzle<H>(col)) << 4) + ((k & 7) << 1);
-            *reinterpret_cast<__bf16*>(smem + (mat * 3 + 0) * IMG + off) = ph;
-            *reinterpret_cast<__bf16*>(smem + (mat * 3 + 1) * IMG + off) = pm;
-            *reinterpret_cast<__bf16*>(smem + (mat * 3 + 2) * IMG + off) = pl;
-        }
-    }
-    __syncthreads();
-
-    const int r = lane & 31, hi = lane >> 5;
-    const int col = c0 + r;
-    const float br = b_ih[col] + b_hh[col], bz = b_ih[H + col] + b_hh[H + col];
-    const float bni = b_ih[2 * H + col], bnh = b_hh[2 * H + col];
-
-    const int64_t tiles = (V + 31) / 32;
-    const int64_t stride = (int64_t)pblocks * NW;
-    int64_t t = (int64_t)pblock * NW + wv;
-    if (t >= tiles) return;
-
-    f32x4 ring[4][4];
-    // chunk c of a tile: operand c>>2 (m, h), floats [16*(c&3), +16) of the lane's half-row
-    auto load_chunk = [&](int64_t tile, int c, f32x4 (&f)[4]) {
-        int64_t row = tile * 32 + r;
-        if (row >= V) row = V - 1;
-        const float* p = ((c >> 2) ? h : m) + row * H + hi * (H / 2) + 16 * (c & 3);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) f[q] = *reinterpret_cast<const f32x4*>(p + 4 * q);
-    };
-    auto bfrag = [&](int mat, int piece, int wcol, int st) {
-        const int chunk = hi * (NCH / 2) + st;
-        return *reinterpret_cast<const bf16x8*>(smem + (mat * 3 + piece) * IMG + wcol * ROWB +
-                                                ((chunk ^ col_swizzle<H>(wcol)) << 4));
-    };
-
-    load_chunk(t, 0, ring[0]);
-    load_chunk(t, 1, ring[1]);
-    load_chunk(t, 2, ring[2]);
-    for (; t < tiles; t += stride) {
-        const int64_t tn = t + stride < tiles ? t + stride : t;     // last tile: harmless re-read
-        f32x16 acc_r, acc_z, acc_ni, acc_nh;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { acc_r[i] = 0.f; acc_z[i] = 0.f; acc_ni[i] = 0.f; acc_nh[i] = 0.f; }
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            if (c + 3 < 8) load_chunk(t, c + 3, ring[(c + 3) & 3]);
-            else load_chunk(tn, c + 3 - 8, ring[(c + 3) & 3]);
-            __builtin_amdgcn_sched_barrier(0);
-            const int mat = c >> 2;
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const int st = 2 * (c & 3) + s2;
-                bf16x8 ah, am, al;
-                split8(ring[c & 3][2 * s2], ring[c & 3][2 * s2 + 1], ah, am, al);
-                mma6(acc_r, ah, am, al, bfrag(mat, 0, r, st), bfrag(mat, 1, r, st), bfrag(mat, 2, r, st));
-                mma6(acc_z, ah, am, al, bfrag(mat, 0, CS + r, st), bfrag(mat, 1, CS + r, st), bfrag(mat, 2, CS + r, st));
-                if (mat == 0)
-                    mma6(acc_ni, ah, am, al, bfrag(0, 0, 2 * CS + r, st), bfrag(0, 1, 2 * CS + r, st),
-                         bfrag(0, 2, 2 * CS + r, st));
-                else
-                    mma6(acc_nh, ah, am, al, bfrag(1, 0, 2 * CS + r, st), bfrag(1, 1, 2 * CS + r, st),
-                         bfrag(1, 2, 2 * CS + r, st));
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float mk4[4], hv4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int64_t row = t * 32 + 8 * g + 4 * hi + u;
-                if (row >= V) row = V - 1;
-                mk4[u] = HAS_MASK ? mask[row] : 1.0f;
-                hv4[u] = h[row * H + col];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = 4 * g + u;
-                const int64_t row = t * 32 + 8 * g + 4 * hi + u;
-                const float mk = mk4[u];
-                const float rg = sigmoid_fast(acc_r[i] + br) * mk;
-                const float zg = sigmoid_fast(acc_z[i] + bz) * mk;
-                const float nh = acc_nh[i] + bnh;
-                const float ng = tanh_fast(acc_ni[i] + bni + rg * nh) * mk;
-                const float o = ((1.0f - zg) * ng + zg * hv4[u]) * mk;
-                if (row < V) {
-                    __builtin_nontemporal_store(o, out + row * H + col);
-                    if (saved) {
-                        float* sv = saved + row * 4 * H + col;
-                        __builtin_nontemporal_store(rg, sv);
-                        __builtin_nontemporal_store(zg, sv + H);
-                        __builtin_nontemporal_store(ng, sv + 2 * H);
-                        __builtin_nontemporal_store(nh, sv + 3 * H);
-                    }
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
-
-static int launch_split128(const float* m, const float* h, const float* mask, const float* W_ih, const float* W_hh,
-                           const float* b_ih, const float* b_hh, float* out, float* saved, int64_t V, hipStream_t s) {
-    const size_t lds = (size_t)2 * 3 * 96 * 256;
-    static const hipError_t attr_done = [&] {   // once per process, thread-safe (C++11 static initialisation)
-        LdsOptIn opt_in_;
-        opt_in_((const void*)gru_update_split128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        opt_in_((const void*)gru_update_split128_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        return opt_in_.err;
-    }();
-    if (attr_done != hipSuccess) return lds_opt_in_failed(attr_done);
-    const int64_t tiles = (V + 31) / 32;
-    int64_t pblocks = 64;                                   // x 4 slices = one block per CU
-    if (pblocks * 8 > tiles) pblocks = (tiles + 7) / 8;
-    pblocks = (pblocks + 7) / 8 * 8;                        // the XCD-aware numbering wants groups of 8 row blocks
-    const dim3 grid((unsigned)(pblocks * 4)), block(512);
-    if (mask)
-        hipLaunchKernelGGL((gru_update_split128_kernel<true>), grid, block, lds, s, m, h, mask, W_ih, W_hh, b_ih, b_hh,
-                           out, saved, V);
-    else
-        hipLaunchKernelGGL((gru_update_split128_kernel<false>), grid, block, lds, s, m, h, mask, W_ih, W_hh, b_ih, b_hh,
-                           out, saved, V);
-    return launch_status("mpnn_gru_update_f32(bf16x6, H=128)");
+    return launch_status("mpnn_gru_update_f32(fp16x3, row guards)");
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// H >= 128, weights STREAMED.  The column-sliced kernel above re-reads a row tile once per 32-feature slice, and PMC
-// shows those re-reads reach the fabric (16 GB for 3.8 GB of operands at H = 128); at H = 256 its resident slice
-// would not even fit.  Here a block owns a 64-feature slice (192 gate columns of both matrices) and the contraction
-// is cut into 32-wide K chunks: all 512 threads split chunk c+1 of the weights into bf16 pieces and park it in the
-// other half of a double-buffered LDS image (one barrier per chunk) while the eight waves multiply chunk c.
-// A wave owns 32 rows x 32 features (two waves share a row tile), accumulators r, z, gi_n, gh_n stay in registers
-// across the whole contraction, its operand rows arrive as 16-float pieces one chunk ahead.  Row operands are read
-// H/64 times (2 at H = 128, 4 at H = 256); the weights come out of L2.
-template <int H, bool HAS_MASK>
-__global__ void __launch_bounds__(512) gru_update_stream_kernel(
-    const float* __restrict__ m, const float* __restrict__ h, const float* __restrict__ mask,
-    const float* __restrict__ W_ih, const float* __restrict__ W_hh, const float* __restrict__ b_ih,
-    const float* __restrict__ b_hh, float* __restrict__ out, float* __restrict__ saved, int64_t V) {
-    constexpr int NS = H / 64, NCHUNK = H / 32, COLS = 192;
-    constexpr int IMGC = COLS * 64;            // bytes of one (matrix, piece) chunk image: 192 columns x 32 k bf16
-    constexpr int BUF = 6 * IMGC;              // 72 KB
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][2 matrices][3 pieces][192][32] bf16
-
-    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    const int slice = jb % NS;                                 // the NS slice blocks of a row group share an XCD
-    const int pblock = (jb / NS) * 8 + xcd, pblocks = gridDim.x / NS;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, hi = lane >> 5;
-    const int tr = wv >> 1, half = wv & 1;
-
-    const int64_t rounds_total = (V + 127) / 128;              // a round = 128 rows = 4 tiles, two waves per tile
-    if (pblock >= rounds_total) return;                        // block-uniform
-    const int64_t nrounds = (rounds_total - pblock + pblocks - 1) / pblocks;
-
-    const int fcol = 64 * slice + 32 * half + r;               // this lane's output feature
-    const float br = b_ih[fcol] + b_hh[fcol], bz = b_ih[H + fcol] + b_hh[H + fcol];
-    const float bni = b_ih[2 * H + fcol], bnh = b_hh[2 * H + fcol];
-
-
-    // ---- weight staging: unit = (matrix, k-octet of the chunk, column); 1536 units, three per thread ----
-    // per-thread constants of its three units: source pointer at chunk 0 and LDS byte offset
-    const float* wsrc[3];
-    int ldst[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int u = tid + 512 * j;
-        const int mat = u / 768, rem = u % 768;
-        const int o = rem / COLS, cl = rem % COLS;
-        wsrc[j] = (mat ? W_hh : W_ih) + (int64_t)(8 * o) * 3 * H + (cl / 64) * H + 64 * slice + (cl % 64);
-        ldst[j] = mat * 3 * IMGC + cl * 64 + ((o ^ ((cl >> 2) & 3)) << 4);
-    }
-    float raw[3][8];
-    auto stage_load = [&](int c) {
-        const int64_t off = (int64_t)(32 * c) * 3 * H;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const float* W = wsrc[j] + off;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) raw[j][i] = W[(int64_t)i * 3 * H];
-        }
-    };
-    auto stage_write = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const f32x4 x0 = {raw[j][0], raw[j][1], raw[j][2], raw[j][3]};
-            const f32x4 x1 = {raw[j][4], raw[j][5], raw[j][6], raw[j][7]};
-            bf16x8 ph, pm, pl;
-            split8(x0, x1, ph, pm, pl);
-            char* base = smem + buf * BUF + ldst[j];
-            *reinterpret_cast<bf16x8*>(base) = ph;
-            *reinterpret_cast<bf16x8*>(base + IMGC) = pm;
-            *reinterpret_cast<bf16x8*>(base + 2 * IMGC) = pl;
-        }
-    };
-    // B fragment: column cl = gate*64 + 32*half + r, k-octet 2*hi + st of the chunk
-    auto bfrag = [&](int buf, int mat, int piece, int gate, int st) {
-        const int cl = gate * 64 + 32 * half + r;
-        const int o = 2 * hi + st;
-        return *reinterpret_cast<const bf16x8*>(smem + buf * BUF + (mat * 3 + piece) * IMGC + cl * 64 +
-                                                ((o ^ ((cl >> 2) & 3)) << 4));
-    };
-    // this lane's 16 floats of chunk c of operand X for row tile `tile`
-    auto load_rows = [&](const float* __restrict__ X, int64_t tile, int c, f32x4 (&f)[4]) {
-        int64_t row = tile * 32 + r;
-        if (row >= V) row = V - 1;
-        const float* p = X + row * H + 32 * c + 16 * hi;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) f[q] = *reinterpret_cast<const f32x4*>(p + 4 * q);
-    };
-
-    f32x16 acc_r, acc_z, acc_ni, acc_nh;
-    f32x4 am0[4], ah0[4], am1[4], ah1[4];
-    int cur = 0;
-    int64_t tile = ((int64_t)pblock) * 4 + tr;
-
-    // one K chunk: stage the next chunk of weights, fetch the next chunk of rows, multiply the current one
-    auto chunk = [&](int c, int64_t tile_next, f32x4 (&xm)[4], f32x4 (&xh)[4], f32x4 (&nm)[4], f32x4 (&nh)[4]) {
-        __syncthreads();                                   // buffer `cur` is complete, `cur ^ 1` is free
-        const int cn = (c + 1) % NCHUNK;
-        stage_load(cn);
-        load_rows(m, cn == 0 ? tile_next : tile, cn, nm);
-        load_rows(h, cn == 0 ? tile_next : tile, cn, nh);
-        __builtin_amdgcn_sched_barrier(0);
-        // twelve mma6 groups (operand, K step, gate)
-        bf16x8 a_h, a_m, a_l;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            const int mat = i / 6, st = (i / 3) % 2, gate = i % 3;
-            if (gate == 0) {
-                if (mat == 0) split8(xm[2 * st], xm[2 * st + 1], a_h, a_m, a_l);
-                else split8(xh[2 * st], xh[2 * st + 1], a_h, a_m, a_l);
-            }
-            f32x16& acc = gate == 0 ? acc_r : gate == 1 ? acc_z : (mat == 0 ? acc_ni : acc_nh);
-            mma6(acc, a_h, a_m, a_l, bfrag(cur, mat, 0, gate, st), bfrag(cur, mat, 1, gate, st), bfrag(cur, mat, 2, gate, st));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        stage_write(cur ^ 1);
-        cur ^= 1;
-    };
-
-    stage_load(0);
-    stage_write(0);
-    load_rows(m, tile, 0, am0);
-    load_rows(h, tile, 0, ah0);
-    for (int64_t rd = 0; rd < nrounds; ++rd) {
-        const int64_t tile_next = rd + 1 < nrounds ? tile + (int64_t)pblocks * 4 : tile;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { acc_r[i] = 0.f; acc_z[i] = 0.f; acc_ni[i] = 0.f; acc_nh[i] = 0.f; }
-#pragma unroll 1
-        for (int c = 0; c < NCHUNK; c += 2) {
-            chunk(c, tile_next, am0, ah0, am1, ah1);
-            chunk(c + 1, tile_next, am1, ah1, am0, ah0);
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float mk4[4], hv4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int64_t row = tile * 32 + 8 * g + 4 * hi + u;
-                if (row >= V) row = V - 1;
-                mk4[u] = HAS_MASK ? mask[row] : 1.0f;
-                hv4[u] = h[row * H + fcol];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = 4 * g + u;
-                const int64_t row = tile * 32 + 8 * g + 4 * hi + u;
-                const float mk = mk4[u];
-                const float rg = sigmoid_fast(acc_r[i] + br) * mk;
-                const float zg = sigmoid_fast(acc_z[i] + bz) * mk;
-                const float nh = acc_nh[i] + bnh;
-                const float ng = tanh_fast(acc_ni[i] + bni + rg * nh) * mk;
-                const float o = ((1.0f - zg) * ng + zg * hv4[u]) * mk;
-                if (row < V) {
-                    __builtin_nontemporal_store(o, out + row * H + fcol);
-                    if (saved) {
-                        float* sv = saved + row * 4 * H + fcol;
-                        __builtin_nontemporal_store(rg, sv);
-                        __builtin_nontemporal_store(zg, sv + H);
-                        __builtin_nontemporal_store(ng, sv + 2 * H);
-                        __builtin_nontemporal_store(nh, sv + 3 * H);
-                    }
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        tile = tile_next;
-    }
-}
-
+// H = 128 / 256, weights STREAMED.  Neither matrix's split images fit in LDS next to anything else (590 KB as three bf16
+// images at H = 128), so a block owns a 64-feature output slice (192 gate columns of both matrices) and the contraction
+// is cut into 32-wide K chunks whose weight images pass through a double-buffered LDS buffer, one barrier per chunk.
+// Accumulators r, z, gi_n, gh_n stay in registers across the whole contraction; operand rows arrive as 16-float pieces
+// one half-chunk ahead.  Row operands are read H / 64 times (2 at H = 128, 4 at H = 256); the weights come out of L2.
+// (Rounds 1-2 also had a resident-slice kernel at H = 128 and a 32 x 32 wave tile at H = 256: 1.5 % / 15 % behind this
+// kernel, removed in round 3.)
 // ---- pre-split weights for the streamed wide kernel (fp16 pieces), one workspace per launch ----
 // [0, 64): inverse weight scale of slice s at float s; then the LDS image of (slice, chunk c) at 64 + (slice * H / 32 + c) * 48 KB:
 // [matrix][piece][192 columns = (gate, column of the slice)][32 k] exactly as gru_update_stream_wide_kernel reads it, so a
@@ -1136,32 +799,6 @@ __global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
     }
 }
 
-template <int H>
-static int launch_stream(const float* m, const float* h, const float* mask, const float* W_ih, const float* W_hh,
-                         const float* b_ih, const float* b_hh, float* out, float* saved, int64_t V, hipStream_t s) {
-    constexpr int NS = H / 64;
-    const size_t lds = (size_t)2 * 6 * 192 * 64;
-    static const hipError_t attr_done = [&] {   // once per process, thread-safe (C++11 static initialisation)
-        LdsOptIn opt_in_;
-        opt_in_((const void*)gru_update_stream_kernel<H, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        opt_in_((const void*)gru_update_stream_kernel<H, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        return opt_in_.err;
-    }();
-    if (attr_done != hipSuccess) return lds_opt_in_failed(attr_done);
-    const int64_t rounds = (V + 127) / 128;
-    int64_t pblocks = 256 / NS;                             // x NS slices = one block per CU (144 KB of LDS)
-    if (pblocks > rounds) pblocks = rounds;
-    pblocks = (pblocks + 7) / 8 * 8;                        // XCD-aware numbering wants groups of 8 row blocks
-    const dim3 grid((unsigned)(pblocks * NS)), block(512);
-    if (mask)
-        hipLaunchKernelGGL((gru_update_stream_kernel<H, true>), grid, block, lds, s, m, h, mask, W_ih, W_hh, b_ih, b_hh,
-                           out, saved, V);
-    else
-        hipLaunchKernelGGL((gru_update_stream_kernel<H, false>), grid, block, lds, s, m, h, mask, W_ih, W_hh, b_ih, b_hh,
-                           out, saved, V);
-    return launch_status("mpnn_gru_update_f32(bf16x6, streamed weights)");
-}
-
 size_t gru_fwd_workspace_bytes(int H) {
     return (H == 128 || H == 256) ? 64 + (size_t)(H / 64) * (H / 32) * (2 * 4 * 192 * 64 / 2) : 0;
 }
@@ -1171,16 +808,11 @@ static int launch_stream_wide(const float* m, const float* h, const float* mask,
                          const float* b_ih, const float* b_hh, float* out, float* saved, int64_t V, void* workspace,
                          hipStream_t s) {
     constexpr int NS = H / 64;
-    const bool f16 = !switches().gru_fwd_bf16;               // default: two fp16 pieces per operand, row-wise range guards
-    const bool presplit = f16 && workspace != nullptr;       // weights split once per launch, copied global -> LDS
-    const size_t lds = f16 ? (size_t)2 * 4 * 192 * 64 : (size_t)2 * 6 * 192 * 64;
+    const bool presplit = workspace != nullptr;              // weights split once per launch, copied global -> LDS
+    const size_t lds = (size_t)2 * 4 * 192 * 64;             // two fp16 pieces per operand, row-wise range guards
     static const hipError_t attr_done = [&] {   // once per process, thread-safe (C++11 static initialisation)
         LdsOptIn opt_in_;
-        const int n = (int)2 * 6 * 192 * 64, n16 = (int)2 * 4 * 192 * 64;
-        opt_in_((const void*)gru_update_stream_wide_kernel<H, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
-        opt_in_((const void*)gru_update_stream_wide_kernel<H, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
-        opt_in_((const void*)gru_update_stream_wide_kernel<H, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
-        opt_in_((const void*)gru_update_stream_wide_kernel<H, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, n);
+        const int n16 = (int)2 * 4 * 192 * 64;
         opt_in_((const void*)gru_update_stream_wide_kernel<H, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n16);
         opt_in_((const void*)gru_update_stream_wide_kernel<H, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n16);
         opt_in_((const void*)gru_update_stream_wide_kernel<H, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n16);
@@ -1205,12 +837,9 @@ static int launch_stream_wide(const float* m, const float* h, const float* mask,
         if (presplit)                                                                                                    \
             hipLaunchKernelGGL((gru_update_stream_wide_kernel<H, MASKED, SAVED, true, true>), grid, block, lds, s, m, h, \
                                mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, wws);                                        \
-        else if (f16)                                                                                                    \
+        else                                                                                                             \
             hipLaunchKernelGGL((gru_update_stream_wide_kernel<H, MASKED, SAVED, true>), grid, block, lds, s, m, h, mask, \
                                W_ih, W_hh, b_ih, b_hh, out, saved, V, wws);                                              \
-        else                                                                                                             \
-            hipLaunchKernelGGL((gru_update_stream_wide_kernel<H, MASKED, SAVED>), grid, block, lds, s, m, h, mask, W_ih, \
-                               W_hh, b_ih, b_hh, out, saved, V, wws);                                                    \
     } while (0)
     if (mask && saved) MPNN_LAUNCH_WIDE(true, true);
     else if (mask) MPNN_LAUNCH_WIDE(true, false);
@@ -1225,14 +854,8 @@ int launch_gru_split(const float* m, const float* h, const float* mask, const fl
                      const float* b_ih, const float* b_hh, float* out, float* saved, int64_t V, int H, void* workspace,
                      hipStream_t s) {
     if (H == 64) return launch_split<64, 2, 8>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, s);
-    // hidden 128: streamed weights with the wide tile (2 output slices) is ~1.5 % ahead of the resident-slice kernel
-    // (4 slices) on c4; MPNN_GRU128_SLICED=1 selects the latter
-    const bool stream128 = !switches().gru128_sliced;
-    if (H == 128 && stream128) return launch_stream_wide<128>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, workspace, s);
-    if (H == 128) return launch_split128(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, s);
-    const bool narrow256 = switches().gru256_narrow;
-    if (H == 256 && !narrow256) return launch_stream_wide<256>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, workspace, s);
-    if (H == 256) return launch_stream<256>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, s);
+    if (H == 128) return launch_stream_wide<128>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, workspace, s);
+    if (H == 256) return launch_stream_wide<256>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, workspace, s);
     return 1;
 }
 

@@ -374,7 +374,7 @@ static int launch_message_wide_t(const float* h, const float* A, const int32_t* 
     hipLaunchKernelGGL(mw_split_kernel<F>, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, A, ws, K);
     int64_t blocks = 256;                                 // one block per CU
     if (blocks > num_tiles) blocks = num_tiles;
-    static const int dbg = getenv("MPNN_MW_DBG") ? atoi(getenv("MPNN_MW_DBG")) : 0;     // timing ablations only
+    const int dbg = 0;                                    // (bits 2 / 4 / 8 switch off the products / the copies / all work: timing ablations)
     hipLaunchKernelGGL(message_sum_wide_kernel<F>, dim3((unsigned)blocks), dim3(512), mw_lds_bytes<F>(), s, h, ws, tile_rec,
                        tile_atom, blk_off, slots, out, (int)num_tiles, K, dbg);
     return launch_status("mpnn_message_aggregate_wide_f32");
@@ -395,8 +395,8 @@ extern "C" int mpnn_message_aggregate_wide_f32(const float* h, const float* A, c
                                                const int32_t* tile_atom, const int32_t* blk_off, const int16_t* slots,
                                                float* out, void* workspace, size_t workspace_bytes, int64_t V,
                                                int64_t num_tiles, int K, int nf, int mf, void* stream) {
-    MPNN_REQUIRE(nf == mf && (nf == 64 || nf == 128 || nf == 256),
-                 "mpnn_message_aggregate_wide_f32: nf = mf in {64, 128, 256} only (got %d, %d)", nf, mf);
+    MPNN_REQUIRE(nf == mf && (nf == 128 || nf == 256),
+                 "mpnn_message_aggregate_wide_f32: nf = mf in {128, 256} only (got %d, %d)", nf, mf);
     MPNN_REQUIRE(K >= 1 && K <= MW_KMAX, "mpnn_message_aggregate_wide_f32: 1 <= K <= %d bond types (got %d)", MW_KMAX, K);
     MPNN_REQUIRE(V >= 0 && num_tiles >= 0 && num_tiles < (1ll << 24), "mpnn_message_aggregate_wide_f32: bad sizes");
     if (V == 0 || num_tiles == 0) return MPNN_OK;
@@ -406,7 +406,6 @@ extern "C" int mpnn_message_aggregate_wide_f32(const float* h, const float* A, c
                  "mpnn_message_aggregate_wide_f32: workspace of %zu bytes, need %zu", workspace_bytes,
                  message_wide_workspace_bytes(K, nf));
     hipStream_t s = (hipStream_t)stream;
-    if (nf == 64) return launch_message_wide_t<64>(h, A, tile_rec, tile_atom, blk_off, slots, out, workspace, num_tiles, K, s);
     if (nf == 128) return launch_message_wide_t<128>(h, A, tile_rec, tile_atom, blk_off, slots, out, workspace, num_tiles, K, s);
     return launch_message_wide_t<256>(h, A, tile_rec, tile_atom, blk_off, slots, out, workspace, num_tiles, K, s);
 }

@@ -227,14 +227,9 @@ static int launch_segsum(const float* msg, const int32_t* row_ptr, const int32_t
     const bool v4 = (F % 4 == 0) && ((reinterpret_cast<uintptr_t>(msg) | reinterpret_cast<uintptr_t>(out)) % 16 == 0);
     const int lpr = pick_lpr(F, v4 ? 4 : 1);
     const dim3 grid(grid_for(V, lpr)), block(256);
-    const int variant = switches().segsum_variant;   // 1 = one atom per lane group, 2 = pair kernel with cached loads/stores (A/B)
-    if (!GATHER && (variant == 2 || variant == 3) && v4 && lpr * 4 >= F) {
+    if (!GATHER && v4 && lpr * 4 >= F) {                   // two atoms per lane group, nontemporal accesses
         const dim3 g2(grid_for((V + 1) / 2, lpr));
-#define MPNN_PAIR(LPR)                                                                                              \
-    if (variant == 3)                                                                                               \
-        hipLaunchKernelGGL((segsum_pair_kernel<4, LPR, true>), g2, block, 0, s, msg, row_ptr, w, out, V, F);        \
-    else                                                                                                            \
-        hipLaunchKernelGGL((segsum_pair_kernel<4, LPR, false>), g2, block, 0, s, msg, row_ptr, w, out, V, F);
+#define MPNN_PAIR(LPR) hipLaunchKernelGGL((segsum_pair_kernel<4, LPR, true>), g2, block, 0, s, msg, row_ptr, w, out, V, F);
         switch (lpr) {
             case 16: MPNN_PAIR(16) break;
             case 32: MPNN_PAIR(32) break;

@@ -42,7 +42,6 @@ class TilePlan:
                          (source atom - tile start) | valid << 14 | bond type << 16;
                          an empty slot reads source row `tile_atoms` (a row of zeros in the kernel's LDS image)
         slot_eid[16*R]   edge id of the slot (-1 = empty); tests use it
-        tile_rtk[T,8K+1] first row-tile of every (block, type) of the tile, then its end (the backward kernel's loop bounds)
     """
 
     def __init__(self, tile_ptr, tile_atom, rt_ptr, slots, slot_eid, tile_atoms, rt_start, num_types):
@@ -57,10 +56,6 @@ class TilePlan:
         rec[:, 2:2 + nb] = rt_ptr[:nb * T].view(T, nb)
         rec[:, 2 + nb] = rt_ptr[nb::nb]
         self.tile_rec = rec.contiguous()
-        # backward: first row-tile of every (block, type) of a tile, then the tile's end -- [T, nb * K + 1]
-        per = nb * num_types
-        idx = torch.arange(T, device=tile_ptr.device).unsqueeze(1) * per + torch.arange(per + 1, device=tile_ptr.device)
-        self.tile_rtk = _i32(rt_start[idx])
         # what one launch reads: a record and the sorted-atom list per tile, every slot word once
         self.nbytes = 4 * (16 * T + tile_atoms * T + 16 * self.num_row_tiles)
 

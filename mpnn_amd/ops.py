@@ -59,26 +59,19 @@ def _timed(name, fn):
 
 
 def math_mode():
-    """"fp32" (MPNN_GRU_MATH=fp32: contractions on the fp32 matrix pipe) or "bf16x6" (default: three-way bf16 operand
-    splits, six bf16 MFMAs per fp32 product)."""
-    return "fp32" if os.environ.get("MPNN_GRU_MATH") == "fp32" else "bf16x6"
+    """"fp32" (MPNN_GRU_MATH=fp32: every contraction on the fp32 matrix pipe) or "split" (default: operand splits on the
+    16-bit matrix pipe with fp32 accumulation)."""
+    return "fp32" if os.environ.get("MPNN_GRU_MATH") == "fp32" else "split"
 
 
 def mfma_per_product(kernel=None, hidden=64):
     """16-bit MFMAs issued per fp32 product by a contraction kernel (`kernel` = its KernelTimer label; 0 = the fp32
-    matrix pipe itself).  Three-way bf16 splits issue six; the kernels on two fp16 pieces issue three: the fused
-    message + sum tile kernel and, at widths 64 / 128 / 256, the GRU backward (unless MPNN_GRU_BWD_BF16) and the GRU
-    forward (unless MPNN_GRU_FWD_BF16)."""
+    matrix pipe itself).  Two range-guarded fp16 pieces, three MFMAs: the fused message + sum kernels and the GRU forward
+    and backward at widths 64 / 128 / 256.  Three bf16 pieces, six MFMAs: the per-edge message kernels."""
     if math_mode() == "fp32":
         return 0
-    if kernel == "gru_update_bwd" and not os.environ.get("MPNN_GRU_BWD_BF16"):
-        if hidden in (128, 256) or (hidden == 64 and not os.environ.get("MPNN_GRU_BWD_FP32TILE")
-                             and not os.environ.get("MPNN_GRU_BWD_UNIFORM")):
-            return 3
-    if kernel == "gru_update" and not os.environ.get("MPNN_GRU_FWD_BF16"):
-        if hidden == 64 or (hidden in (128, 256) and not os.environ.get("MPNN_GRU128_SLICED")
-                            and not os.environ.get("MPNN_GRU256_NARROW")):
-            return 3
+    if kernel in ("gru_update", "gru_update_bwd") and hidden in (64, 128, 256):
+        return 3
     if kernel == "message_aggregate":
         return 3
     return 6
@@ -86,10 +79,10 @@ def mfma_per_product(kernel=None, hidden=64):
 
 def math_description():
     return {"fp32": "fp32 matrix pipe (MPNN_GRU_MATH=fp32)",
-            "bf16x6": "fp32 data and accumulation; dense contractions as three-way bf16 operand splits "
-                      "(six bf16 MFMAs per fp32 product) or, in the fused message+sum kernel and the GRU forward and "
-                      "backward at widths 64/128/256, range-guarded two-way fp16 splits (three MFMAs per product); parity 1e-5 as the "
-                      "fp32 kernels"}[math_mode()]
+            "split": "fp32 data and accumulation; dense contractions on the 16-bit matrix pipe: range-guarded two-way fp16 "
+                     "operand splits (three MFMAs per product) in the fused message+sum kernels and the GRU forward and "
+                     "backward at widths 64/128/256, three-way bf16 splits (six MFMAs) in the per-edge message kernels; "
+                     "parity 1e-5 as the fp32 kernels"}[math_mode()]
 
 
 # --------------------------------------------------------------------------- raw launches
@@ -173,10 +166,9 @@ def wide_kernel_applies(A, gate, w, graph):
     """The fused message+sum kernel at widths 128 / 256 (typed aggregate-then-contract on molecule tiles of up to 256
     atoms, csrc/message_tile_wide.hip) covers: no gate, unit edge weights, nf = mf in {128, 256}, a batch of separate
     molecules with at most 8 bond types (graph.wide_plan), default math.  MPNN_UNFUSED_MESSAGE=1 keeps the two-kernel
-    path; MPNN_WIDE_MESSAGE64=1 sends width 64 through this kernel too (A/B against the width-64 tile kernel)."""
+    path."""
     K, mf, nf = (int(s) for s in A.shape)
-    widths = (64, 128, 256) if os.environ.get("MPNN_WIDE_MESSAGE64") else (128, 256)
-    if (gate is not None or w is not None or mf != nf or nf not in widths or math_mode() == "fp32"
+    if (gate is not None or w is not None or mf != nf or nf not in (128, 256) or math_mode() == "fp32"
             or os.environ.get("MPNN_UNFUSED_MESSAGE")):
         return False
     plan = graph.wide_plan
@@ -221,7 +213,7 @@ def gru_update_raw(m, h, mask, W_ih, W_hh, b_ih, b_hh, save):
     V, H = int(h.shape[0]), int(h.shape[1])
     out = _empty((V, H), h)
     saved = _empty((V, 4 * H), h) if save else None
-    ws_bytes = 0 if os.environ.get("MPNN_GRU_FWD_NOWS") else lib.mpnn_gru_fwd_workspace_bytes(V, H)   # A/B: in-kernel weight split
+    ws_bytes = lib.mpnn_gru_fwd_workspace_bytes(V, H)
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=h.device) if ws_bytes else None
     _lib.check(_timed("gru_update", lambda: lib.mpnn_gru_update_f32(
         _lib.fptr(m), _lib.fptr(h), _lib.fptr(mask), _lib.fptr(W_ih), _lib.fptr(W_hh), _lib.fptr(b_ih),
@@ -349,16 +341,6 @@ class MessageAggregate(torch.autograd.Function):
                 return None, None, None, None, None
             lib = _lib.load()
             dA = torch.zeros_like(A)
-            # The tile-plan weight gradient (dagg and h read once, no per-edge gathers from HBM) is parity-green but
-            # measured no faster than the per-edge gather kernel at the c2 size (0.70 vs 0.64-0.70 ms: three MFMAs per
-            # row-tile and wave leave its loop latency-bound), so it is opt-in: MPNN_TILE_BWD=1.
-            if os.environ.get("MPNN_TILE_BWD") and tile_kernel_applies(A, gate, w, g) and g.num_edges:
-                plan = g.tile_plan
-                _lib.check(_timed("message_aggregate_bwd", lambda: lib.mpnn_message_aggregate_bwd_da_f32(
-                    _lib.fptr(dout), _lib.fptr(h), _lib.iptr(plan.tile_rec), _lib.iptr(plan.tile_atom),
-                    _lib.iptr(plan.tile_rtk), _lib.iptr(plan.slots), _lib.fptr(dA), g.num_nodes, plan.num_tiles, K, nf, mf,
-                    _lib.stream())), "mpnn_message_aggregate_bwd_da_f32")
-                return None, dA, None, None, None
             if g.num_edges:
                 _lib.check(_timed("message_aggregate_bwd", lambda: lib.mpnn_edge_message_agg_bwd_da_f32(
                     _lib.fptr(dout), _lib.fptr(h), _lib.iptr(g.col_idx), _lib.iptr(g.edge_dst), _lib.fptr(w),

@@ -129,20 +129,15 @@ def test_reference_module_names_importable_with_package_dir_on_path():
     assert r.stdout.strip() == "63"
 
 
-def test_mfma_pricing_follows_the_math_switches(monkeypatch):
+def test_mfma_pricing_follows_the_math_switch(monkeypatch):
     """bench.py prices each contraction kernel against the 16-bit MFMA peak divided by the MFMAs it issues per fp32
-    product (ops.mfma_per_product): six for the three-way bf16 splits, three for the kernels on two fp16 pieces, zero
-    (= the fp32 pipe itself) under MPNN_GRU_MATH=fp32.  The table must follow the same switches the library reads."""
+    product (ops.mfma_per_product): six for the three-way bf16 splits of the per-edge message kernels, three for the
+    kernels on two fp16 pieces, zero (= the fp32 pipe itself) under MPNN_GRU_MATH=fp32 -- the one math switch the library
+    reads."""
     from mpnn_amd import ops
-    for k in ("MPNN_GRU_MATH", "MPNN_GRU_BWD_BF16", "MPNN_GRU_FWD_BF16", "MPNN_GRU_BWD_FP32TILE",
-              "MPNN_GRU_BWD_UNIFORM", "MPNN_GRU128_SLICED", "MPNN_GRU256_NARROW"):
-        monkeypatch.delenv(k, raising=False)
+    monkeypatch.delenv("MPNN_GRU_MATH", raising=False)
     assert [ops.mfma_per_product("gru_update_bwd", h) for h in (64, 128, 256)] == [3, 3, 3]
     assert [ops.mfma_per_product("gru_update", h) for h in (64, 128, 256)] == [3, 3, 3]
     assert ops.mfma_per_product("message_aggregate", 64) == 3 and ops.mfma_per_product("edge_message", 128) == 6
-    monkeypatch.setenv("MPNN_GRU_BWD_BF16", "1")
-    monkeypatch.setenv("MPNN_GRU_FWD_BF16", "1")
-    assert [ops.mfma_per_product("gru_update_bwd", h) for h in (64, 128, 256)] == [6, 6, 6]
-    assert [ops.mfma_per_product("gru_update", h) for h in (64, 128, 256)] == [6, 6, 6]
     monkeypatch.setenv("MPNN_GRU_MATH", "fp32")
     assert ops.mfma_per_product("gru_update_bwd", 64) == 0 and "fp32 matrix pipe" in ops.math_description()

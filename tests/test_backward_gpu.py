@@ -152,24 +152,6 @@ def test_gru_forward_backward_at_tile_boundaries(dev, V, H):
         assert err < 2e-5, (name, err)
 
 
-def test_gru_backward_h64_bf16_alternate_holds_the_parity_bar():
-    """MPNN_GRU_BWD_BF16=1 (three bf16 pieces, six MFMAs per product: round 1's kernel, kept as the A/B alternate of the
-    fp16 default) against float64 at the c2 size.  Switches are read once per process, so it runs in a child
-    (tools/bench_gru_bwd.py prints the errors)."""
-    import os
-    import re
-    import subprocess
-    import sys
-    from conftest import REPO
-    env = dict(os.environ, MPNN_GRU_BWD_BF16="1")
-    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "bench_gru_bwd.py")], capture_output=True, text=True,
-                       timeout=600, env=env)
-    assert r.returncode == 0, r.stderr[-2000:]
-    errs = [float(x) for line in r.stdout.splitlines() if "max err / max |ref|" in line
-            for x in re.findall(r"(?:dm|dh|dW_ih|dW_hh|db_ih|db_hh) ([0-9.]+e[+-][0-9]+)", line)]
-    assert len(errs) == 24 and max(errs) < 1e-5, r.stdout
-
-
 @pytest.mark.parametrize("nf,mf,K,V", [(8, 8, 4, 60), (22, 22, 5, 333), (64, 64, 4, 3000), (128, 128, 4, 700),
                                        (256, 256, 3, 300), (64, 32, 2, 500), (64, 64, 100, 900),
                                        (64, 64, 5000, 2500), (24, 40, 4500, 2400), (130, 70, 4200, 2300)])

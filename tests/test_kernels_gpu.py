@@ -375,20 +375,3 @@ def test_gru_forward_wide_row_guards(dev, H, profile):
     nh_ref = gh[:, 2 * H:]
     assert float((sv[:, 3] - nh_ref).abs().max()) < 1e-5 * max(1.0, float(nh_ref.abs().max()))
     assert float(out[mask == 0].abs().max()) == 0.0
-
-
-def test_gru_forward_wide_bf16_alternate_holds_the_parity_bar():
-    """MPNN_GRU_FWD_BF16=1 (three bf16 pieces: round 1's kernels, the A/B alternates of the fp16 default)
-    against float64; switches are read once per process, so it runs in a child (tools/bench_gru_fwd.py prints the error)."""
-    import os
-    import re
-    import subprocess
-    import sys
-    from conftest import REPO
-    env = dict(os.environ, MPNN_GRU_FWD_BF16="1")
-    for width in ("64", "128"):
-        r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "bench_gru_fwd.py"), width], capture_output=True,
-                           text=True, timeout=600, env=env)
-        assert r.returncode == 0, r.stderr[-2000:]
-        err = float(re.search(r"max \|out - float64\| over \d+ atoms = ([0-9.e+-]+)", r.stdout).group(1))
-        assert err < 2e-6, (width, err)

@@ -153,57 +153,6 @@ def test_basic_model_golden_fixture_through_the_tile_kernel(dev, golden):
     assert max_err(state.cpu(), ref_state) < 1e-5 and max_err(out.cpu(), ref) < 1e-4
 
 
-# ------------------------------------------------------------------------------------------ weight gradient on the tile plan
-def _ref_dA(g, h, dagg, K):
-    src, dst, typ = g.col_idx.long(), g.edge_dst.long(), g.edge_type.long()
-    out = []
-    for k in range(K):
-        idx = (typ == k).nonzero().squeeze(1)
-        out.append(dagg.double()[dst[idx]].t() @ h.double()[src[idx]])
-    return torch.stack(out)
-
-
-@pytest.mark.parametrize("n_mols,seed", [(1, 21), (5, 22), (300, 23), (20000, 24)])
-def test_tile_backward_weight_gradient_matches_float64(dev, n_mols, seed):
-    from mpnn_amd import ops
-    mb, g, h = _graph(dev, n_mols, seed)
-    gen = torch.Generator(device=dev).manual_seed(seed)
-    K = g.num_types
-    A = (torch.randn(K, 64, 64, device=dev, generator=gen) / 8.0).requires_grad_(True)
-    dagg = torch.randn(g.num_nodes, 64, device=dev, generator=gen)
-    monkey = {"MPNN_TILE_BWD": "1"}
-    os.environ.update(monkey)                      # opt-in kernel (the per-edge gather kernel is the default: faster)
-    try:
-        out = ops.message_aggregate(h, A, g)
-        out.backward(dagg)
-    finally:
-        del os.environ["MPNN_TILE_BWD"]
-    ref = _ref_dA(g, h, dagg, K)
-    assert max_err(A.grad, ref) / max(1.0, float(ref.abs().max())) < 1e-5
-    # the default kernel (rows gathered per edge from HBM) agrees
-    A2 = A.detach().clone().requires_grad_(True)
-    ops.message_aggregate(h, A2, g).backward(dagg)
-    assert max_err(A.grad, A2.grad) / max(1.0, float(ref.abs().max())) < 1e-5
-
-
-@pytest.mark.parametrize("d_scale,h_scale", [(1e6, 1.0), (1e-7, 1.0), (1.0, 1e5), (1e-12, 1e9)])
-def test_tile_backward_is_scale_invariant(dev, d_scale, h_scale):
-    from mpnn_amd import ops
-    mb, g, h = _graph(dev, 800, 31)
-    gen = torch.Generator(device=dev).manual_seed(31)
-    K = g.num_types
-    A = (torch.randn(K, 64, 64, device=dev, generator=gen) / 8.0).requires_grad_(True)
-    dagg = torch.randn(g.num_nodes, 64, device=dev, generator=gen) * d_scale
-    os.environ["MPNN_TILE_BWD"] = "1"
-    try:
-        ops.message_aggregate(h * h_scale, A, g).backward(dagg)
-    finally:
-        del os.environ["MPNN_TILE_BWD"]
-    ref = _ref_dA(g, h * h_scale, dagg, K)
-    assert torch.isfinite(A.grad).all()
-    assert max_err(A.grad, ref) / float(ref.abs().max()) < 2e-6
-
-
 @pytest.mark.parametrize("K", [1, 2, 3])
 def test_tile_kernel_with_fewer_bond_types(dev, K):
     from mpnn_amd import ops, synth

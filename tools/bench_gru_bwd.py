@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GRU forward/backward kernels alone at hidden 64 (c2 size), 128 (c4 size) or 256: timing and float64 error.
     python tools/bench_gru_bwd.py [128]                      (default: backward on two fp16 pieces, three MFMAs per product)
-    MPNN_GRU_BWD_BF16=1 python tools/bench_gru_bwd.py [128]  (three bf16 pieces, six MFMAs per product)"""
+    MPNN_GRU_MATH=fp32 python tools/bench_gru_bwd.py [128]   (strict fp32 MFMA)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mpnn_amd import ops

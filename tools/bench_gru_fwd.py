@@ -1,6 +1,6 @@
 """GRU forward at hidden 64 (c2 size; or 128 / 256 as argument): timing and float64 error of the running math mode.
-    python tools/bench_gru_fwd.py [64|128|256]                     (default: two row-guarded fp16 pieces, three MFMAs per product)
-    MPNN_GRU_FWD_BF16=1 python tools/bench_gru_fwd.py [64|128|256] (three bf16 pieces, six MFMAs per product)"""
+    python tools/bench_gru_fwd.py [64|128|256]                   (default: two row-guarded fp16 pieces, three MFMAs per product)
+    MPNN_GRU_MATH=fp32 python tools/bench_gru_fwd.py [64|128]    (strict fp32 MFMA)"""
 import os
 import sys
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""A/B of aggregator variants on the c2 graph (run each variant in its own process: the variant is
-read once per process from MPNN_SEGSUM_VARIANT).  Prints ms and algorithmic GB/s."""
+"""The standalone segmented-sum aggregator (mpnn_segsum_f32) on a synthetic graph, beside plain copy / add streams of
+the same byte count: ms and algorithmic GB/s.   python tools/bench_segsum.py [F] [drug|skewed] [mols]"""
 import os
 import sys
 import time
@@ -33,7 +33,7 @@ for weights in (None, w):
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / n
     by = 4.0 * F * (E + V) + 4.0 * (V + 1) + (4.0 * E if weights is not None else 0)
-    print("variant=%s F=%d dist=%s weights=%s  %.4f ms  %.0f GB/s" % (os.environ.get("MPNN_SEGSUM_VARIANT", "1"), F, dist,
+    print("variant=%s F=%d dist=%s weights=%s  %.4f ms  %.0f GB/s" % ("pair+nt", F, dist,
           weights is not None, ms, by / ms / 1e6))
 
 # calibration: plain streaming kernels of the same read:write mix (torch elementwise), same bytes
