@@ -356,6 +356,240 @@ __global__ void __launch_bounds__(512) message_sum_wide_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------ width 64: resident matrices
+// At nf = mf = 64 the K <= 4 matrices fit in LDS as fp16 piece pairs (16 KB per type) next to a whole 256-atom tile of h
+// rows (64 KB as fp32), so nothing is streamed in phases: after the tile's rows are parked (they were fetched into
+// registers during the previous tile, with the tile's slot rows and atom list) every wave walks the bond types of its
+// 32-atom block at its own pace -- sum the neighbours' rows (all 64 columns), guard, split, 24 MFMAs -- and the only
+// block barriers are the two around the parking.  Same plan (graph.py::WidePlan), same math as the kernel above.
+constexpr int M64_K = 4;
+constexpr int M64_AIMG = 8192;                  // one (type, piece) image: 64 output columns x 128 bytes
+constexpr int M64_HT = (MW_TV + 1) * 256;
+__host__ __device__ constexpr int m64_lds_bytes() {
+    return M64_K * 2 * M64_AIMG + M64_HT + MW_ROWS * 64 + MW_TV * 4 + (MW_NB * M64_K + 1) * 4 + 64;
+}
+
+// workspace: scale | inverse, then [type][piece][column n][64 halves], the 16-byte slots of a column XOR-ed by (n >> 1) & 7
+__global__ void __launch_bounds__(256) m64_split_kernel(const float* __restrict__ A, char* __restrict__ ws, int K) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;       // (k, n, octet o)
+    if (idx >= K * 64 * 8) return;
+    const int k = idx >> 9, n = (idx >> 3) & 63, o = idx & 7;
+    const float sc = reinterpret_cast<const float*>(ws)[0];
+    const float* p = A + ((int64_t)k * 64 + n) * 64 + 8 * o;
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(p), x1 = *reinterpret_cast<const f32x4*>(p + 4);
+    h16x8 ph, pl;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = x0[j] * sc, b = x1[j] * sc;
+        ph[j] = (_Float16)a;
+        pl[j] = (_Float16)(a - (float)ph[j]);
+        ph[4 + j] = (_Float16)b;
+        pl[4 + j] = (_Float16)(b - (float)ph[4 + j]);
+    }
+    char* dst = ws + 64 + (int64_t)(2 * k) * M64_AIMG + n * 128 + ((o ^ ((n >> 1) & 7)) << 4);
+    *reinterpret_cast<h16x8*>(dst) = ph;
+    *reinterpret_cast<h16x8*>(dst + M64_AIMG) = pl;
+}
+
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) message_sum_res64_kernel(
+    const float* __restrict__ h, const char* __restrict__ ws, const int32_t* __restrict__ tile_rec,
+    const int32_t* __restrict__ tile_atom, const int32_t* __restrict__ blk_off, const int16_t* __restrict__ slots,
+    float* __restrict__ out, int num_tiles, int K) {
+    constexpr int F = 64, CT = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const AR = smem;                               // resident matrices
+    char* const HT = smem + M64_K * 2 * M64_AIMG;        // the tile's h rows (fp32, 256 bytes each) + the zero row
+    int16_t* const SL = reinterpret_cast<int16_t*>(HT + M64_HT);
+    int* const AT = reinterpret_cast<int*>(reinterpret_cast<char*>(SL) + MW_ROWS * 64);
+    int* const OFF = AT + MW_TV;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hi = lane >> 5;
+    const float a_inv = reinterpret_cast<const float*>(ws)[1];
+
+    // matrices: K x 16 KB, copied verbatim (2 K wave-instructions per wave); the zero row of the h image
+    for (int i = wv; i < K * 16; i += 8) mw_copy(ws + 64 + i * 1024 + lane * 16, lds_addr(AR + i * 1024));
+    if (tid < 16) *reinterpret_cast<f32x4*>(HT + MW_TV * 256 + 16 * tid) = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging registers of the NEXT tile: thread = (row prow + 32 j, 16-byte slot) of the h rows, two slot-row quads,
+    // one atom id, one offset word
+    // The loads are inline assembly on purpose.  A tile's 32 out stores are issued AFTER the next tile's loads and BEFORE
+    // they are used; vmcnt retires in order, so the right wait is "all but the youngest stores" -- but across the loop's
+    // back edge the compiler waits vmcnt(<= 9) for its own loads, i.e. until the tile's stores have been acknowledged as
+    // well (measured: tile time = stream time + compute time instead of their maximum).  Hidden from its bookkeeping,
+    // the loads are waited for by hand in park(): vmcnt(16) -- at least 16 of the 32 stores that follow them stay in flight.
+    const int prow = tid >> 4, pslot = tid & 15;
+    f32x4 pf[8];
+    int4 psl0 = {0, 0, 0, 0}, psl1 = psl0;                // (two named values: as an array they lived in scratch)
+    int pat = -1, poff = 0;
+    auto fetch = [&](int t) {
+        const int a0 = tile_rec[4 * t], n = tile_rec[4 * t + 1], row0 = tile_rec[4 * t + 2], nrows = tile_rec[4 * t + 3];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = prow + 32 * j;
+            const int rr = row < n ? row : n - 1;
+            pf[j] = *reinterpret_cast<const f32x4*>(h + (int64_t)(a0 + rr) * F + 4 * pslot);
+        }
+        const int4* sp = reinterpret_cast<const int4*>(slots + (int64_t)row0 * 32);
+        psl0 = sp[tid < nrows * 4 ? tid : 0];
+        psl1 = sp[tid + 512 < nrows * 4 ? tid + 512 : 0];
+        if (tid < MW_TV) pat = tile_atom[(int64_t)t * MW_TV + tid];
+        if (tid < MW_NB * K + 1) poff = blk_off[(int64_t)t * (MW_NB * K + 1) + tid];
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = prow + 32 * j;
+            *reinterpret_cast<f32x4*>(HT + row * 256 + ((pslot ^ (row & 15)) << 4)) = pf[j];
+        }
+        reinterpret_cast<int4*>(SL)[tid] = psl0;
+        reinterpret_cast<int4*>(SL)[tid + 512] = psl1;
+        if (tid < MW_TV) AT[tid] = pat;
+        if (tid < MW_NB * K + 1) OFF[tid] = poff;
+    };
+
+    int t = blockIdx.x;
+    if (t < num_tiles) fetch(t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the matrices' copies)
+    for (; t < num_tiles; t += gridDim.x) {
+        mw_barrier();                                     // every wave is done with the previous tile's LDS data
+        park();
+        mw_barrier();
+        if (t + (int)gridDim.x < num_tiles) fetch(t + (int)gridDim.x);    // in flight during this tile's work
+
+        f32x16 acc[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+        float row_sc = 0.f, row_inv = 0.f;                // 0 = this atom has not seen a non-zero sum yet
+        for (int k = 0; k < K; ++k) {
+            const int base = __builtin_amdgcn_readfirstlane(OFF[wv * K + k]);
+            const int cnt = __builtin_amdgcn_readfirstlane(OFF[wv * K + k + 1]) - base;
+            if (cnt <= 0) continue;
+            // ---- S: per atom (lane r; half hi holds columns 16 st + 8 hi ...) the sum of its type-k neighbours' rows
+            f32x4 s[4][2];
+#pragma unroll
+            for (int st = 0; st < 4; ++st) s[st][0] = s[st][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            auto add_row = [&](int w) {
+                const char* row = HT + w * 256;
+                const int sw = w & 15;
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const int c0 = 4 * st + 2 * hi;
+                    s[st][0] += *reinterpret_cast<const f32x4*>(row + ((c0 ^ sw) << 4));
+                    s[st][1] += *reinterpret_cast<const f32x4*>(row + (((c0 + 1) ^ sw) << 4));
+                }
+            };
+            {
+                const int16_t* sl = SL + base * 32 + r;
+                int w[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ww = sl[32 * (q < cnt ? q : 0)];
+                    w[q] = q < cnt ? ww : MW_TV;
+                }
+                add_row(w[0]);
+                add_row(w[1]);
+                if (cnt > 2) {
+                    add_row(w[2]);
+                    add_row(w[3]);
+                    for (int q = 4; q < cnt; ++q) add_row(sl[32 * q]);
+                }
+            }
+            // ---- range guard: one power-of-two scale per atom, lowered when a later type's sums outgrow it
+            float mx = 0.f;
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fmaxf(fabsf(s[st][0][u]), fabsf(s[st][1][u])));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const bool unset = row_sc == 0.f;
+            const bool grow = unset ? mx > 0.f : mx * row_sc >= 32768.0f;
+            if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+                int e = (__float_as_int(mx) >> 23) & 0xff;
+                e = e < 40 ? 40 : (e > 240 ? 240 : e);
+                const float ns = grow ? __int_as_float((267 - e) << 23) : row_sc;    // mx * ns in [2^13, 2^14)
+                const float ni = grow ? __int_as_float((e - 13) << 23) : row_inv;
+                if (__builtin_amdgcn_ballot_w64(grow && !unset) != 0) {
+                    const float ratio = unset ? 1.0f : ns * row_inv;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int dr = 8 * (i >> 2) + (i & 3);
+                        const float f_lo = readlane_f(ratio, dr), f_hi = readlane_f(ratio, 4 + dr);
+                        const float f = hi ? f_hi : f_lo;
+#pragma unroll
+                        for (int c = 0; c < CT; ++c) acc[c][i] *= f;
+                    }
+                }
+                row_sc = ns;
+                row_inv = ni;
+            }
+            // ---- split and contract: 4 K = 16 steps x 2 column tiles x 3 MFMAs
+            const char* ak = AR + (2 * k) * M64_AIMG;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                h16x8 ah, al;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float a = s[st][0][u] * row_sc, b = s[st][1][u] * row_sc;
+                    ah[u] = (_Float16)a;
+                    al[u] = (_Float16)(a - (float)ah[u]);
+                    ah[4 + u] = (_Float16)b;
+                    al[4 + u] = (_Float16)(b - (float)ah[4 + u]);
+                }
+                const int o = 2 * st + hi;
+                const int n0 = r, n1 = 32 + r;
+                const char* p0 = ak + n0 * 128 + ((o ^ ((n0 >> 1) & 7)) << 4);
+                const char* p1 = ak + n1 * 128 + ((o ^ ((n1 >> 1) & 7)) << 4);
+                const h16x8 b0h = *reinterpret_cast<const h16x8*>(p0), b0l = *reinterpret_cast<const h16x8*>(p0 + M64_AIMG);
+                const h16x8 b1h = *reinterpret_cast<const h16x8*>(p1), b1l = *reinterpret_cast<const h16x8*>(p1 + M64_AIMG);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b0h, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b1h, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0l, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1l, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0h, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1h, acc[1], 0, 0, 0);
+            }
+        }
+        // ---- out rows
+        int atom[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) atom[i] = AT[32 * wv + 8 * (i >> 2) + (i & 3) + 4 * hi];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int dr = 8 * (i >> 2) + (i & 3);
+            const float u_lo = readlane_f(row_inv, dr), u_hi = readlane_f(row_inv, 4 + dr);
+            const float un = (hi ? u_hi : u_lo) * a_inv;
+            if (atom[i] >= 0) {
+                float* o = out + (int64_t)atom[i] * F + r;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) __builtin_nontemporal_store(acc[c][i] * un, o + 32 * c);
+            }
+        }
+    }
+}
+
+static int launch_message_res64(const float* h, const float* A, const int32_t* tile_rec, const int32_t* tile_atom,
+                                const int32_t* blk_off, const int16_t* slots, float* out, void* workspace,
+                                int64_t num_tiles, int K, hipStream_t s) {
+    static const hipError_t attr = [] {
+        LdsOptIn opt_in_;
+        opt_in_((const void*)message_sum_res64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, m64_lds_bytes());
+        return opt_in_.err;
+    }();
+    if (attr != hipSuccess) return lds_opt_in_failed(attr);
+    char* ws = (char*)workspace;
+    hipLaunchKernelGGL(mw_absmax_kernel, dim3(1), dim3(1024), 0, s, A, (int64_t)K * 64 * 64, (float*)ws);
+    hipLaunchKernelGGL(m64_split_kernel, dim3((unsigned)((K * 512 + 255) / 256)), dim3(256), 0, s, A, ws, K);
+    int64_t blocks = 256;
+    if (blocks > num_tiles) blocks = num_tiles;
+    hipLaunchKernelGGL(message_sum_res64_kernel, dim3((unsigned)blocks), dim3(512), m64_lds_bytes(), s, h, ws, tile_rec,
+                       tile_atom, blk_off, slots, out, (int)num_tiles, K);
+    return launch_status("mpnn_message_aggregate_wide_f32(64)");
+}
+
 size_t message_wide_workspace_bytes(int K, int F) { return 64 + (size_t)K * F * F * 4; }
 
 template <int F>
@@ -395,8 +629,9 @@ extern "C" int mpnn_message_aggregate_wide_f32(const float* h, const float* A, c
                                                const int32_t* tile_atom, const int32_t* blk_off, const int16_t* slots,
                                                float* out, void* workspace, size_t workspace_bytes, int64_t V,
                                                int64_t num_tiles, int K, int nf, int mf, void* stream) {
-    MPNN_REQUIRE(nf == mf && (nf == 128 || nf == 256),
-                 "mpnn_message_aggregate_wide_f32: nf = mf in {128, 256} only (got %d, %d)", nf, mf);
+    MPNN_REQUIRE(nf == mf && (nf == 64 || nf == 128 || nf == 256),
+                 "mpnn_message_aggregate_wide_f32: nf = mf in {64, 128, 256} only (got %d, %d)", nf, mf);
+    MPNN_REQUIRE(nf != 64 || K <= M64_K, "mpnn_message_aggregate_wide_f32: at most %d bond types at width 64 (got %d)", M64_K, K);
     MPNN_REQUIRE(K >= 1 && K <= MW_KMAX, "mpnn_message_aggregate_wide_f32: 1 <= K <= %d bond types (got %d)", MW_KMAX, K);
     MPNN_REQUIRE(V >= 0 && num_tiles >= 0 && num_tiles < (1ll << 24), "mpnn_message_aggregate_wide_f32: bad sizes");
     if (V == 0 || num_tiles == 0) return MPNN_OK;
@@ -406,6 +641,7 @@ extern "C" int mpnn_message_aggregate_wide_f32(const float* h, const float* A, c
                  "mpnn_message_aggregate_wide_f32: workspace of %zu bytes, need %zu", workspace_bytes,
                  message_wide_workspace_bytes(K, nf));
     hipStream_t s = (hipStream_t)stream;
+    if (nf == 64) return launch_message_res64(h, A, tile_rec, tile_atom, blk_off, slots, out, workspace, num_tiles, K, s);
     if (nf == 128) return launch_message_wide_t<128>(h, A, tile_rec, tile_atom, blk_off, slots, out, workspace, num_tiles, K, s);
     return launch_message_wide_t<256>(h, A, tile_rec, tile_atom, blk_off, slots, out, workspace, num_tiles, K, s);
 }

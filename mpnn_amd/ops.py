@@ -163,12 +163,14 @@ def message_aggregate_tile_raw(h, A, graph):
 
 
 def wide_kernel_applies(A, gate, w, graph):
-    """The fused message+sum kernel at widths 128 / 256 (typed aggregate-then-contract on molecule tiles of up to 256
-    atoms, csrc/message_tile_wide.hip) covers: no gate, unit edge weights, nf = mf in {128, 256}, a batch of separate
-    molecules with at most 8 bond types (graph.wide_plan), default math.  MPNN_UNFUSED_MESSAGE=1 keeps the two-kernel
-    path."""
+    """The fused message+sum kernels on molecule tiles of up to 256 atoms (typed aggregate-then-contract,
+    csrc/message_tile_wide.hip) cover: no gate, unit edge weights, nf = mf in {128, 256} with at most 8 bond types, or
+    nf = mf = 64 with at most 4 (the resident-matrix form: what width-64 batches with molecules of more than 128 atoms
+    take, the 128-atom tile kernel of message_tile.hip being tried first), a batch of separate molecules
+    (graph.wide_plan), default math.  MPNN_UNFUSED_MESSAGE=1 keeps the two-kernel path."""
     K, mf, nf = (int(s) for s in A.shape)
-    if (gate is not None or w is not None or mf != nf or nf not in (128, 256) or math_mode() == "fp32"
+    widths = (64, 128, 256) if K <= 4 else (128, 256)    # (width 64: resident matrices, K <= 4)
+    if (gate is not None or w is not None or mf != nf or nf not in widths or math_mode() == "fp32"
             or os.environ.get("MPNN_UNFUSED_MESSAGE")):
         return False
     plan = graph.wide_plan
@@ -321,10 +323,10 @@ class MessageAggregate(torch.autograd.Function):
         gate = gate.contiguous() if gate is not None else None
         ctx.graph = graph
         ctx.save_for_backward(h, A, gate, w)
-        if wide_kernel_applies(A, gate, w, graph):
-            return message_aggregate_wide_raw(h, A, graph)
         if tile_kernel_applies(A, gate, w, graph):
             return message_aggregate_tile_raw(h, A, graph)
+        if wide_kernel_applies(A, gate, w, graph):
+            return message_aggregate_wide_raw(h, A, graph)
         msg = edge_message_raw(h, A, graph, gate)
         return segsum_raw(msg, graph.row_ptr, w, graph.num_nodes)
 

@@ -146,3 +146,59 @@ def test_other_type_counts_and_the_autograd_node(dev, monkeypatch):
         ops.set_kernel_timer(None)
     assert max_err(out.detach(), out2.detach()) < 2e-5
     assert max_err(gA, A.grad) < 1e-5 * float(A.grad.abs().max())
+
+
+# ------------------------------------------------------------------------------------------ width 64, resident matrices
+@pytest.mark.parametrize("n_mols,seed,dist", [(1, 1, "drug"), (3, 2, "drug"), (37, 3, "drug"), (5000, 4, "drug"),
+                                              (40, 6, "skewed"), (1500, 7, "skewed")])
+def test_width64_resident_kernel_matches_float64(dev, n_mols, seed, dist):
+    from mpnn_amd import ops
+    mb, g, h = _graph(dev, n_mols, 64, seed, dist)
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    A = torch.randn(g.num_types, 64, 64, device=dev, generator=gen) / 8.0
+    assert ops.wide_kernel_applies(A, None, None, g)
+    out = ops.message_aggregate_wide_raw(h, A, g)
+    ref = _ref(g, h, A)
+    assert max_err(out, ref) < 1e-5 * max(1.0, float(ref.abs().max()))
+    assert torch.equal(out, ops.message_aggregate_wide_raw(h, A, g))           # bit-reproducible
+
+
+@pytest.mark.parametrize("h_scale,a_scale", [(1e6, 1.0), (1e-6, 1.0), (1.0, 3e4), (1e-20, 1e20)])
+def test_width64_resident_kernel_scales_and_rows_apart(dev, h_scale, a_scale):
+    from mpnn_amd import ops
+    mb, g, h = _graph(dev, 300, 64, 11)
+    gen = torch.Generator(device=dev).manual_seed(11)
+    A = torch.randn(g.num_types, 64, 64, device=dev, generator=gen) / 8.0
+    out = ops.message_aggregate_wide_raw(h * h_scale, A * a_scale, g)
+    ref = _ref(g, h * h_scale, A * a_scale)
+    assert torch.isfinite(out).all() and max_err(out, ref) / float(ref.abs().max()) < 2e-6
+    scale = torch.pow(10.0, torch.randint(-3, 4, (g.num_nodes, 1), device=dev, generator=gen).float())
+    hh = h * scale
+    A2 = A.clone()
+    A2[1] *= 1e-3
+    out = ops.message_aggregate_wide_raw(hh, A2, g)
+    src, dst, typ = g.col_idx.long(), g.edge_dst.long(), g.edge_type.long()
+    bound = torch.zeros(g.num_nodes, 64, dtype=torch.float64, device=dev)
+    for k in range(A2.shape[0]):
+        idx = (typ == k).nonzero().squeeze(1)
+        bound.index_add_(0, dst[idx], hh.double()[src[idx]].abs() @ A2.double()[k].abs().t())
+    assert float(((out.double() - _ref(g, hh, A2)).abs() / (bound + 1e-300)).max()) < 4e-6
+
+
+def test_width64_batches_with_large_molecules_take_the_fused_path(dev):
+    """A width-64 batch with molecules of more than 128 atoms does not fit the 128-atom tile kernel (message_tile.hip);
+    the autograd node then takes the 256-atom resident-matrix kernel instead of the two-kernel path."""
+    from mpnn_amd import ops
+    mb, g, h = _graph(dev, 600, 64, 9, "skewed")
+    assert int(mb.n_atoms.max()) > 128 and g.tile_plan is None and g.wide_plan is not None
+    gen = torch.Generator(device=dev).manual_seed(9)
+    A = torch.randn(g.num_types, 64, 64, device=dev, generator=gen) / 8.0
+    timer = ops.KernelTimer(["message_aggregate", "edge_message", "segsum"])
+    ops.set_kernel_timer(timer)
+    try:
+        out = ops.message_aggregate(h, A, g)
+    finally:
+        ops.set_kernel_timer(None)
+    assert len(timer.events["message_aggregate"]) == 1 and not timer.events["edge_message"]
+    ref = _ref(g, h, A)
+    assert max_err(out, ref) < 1e-5 * max(1.0, float(ref.abs().max()))
