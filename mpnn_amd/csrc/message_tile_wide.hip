@@ -33,6 +33,13 @@ namespace mpnn {
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
+#ifdef MW_STAMP   // diagnostic build only (-DMW_STAMP): cycle sums per phase part of block 3, waves 0 and 7
+__device__ unsigned long long g_mw_stamps[32];
+#define MW_T(var) unsigned long long var; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0)
+#else
+#define MW_T(var)
+#endif
+
 namespace {
 constexpr int MW_TV = 256;          // atoms per tile (upper bound); LDS image row MW_TV is all zeros
 constexpr int MW_NB = 8;            // blocks of 32 atoms = waves
@@ -144,24 +151,21 @@ __global__ void __launch_bounds__(512) message_sum_wide_kernel(
 
     // copies: an h chunk = 256 rows x 128 bytes = 32 wave-instructions (8 rows each), four per wave; lane = (row, 16-byte
     // slot c): the source is slot c ^ (row & 7) of the row's line, so a reader finds slot j at position j ^ (row & 7)
-    auto copy_h = [&](int a0, int n, int kc, int buf) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int row8 = 4 * wv + it;                 // group of 8 rows
+    // (rank, share): this wave copies pieces rank, rank + share, ... -- the waves whose block has no work in a phase take
+    // the phase's copies off the others (in-kernel stamps: issuing its share and waiting for it cost the one wave that is
+    // busy in EVERY phase 1,400 of its 4,600 cycles per phase, while the other waves sat at the barrier)
+    auto copy_h = [&](int a0, int n, int kc, int buf, int rank, int share) {
+        for (int row8 = rank; row8 < 32; row8 += share) {  // group of 8 rows
             const int row = 8 * row8 + (lane >> 3), c = lane & 7;
             const int rr = row < n ? row : n - 1;
             const char* src = reinterpret_cast<const char*>(h + (int64_t)(a0 + rr) * F + 32 * kc) + ((c ^ (row & 7)) << 4);
             mw_copy(src, lds_addr(HB + buf * MW_HB + row8 * 1024));
         }
     };
-    // a matrix chunk = F x 128 bytes, contiguous in the workspace: F / 8 wave-instructions, F / 64 per wave
-    auto copy_a = [&](int phase, int buf) {
+    // a matrix chunk = F x 128 bytes, contiguous in the workspace: F / 8 wave-instructions
+    auto copy_a = [&](int phase, int buf, int rank, int share) {
         const char* src = wsA + (int64_t)phase * ABUF + lane * 16;
-#pragma unroll
-        for (int it = 0; it < F / 64; ++it) {
-            const int blk = (F / 64) * wv + it;
-            mw_copy(src + blk * 1024, lds_addr(AB + buf * ABUF + blk * 1024));
-        }
+        for (int blk = rank; blk < F / 8; blk += share) mw_copy(src + blk * 1024, lds_addr(AB + buf * ABUF + blk * 1024));
     };
 
     // ---- per-wave pieces of a phase
@@ -209,8 +213,8 @@ __global__ void __launch_bounds__(512) message_sum_wide_kernel(
     if (t < num_tiles) {
         a0 = tile_rec[4 * t];
         n = tile_rec[4 * t + 1];
-        copy_h(a0, n, 0, 0);                              // the first tile's first images; later tiles' are requested
-        copy_a(0, 0);                                     // during the previous tile's last chunk
+        copy_h(a0, n, 0, 0, wv, 8);                       // the first tile's first images; later tiles' are requested
+        copy_a(0, 0, wv, 8);                              // during the previous tile's last chunk
     }
     for (; t < num_tiles; t += gridDim.x) {
         const int row0 = tile_rec[4 * t + 2], nrows = tile_rec[4 * t + 3];
@@ -232,6 +236,9 @@ __global__ void __launch_bounds__(512) message_sum_wide_kernel(
         for (int k = 0; k < K; ++k)
             amask |= (__builtin_amdgcn_readfirstlane(OFF[wv * K + k + 1]) > __builtin_amdgcn_readfirstlane(OFF[wv * K + k])) << k;
         if (dbg & 8) amask = 0;
+        // ... and which (block, type) pairs of the whole tile have work: bit b * K + k
+        const unsigned long long pairs = __builtin_amdgcn_ballot_w64(lane < MW_NB * K && OFF[lane < MW_NB * K ? lane + 1 : 1] >
+                                                                                       OFF[lane < MW_NB * K ? lane : 0]);
 
         f32x16 acc[CT];
 #pragma unroll
@@ -285,13 +292,21 @@ __global__ void __launch_bounds__(512) message_sum_wide_kernel(
 
         for (int ph = 0; ph < nphase; ++ph) {
             const int kc = ph / K, k = ph - kc * K;
+            MW_T(s0);
             mw_barrier();                                 // this phase's images are complete, last phase's are free
-            if (!(dbg & 4)) {
-                if (ph + 1 < nphase) copy_a(ph + 1, (ph + 1) & 1);
-                else if (more) copy_a(0, 0);              // next tile, first phase (NKC is even: buffer 0 is free)
+            MW_T(s1);
+            // who copies: the waves without work in this phase, or everybody when every block has some
+            int idle = 0;
+            for (int b = 0; b < MW_NB; ++b) idle |= (int)(((pairs >> (b * K + k)) & 1ull) ^ 1ull) << b;
+            const bool i_copy = idle == 0 || ((idle >> wv) & 1);
+            const int share = idle == 0 ? MW_NB : __builtin_popcount(idle);
+            const int rank = idle == 0 ? wv : __builtin_popcount(idle & ((1 << wv) - 1));
+            if (!(dbg & 4) && i_copy) {
+                if (ph + 1 < nphase) copy_a(ph + 1, (ph + 1) & 1, rank, share);
+                else if (more) copy_a(0, 0, rank, share);   // next tile, first phase (NKC is even: buffer 0 is free)
                 if (k == 0) {
-                    if (kc + 1 < NKC) copy_h(a0, n, kc + 1, (kc + 1) & 1);
-                    else if (more) copy_h(a0n, nn, 0, 0);
+                    if (kc + 1 < NKC) copy_h(a0, n, kc + 1, (kc + 1) & 1, rank, share);
+                    else if (more) copy_h(a0n, nn, 0, 0, rank, share);
                 }
             }
             if ((amask >> k) & 1) {
@@ -301,8 +316,10 @@ __global__ void __launch_bounds__(512) message_sum_wide_kernel(
                     const int b0 = __builtin_amdgcn_readfirstlane(OFF[wv * K + k]);
                     gather(hb, b0, __builtin_amdgcn_readfirstlane(OFF[wv * K + k + 1]) - b0, s);
                 }
+                MW_T(s2);
                 h16x8 ah[2], al[2];
                 guard_split(ah, al);
+                MW_T(s3);
                 // the next type of my block in this chunk: its sums are gathered while this phase's products run
                 const int rest = amask >> (k + 1);
                 have = rest != 0;
@@ -333,8 +350,23 @@ __global__ void __launch_bounds__(512) message_sum_wide_kernel(
                 } else {
                     asm volatile("" ::"v"(ah[0]), "v"(al[0]), "v"(ah[1]), "v"(al[1]));
                 }
+#ifdef MW_STAMP
+                MW_T(s4);
+                if (blockIdx.x == 3 && lane == 0 && (wv == 0 || wv == 7)) {
+                    unsigned long long* q = g_mw_stamps + 16 * (wv == 7);
+                    atomicAdd(q + 4 + 0, s2 - s1); atomicAdd(q + 4 + 1, s3 - s2); atomicAdd(q + 4 + 2, s4 - s3); atomicAdd(q + 4 + 3, 1ull);
+                }
+#endif
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my copies for the next phase have landed
+            MW_T(s5);
+            if (i_copy) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my copies for the next phase have landed
+#ifdef MW_STAMP
+            MW_T(s6);
+            if (blockIdx.x == 3 && lane == 0 && (wv == 0 || wv == 7)) {
+                unsigned long long* q = g_mw_stamps + 16 * (wv == 7);
+                atomicAdd(q + 0, s1 - s0); atomicAdd(q + 1, s5 - s1); atomicAdd(q + 2, s6 - s5); atomicAdd(q + 3, 1ull);
+            }
+#endif
         }
         // ---- out rows: accumulator (row 8 (i >> 2) + (i & 3) + 4 hi, column 32 c + r) scaled back, at the atom's place
         int atom[16];
@@ -617,6 +649,16 @@ static int launch_message_wide_t(const float* h, const float* A, const int32_t* 
 }  // namespace mpnn
 
 using namespace mpnn;
+
+#ifdef MW_STAMP
+extern "C" int mpnn_debug_mw_stamps(unsigned long long* host32, int reset) {
+    if (reset) {
+        unsigned long long z[32] = {0};
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_mw_stamps), z, sizeof(z));
+    }
+    return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(g_mw_stamps), 32 * sizeof(unsigned long long));
+}
+#endif
 
 extern "C" int mpnn_message_aggregate_wide_tile_atoms(void) { return MW_TV; }
 extern "C" int mpnn_message_aggregate_wide_max_types(void) { return MW_KMAX; }
