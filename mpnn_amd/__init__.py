@@ -8,4 +8,4 @@
 Importing the package needs neither a GPU nor the built library; the first kernel call loads
 mpnn_amd/lib/libmpnn_amd.so and raises if it is missing (there is no CPU fallback).
 """
-__version__ = "0.1.0"
+__version__ = "0.3.0"

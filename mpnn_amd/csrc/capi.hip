@@ -26,7 +26,7 @@ const Switches& switches() {
 }
 }  // namespace mpnn
 
-extern "C" int mpnn_version(void) { return 200; /* 0.2.0 */ }
+extern "C" int mpnn_version(void) { return 300; /* 0.3.0: mpnn_gru_update_f32 takes a workspace, mpnn_message_aggregate_wide_f32 added, mpnn_message_aggregate_bwd_da_f32 removed */ }
 
 extern "C" int mpnn_init(void) {
     (void)mpnn::switches();
