@@ -456,6 +456,12 @@ def main():
         hoisted = (timed(step_fwd), timed(step_train) if args.mode == "train" else float("nan"))
         model.hoist_message = False
 
+    unfused_norm = None
+    if world == 1 and getattr(model, "fuse_norm", False) and model._norm_fusable(afm):
+        model.fuse_norm = False
+        unfused_norm = (timed(step_fwd), timed(step_train) if args.mode == "train" else float("nan"))
+        model.fuse_norm = True
+
     cold = None
     if world == 1 and args.scaling == "weak":
         # what a training loop that sees a NEW batch every step would pay on top of the resident-batch step time:
@@ -618,6 +624,12 @@ def main():
             out["cold_batch"] = cold
         if fp32_pipe is not None:
             out["fp32_pipe"] = fp32_pipe
+        if unfused_norm is not None:
+            out["standalone_norm"] = {
+                "train_ms_per_step": unfused_norm[1] / args.steps * 1e3, "forward_ms_per_step": unfused_norm[0] / args.steps * 1e3,
+                "note": "NOT the headline: the same model with fuse_norm=False -- the masked norm after every update as "
+                        "reduction + apply passes of its own (the headline takes the norm's moments in the update kernel's "
+                        "epilogue and applies it where the next update reads its state, mpnn_gru_update_norm_f32)"}
         if hoisted is not None:
             out["hoisted_message"] = {
                 "train_ms_per_step": hoisted[1] / args.steps * 1e3, "forward_ms_per_step": hoisted[0] / args.steps * 1e3,

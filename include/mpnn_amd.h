@@ -247,6 +247,24 @@ int mpnn_gru_update_f32(const float* m, const float* h, const float* mask,
                         float* out, float* saved, void* workspace, size_t workspace_bytes, int64_t V, int H,
                         void* stream);
 /*
+ * The same update with the masked batch norm that the lipo / attention models put in front of its `h` input fused in
+ * (replaces: models/mask_batch_norm.py:5-38 composed with gru_update.py:26-35 as models/att_model.py:58 and
+ * lipo_basic_model.py:85 call them).  `h_raw` is the previous update's RAW output y; the state the
+ * reference normalises in passes of its own is  hn = (y * h_scale[col] + h_shift[col]) * mask  (h_scale = gamma /
+ * std, h_shift = beta - mean * gamma / std of the norm in question) and is formed inside the kernel.  The caller folds
+ * the same affine map into the hidden weights: W_hh_folded[k, :] = h_scale[k] * W_hh[k, :], b_hh_folded = b_hh +
+ * h_shift W_hh.  out_moments [2H] doubles, ACCUMULATED (caller zeroes): column sums of `out` and of out^2 over all
+ * atoms -- the moments the norm that follows this update needs, so it runs no reduction pass.  With saved != NULL the
+ * kernel also writes h_norm [V,H] (= hn, the `h` operand of mpnn_gru_update_bwd_f32).  Widths: those for which
+ * mpnn_gru_update_norm_supported(H) returns 1 (128, 256; 0 under MPNN_GRU_MATH=fp32); the workspace is required.
+ */
+int mpnn_gru_update_norm_supported(int H);
+int mpnn_gru_update_norm_f32(const float* m, const float* h_raw, const float* mask, const float* W_ih,
+                             const float* W_hh_folded, const float* b_ih, const float* b_hh_folded,
+                             const float* h_scale, const float* h_shift, float* out, float* saved,
+                             float* h_norm, double* out_moments, void* workspace, size_t workspace_bytes,
+                             int64_t V, int H, void* stream);
+/*
  * Backward: given dout [V,H] and `saved`, writes dm [V,H], dh [V,H] and ACCUMULATES into
  * dW_ih, dW_hh [H,3H], db_ih, db_hh [3H] (caller zeroes them).  `workspace`: mpnn_gru_bwd_workspace_bytes(V, H)
  * bytes.  At H = 64 the backward is one kernel that keeps the gate gradients in LDS and needs NO workspace (the

@@ -329,6 +329,9 @@ int launch_gru_split(const float* m, const float* h, const float* mask, const fl
                      const float* b_ih, const float* b_hh, float* out, float* saved, int64_t V, int H, void* workspace,
                      hipStream_t s);
 size_t gru_fwd_workspace_bytes(int H);
+int launch_gru_split_norm(const float* m, const float* h, const float* mask, const float* W_ih, const float* W_hh,
+                          const float* b_ih, const float* b_hh, const float* hs, const float* ht, float* out,
+                          float* saved, float* hnorm, double* stats, int64_t V, int H, void* workspace, hipStream_t s);
 
 }  // namespace mpnn
 
@@ -373,4 +376,33 @@ extern "C" int mpnn_gru_update_f32(const float* m, const float* h, const float* 
     hipLaunchKernelGGL(gru_update_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, m, h, mask, W_ih,
                        W_hh, b_ih, b_hh, out, saved, V, H, (int)row_tiles, col_slices);
     return launch_status("mpnn_gru_update_f32");
+}
+
+extern "C" int mpnn_gru_update_norm_supported(int H) {
+    return (H == 128 || H == 256) && !switches().math_fp32 ? 1 : 0;
+}
+
+extern "C" int mpnn_gru_update_norm_f32(const float* m, const float* h_raw, const float* mask, const float* W_ih,
+                                        const float* W_hh_folded, const float* b_ih, const float* b_hh_folded,
+                                        const float* h_scale, const float* h_shift, float* out, float* saved,
+                                        float* h_norm, double* out_moments, void* workspace, size_t workspace_bytes,
+                                        int64_t V, int H, void* stream) {
+    MPNN_REQUIRE(mpnn_gru_update_norm_supported(H), "mpnn_gru_update_norm_f32: no fused-norm kernel at H=%d%s", H,
+                 switches().math_fp32 ? " under MPNN_GRU_MATH=fp32" : "");
+    MPNN_REQUIRE(V >= 0, "mpnn_gru_update_norm_f32: V=%lld out of range", (long long)V);
+    if (V == 0) return MPNN_OK;
+    MPNN_REQUIRE(m && h_raw && W_ih && W_hh_folded && b_ih && b_hh_folded && h_scale && h_shift && out && out_moments,
+                 "mpnn_gru_update_norm_f32: NULL buffer");
+    MPNN_REQUIRE(!saved || h_norm, "mpnn_gru_update_norm_f32: a training pass (saved != NULL) also needs h_norm");
+    MPNN_REQUIRE(workspace && workspace_bytes >= gru_fwd_workspace_bytes(H),
+                 "mpnn_gru_update_norm_f32: workspace of mpnn_gru_fwd_workspace_bytes(V, H) bytes required");
+    const uintptr_t al = reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(h_raw) |
+                         reinterpret_cast<uintptr_t>(W_ih) | reinterpret_cast<uintptr_t>(W_hh_folded) |
+                         reinterpret_cast<uintptr_t>(workspace);
+    MPNN_REQUIRE(al % 16 == 0 && reinterpret_cast<uintptr_t>(out_moments) % 8 == 0,
+                 "mpnn_gru_update_norm_f32: buffers must be 16-byte aligned");
+    const int rc = launch_gru_split_norm(m, h_raw, mask, W_ih, W_hh_folded, b_ih, b_hh_folded, h_scale, h_shift, out,
+                                         saved, h_norm, out_moments, V, H, workspace, (hipStream_t)stream);
+    MPNN_REQUIRE(rc != 1, "mpnn_gru_update_norm_f32: width %d not covered", H);
+    return rc;
 }

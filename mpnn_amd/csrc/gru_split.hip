@@ -491,13 +491,27 @@ __device__ __forceinline__ void w_copy_to_lds(const char* src, unsigned lds_dst)
                  : "memory");
 }
 
-template <int H, bool HAS_MASK, bool SAVE, bool F16 = false, bool WS = false>
+// NORM (the masked batch norm of models/mask_batch_norm.py:5-38 fused into the update): `h` is the RAW
+// output of the previous update; the state the reference would have normalised in a pass of its own is
+// hn = (h * hs[col] + ht[col]) * mask, formed here where the epilogue reads h anyway (the contraction sees it through
+// weights and biases the caller folded: W_hh' = diag(hs) W_hh, b_hh' = b_hh + ht W_hh).  The column sums of `out` and of
+// its squares over the rows written -- the moments the NEXT norm needs -- leave through `stats` (2 H doubles, the caller
+// zeroes them), and with SAVE `hn` is written for the backward pass.
+struct GruNormArgs {
+    const float* hs;     // (H) scale of h
+    const float* ht;     // (H) shift of h
+    float* hnorm;        // (V, H) normalised state, written with SAVE
+    double* stats;       // [0, H) sum of out, [H, 2H) sum of out^2
+};
+
+template <int H, bool HAS_MASK, bool SAVE, bool F16 = false, bool WS = false, bool NORM = false>
 __global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
     const float* __restrict__ m, const float* __restrict__ h, const float* __restrict__ mask,
     const float* __restrict__ W_ih, const float* __restrict__ W_hh, const float* __restrict__ b_ih,
     const float* __restrict__ b_hh, float* __restrict__ out, float* __restrict__ saved, int64_t V,
-    const char* __restrict__ wws) {
+    const char* __restrict__ wws, GruNormArgs na) {
     static_assert(!WS || F16, "pre-split weights are fp16 pieces");
+    static_assert(!NORM || WS, "the fused norm rides on the pre-split kernel");
     constexpr int NS = H / 64, NCHUNK = H / 32, COLS = 192;
     constexpr int IMGC = COLS * 64;            // bytes of one (matrix, piece) chunk image: 192 columns x 32 k of 16 bits
     constexpr int NP = F16 ? 2 : 3;            // pieces per operand
@@ -506,6 +520,8 @@ __global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
     __shared__ float redw[8];
     __shared__ float bias_s[4][64];            // the slice's gate biases (b_r, b_z, b_in, b_hn): read per tile from LDS --
                                                // as per-lane global pointers they were loop invariants that got spilled
+    __shared__ float norm_s[NORM ? 2 : 1][64];            // NORM: the slice's hs | ht
+    __shared__ double stat_s[NORM ? 8 : 1][2][64];        // NORM: per wave, column sums of out | out^2 over its tiles
 
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
     const int slice = jb % NS;                                 // the NS slice blocks of a row group share an XCD
@@ -523,7 +539,13 @@ __global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
         bias_s[1][tid] = b_ih[H + fc] + b_hh[H + fc];
         bias_s[2][tid] = b_ih[2 * H + fc];
         bias_s[3][tid] = b_hh[2 * H + fc];
+        if (NORM) {
+            norm_s[0][tid] = na.hs[fc];
+            norm_s[1][tid] = na.ht[fc];
+        }
     }                                                          // (the first chunk's barrier publishes them)
+    if (NORM)
+        for (int i = tid; i < 8 * 2 * 64; i += 512) (&stat_s[0][0][0])[i] = 0.0;
 
     // F16: one power-of-two scale for the block's weights (its 64 features x 3 gates of both matrices land below 2^15)
     float w_sc = 1.0f, w_inv = 1.0f;
@@ -755,10 +777,13 @@ __global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
             __builtin_amdgcn_sched_barrier(0);
             float* ob = out + tile * 32 * H + eo;
             float* sb = saved + tile * 32 * 4 * H + so;
+            float* nb_out = NORM && SAVE ? na.hnorm + tile * 32 * H + eo : nullptr;
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
                 const float br = bias_s[0][32 * nb + r], bz = bias_s[1][32 * nb + r];      // this lane's output feature
                 const float bni = bias_s[2][32 * nb + r], bnh = bias_s[3][32 * nb + r];
+                float hsc = 1.0f, hsh = 0.0f, sum1 = 0.0f, sum2 = 0.0f;
+                if (NORM) { hsc = norm_s[0][32 * nb + r]; hsh = norm_s[1][32 * nb + r]; }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int dr = 8 * (i >> 2) + (i & 3);
@@ -776,10 +801,16 @@ __global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
                     const float zg = sigmoid_fast(acc_z[nb][i] * un + bz) * mk;
                     const float nh = acc_nh[nb][i] * un + bnh;
                     const float ng = tanh_fast(acc_ni[nb][i] * un + bni + rg * nh) * mk;
-                    const float hval = FULL ? hv[nb][i] : (row0 + dr < V ? hb[dr * H + 32 * nb] : 0.f);
+                    float hval = FULL ? hv[nb][i] : (row0 + dr < V ? hb[dr * H + 32 * nb] : 0.f);
+                    if (NORM) hval = fmaf(hval, hsc, hsh) * mk;
                     const float o = ((1.0f - zg) * ng + zg * hval) * mk;
                     if (FULL || row0 + dr < V) {
                         __builtin_nontemporal_store(o, ob + dr * H + 32 * nb);
+                        if (NORM) {
+                            sum1 += o;
+                            sum2 = fmaf(o, o, sum2);
+                            if (SAVE) __builtin_nontemporal_store(hval, nb_out + dr * H + 32 * nb);
+                        }
                         if (SAVE) {
                             float* sv = sb + dr * 4 * H + 32 * nb;
                             __builtin_nontemporal_store(rg, sv);
@@ -790,12 +821,30 @@ __global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if (NORM) {                                // the tile's 32 rows of this column, then the wave's running sum
+                    sum1 += __shfl_xor(sum1, 32);
+                    sum2 += __shfl_xor(sum2, 32);
+                    if (hi == 0) {
+                        stat_s[wv][0][32 * nb + r] += (double)sum1;
+                        stat_s[wv][1][32 * nb + r] += (double)sum2;
+                    }
+                }
             }
         };
         // (in the last round a wave's whole tile can lie past V: nothing to do then)
         if (tile * 32 + 32 <= V) epilogue(std::true_type{});
         else if (tile * 32 < V) epilogue(std::false_type{});
         tile = tile_next;
+    }
+    if (NORM) {
+        __syncthreads();
+        if (tid < 128) {
+            const int k = tid >> 6, cl = tid & 63;
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) t += stat_s[w][k][cl];
+            atomicAdd(na.stats + k * H + 64 * slice + cl, t);
+        }
     }
 }
 
@@ -806,7 +855,7 @@ size_t gru_fwd_workspace_bytes(int H) {
 template <int H>
 static int launch_stream_wide(const float* m, const float* h, const float* mask, const float* W_ih, const float* W_hh,
                          const float* b_ih, const float* b_hh, float* out, float* saved, int64_t V, void* workspace,
-                         hipStream_t s) {
+                         const GruNormArgs* norm, hipStream_t s) {
     constexpr int NS = H / 64;
     const bool presplit = workspace != nullptr;              // weights split once per launch, copied global -> LDS
     const size_t lds = (size_t)2 * 4 * 192 * 64;             // two fp16 pieces per operand, row-wise range guards
@@ -821,6 +870,10 @@ static int launch_stream_wide(const float* m, const float* h, const float* mask,
         opt_in_((const void*)gru_update_stream_wide_kernel<H, true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n16);
         opt_in_((const void*)gru_update_stream_wide_kernel<H, false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n16);
         opt_in_((const void*)gru_update_stream_wide_kernel<H, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n16);
+        opt_in_((const void*)gru_update_stream_wide_kernel<H, true, true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n16);
+        opt_in_((const void*)gru_update_stream_wide_kernel<H, true, false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n16);
+        opt_in_((const void*)gru_update_stream_wide_kernel<H, false, true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n16);
+        opt_in_((const void*)gru_update_stream_wide_kernel<H, false, false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, n16);
         return opt_in_.err;
     }();
     if (attr_done != hipSuccess) return lds_opt_in_failed(attr_done);
@@ -830,16 +883,21 @@ static int launch_stream_wide(const float* m, const float* h, const float* mask,
     pblocks = (pblocks + 7) / 8 * 8;                        // XCD-aware numbering wants groups of 8 row blocks
     const dim3 grid((unsigned)(pblocks * NS)), block(512);
     const char* wws = (const char*)workspace;
+    if (norm && !presplit) return 1;                         // the fused norm exists on the pre-split kernel only
+    const GruNormArgs na = norm ? *norm : GruNormArgs{nullptr, nullptr, nullptr, nullptr};
     if (presplit)
         hipLaunchKernelGGL(gru_fwd_presplit_kernel<H>, dim3(NS * (H / 32)), dim3(512), 0, s, W_ih, W_hh, (char*)workspace);
 #define MPNN_LAUNCH_WIDE(MASKED, SAVED)                                                                                  \
     do {                                                                                                                 \
-        if (presplit)                                                                                                    \
+        if (norm)                                                                                                        \
+            hipLaunchKernelGGL((gru_update_stream_wide_kernel<H, MASKED, SAVED, true, true, true>), grid, block, lds, s, \
+                               m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, wws, na);                              \
+        else if (presplit)                                                                                               \
             hipLaunchKernelGGL((gru_update_stream_wide_kernel<H, MASKED, SAVED, true, true>), grid, block, lds, s, m, h, \
-                               mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, wws);                                        \
+                               mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, wws, na);                                    \
         else                                                                                                             \
             hipLaunchKernelGGL((gru_update_stream_wide_kernel<H, MASKED, SAVED, true>), grid, block, lds, s, m, h, mask, \
-                               W_ih, W_hh, b_ih, b_hh, out, saved, V, wws);                                              \
+                               W_ih, W_hh, b_ih, b_hh, out, saved, V, wws, na);                                          \
     } while (0)
     if (mask && saved) MPNN_LAUNCH_WIDE(true, true);
     else if (mask) MPNN_LAUNCH_WIDE(true, false);
@@ -854,8 +912,19 @@ int launch_gru_split(const float* m, const float* h, const float* mask, const fl
                      const float* b_ih, const float* b_hh, float* out, float* saved, int64_t V, int H, void* workspace,
                      hipStream_t s) {
     if (H == 64) return launch_split<64, 2, 8>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, s);
-    if (H == 128) return launch_stream_wide<128>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, workspace, s);
-    if (H == 256) return launch_stream_wide<256>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, workspace, s);
+    if (H == 128) return launch_stream_wide<128>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, workspace, nullptr, s);
+    if (H == 256) return launch_stream_wide<256>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, workspace, nullptr, s);
+    return 1;
+}
+
+// the update with the masked batch norm of its `h` input folded in and the moments of its output taken (NORM above);
+// returns 1 when the width has no such kernel
+int launch_gru_split_norm(const float* m, const float* h, const float* mask, const float* W_ih, const float* W_hh,
+                          const float* b_ih, const float* b_hh, const float* hs, const float* ht, float* out,
+                          float* saved, float* hnorm, double* stats, int64_t V, int H, void* workspace, hipStream_t s) {
+    const GruNormArgs na{hs, ht, hnorm, stats};
+    if (H == 128) return launch_stream_wide<128>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, workspace, &na, s);
+    if (H == 256) return launch_stream_wide<256>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, workspace, &na, s);
     return 1;
 }
 

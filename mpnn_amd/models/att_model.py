@@ -3,12 +3,19 @@ Reference: models/att_model.py:6-59 (default readout Set2Vec, as there)."""
 import torch
 from torch import nn
 
+from mpnn_amd import ops
 from mpnn_amd.mpnn_functions import AdjMsgAgg, AttEdgeNetwork, GRUUpdate, Set2Vec
 from ._batch import graph_of
 from .mask_batch_norm import MaskBatchNorm
 
 
 class BasicModel(nn.Module):
+    # True: where the library has the kernel (hidden 128 / 256), the parameter-free masked norm after each update is not
+    # run as passes of its own -- its moments come out of the update kernel's epilogue and it is applied where the NEXT
+    # update reads its state (ops.gru_update_norm_in).  Same function of the inputs; False = the
+    # standalone norm kernels, as at every other width.
+    fuse_norm = True
+
     def __init__(self, node_features, edge_features, message_features, adjacency_dim, output_dim,
                  message_func=AttEdgeNetwork, message_opts={},
                  message_agg_func=AdjMsgAgg, agg_opts={},
@@ -35,8 +42,33 @@ class BasicModel(nn.Module):
         self.of = readout_func(**readout_opts)
         self.bn = MaskBatchNorm()
 
+    def _norm_fusable(self, afm):
+        return (self.fuse_norm and type(self.bn) is MaskBatchNorm and not self.bn.sync_stats
+                and type(self.uf) is GRUUpdate and self.uf.mf == self.uf.nf == afm.shape[-1]
+                and ops.gru_norm_applies(self.uf.nf, afm))
+
+    def _message_passing_fused_norm(self, afm, bfm, adj, mask, graph):
+        """models/att_model.py:57-58 with bn(uf(...)) evaluated as: update t takes the RAW output of update t-1 plus its
+        moments, normalises it on the way in, and emits its own moments; only the last norm (whose output the readout
+        reads) is an apply pass of its own."""
+        cell = self.uf.gru_cell
+        mk = mask.reshape(-1)
+        count = mk.sum().reshape(1)
+        y, moments = afm.reshape(-1, cell.nf), None
+        for mf in self.mfs:
+            if hasattr(mf, "bind_graph"):
+                mf.bind_graph(graph)
+            msg = self.ma(mf(afm, bfm), adj).reshape(-1, cell.mf)
+            y, moments = ops.gru_update_norm_in(msg, y, mk, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh,
+                                                moments=moments, eps=1e-6, flags=ops.BN_EPS_INSIDE, count=count)
+        if moments is None:
+            return afm
+        return ops.masked_batch_norm_given(y, mk, moments, eps=1e-6, flags=ops.BN_EPS_INSIDE).view(afm.shape)
+
     def message_passing(self, afm, bfm, adj, mask):
         graph = graph_of(afm, bfm, adj)
+        if self._norm_fusable(afm):
+            return self._message_passing_fused_norm(afm, bfm, adj, mask, graph), graph
         node_state = afm
         for mf in self.mfs:
             if hasattr(mf, "bind_graph"):

@@ -471,6 +471,151 @@ class GRUUpdateFn(torch.autograd.Function):
         return dm, dh, None, dW_ih, dW_hh, db_ih, db_hh, None
 
 
+# ---- masked batch norm fused into the update (models/att_model.py:58, lipo_basic_model.py:85) ----
+def gru_norm_applies(H, tensor):
+    """True when mpnn_gru_update_norm_f32 covers hidden width H on this tensor's device."""
+    return bool(tensor.is_cuda and tensor.dtype == torch.float32 and _lib.load().mpnn_gru_update_norm_supported(int(H)))
+
+
+class OutputMoments:
+    """Column sums of an update's output and of its squares over all atoms (2H doubles, from the update kernel's
+    epilogue) with the masked atom count: the batch statistics the norm after that update needs."""
+
+    def __init__(self, sums, count):
+        self.sums, self.count = sums, count               # (2H,) float64, (1,) float32 = mask.sum()
+        self._mv = None
+
+    def mean_var(self):
+        if self._mv is None:
+            H = self.sums.shape[0] // 2
+            n = self.count.double()
+            mean = self.sums[:H] / n
+            var = (self.sums[H:] / n - mean * mean).clamp_min_(0.0)      # biased, as mask_batch_norm.py:14,31
+            self._mv = (mean.float(), var.float())
+        return self._mv
+
+
+def _norm_scale(var, eps, flags):
+    return torch.sqrt(var + eps) if flags & BN_EPS_INSIDE else torch.sqrt(var) + eps
+
+
+class GRUUpdateNormIn(torch.autograd.Function):
+    """y, sums = update(m, norm(y_prev)) with the norm applied inside the update kernel and the moments of y taken
+    in its epilogue.  `y_prev` is the previous update's raw output, (mean, var) its batch statistics (None: `y_prev`
+    enters as it is -- the first step).  Backward = the GRU backward kernels on the normalised state the forward
+    kernel saved, then the masked-norm backward kernels (reduction + apply) for y_prev."""
+
+    @staticmethod
+    def forward(ctx, m, y_prev, mask, W_ih, W_hh, b_ih, b_hh, weight, bias, mean, var, count, eps, flags, grad_mode):
+        lib = _lib.load()
+        m, y_prev = m.contiguous(), y_prev.contiguous()
+        mask = mask.contiguous() if mask is not None else None
+        V, H = int(y_prev.shape[0]), int(y_prev.shape[1])
+        W_ih, W_hh, b_ih, b_hh = W_ih.contiguous(), W_hh.contiguous(), b_ih.contiguous(), b_hh.contiguous()
+        normed = mean is not None
+        if normed:
+            inv = 1.0 / _norm_scale(var, eps, flags)
+            hs = inv * weight if weight is not None else inv
+            ht = -mean * hs + (bias if bias is not None else 0.0)
+            Wf = (W_hh * hs.unsqueeze(1)).contiguous()                    # hn W_hh + b_hh = y (diag(hs) W_hh) + (ht W_hh + b_hh)
+            bf = torch.addmv(b_hh, W_hh.t(), ht)
+        else:
+            hs, ht = torch.ones(H, dtype=torch.float32, device=m.device), torch.zeros(H, dtype=torch.float32, device=m.device)
+            Wf, bf = W_hh, b_hh
+        need = grad_mode and any(ctx.needs_input_grad)
+        out = _empty((V, H), y_prev)
+        saved = _empty((V, 4 * H), y_prev) if need else None
+        hn = _empty((V, H), y_prev) if need else None
+        sums = torch.zeros(2 * H, dtype=torch.float64, device=m.device)
+        ws_bytes = lib.mpnn_gru_fwd_workspace_bytes(V, H)
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=m.device)
+        _lib.check(_timed("gru_update", lambda: lib.mpnn_gru_update_norm_f32(
+            _lib.fptr(m), _lib.fptr(y_prev), _lib.fptr(mask), _lib.fptr(W_ih), _lib.fptr(Wf), _lib.fptr(b_ih),
+            _lib.fptr(bf), _lib.fptr(hs), _lib.fptr(ht), _lib.fptr(out), _lib.fptr(saved), _lib.fptr(hn),
+            _lib.ptr(sums), _lib.ptr(ws), ws_bytes, V, H, _lib.stream())), "mpnn_gru_update_norm_f32")
+        if need:
+            ctx.save_for_backward(m, hn, y_prev if normed else None, mask, W_ih, W_hh, saved, weight, mean, var, count)
+        ctx.normed, ctx.eps, ctx.flags = normed, float(eps), int(flags)
+        ctx.mark_non_differentiable(sums)
+        return out, sums
+
+    @staticmethod
+    def backward(ctx, dout, _dsums):
+        lib = _lib.load()
+        m, hn, y_prev, mask, W_ih, W_hh, saved, weight, mean, var, count = ctx.saved_tensors
+        dm, dhn, dW_ih, dW_hh, db_ih, db_hh = gru_update_bwd_raw(dout.contiguous(), m, hn, mask, W_ih, W_hh, saved)
+        dweight = dbias = None
+        if ctx.normed:
+            V, F = int(hn.shape[0]), int(hn.shape[1])
+            dy = _empty((V, F), hn)
+            if weight is not None:
+                dweight, dbias = _empty((F,), hn), _empty((F,), hn)
+            ws_bytes = lib.mpnn_masked_bn_workspace_bytes(F)
+            ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=hn.device)
+            _lib.check(lib.mpnn_masked_bn_bwd_f32(_lib.fptr(dhn), _lib.fptr(y_prev), _lib.fptr(mask), _lib.fptr(weight),
+                                                  _lib.fptr(mean), _lib.fptr(var), _lib.fptr(dy), _lib.fptr(dweight),
+                                                  _lib.fptr(dbias), V, F, ctx.eps, ctx.flags, _lib.fptr(count),
+                                                  _lib.ptr(ws), ws_bytes, _lib.stream()), "mpnn_masked_bn_bwd_f32")
+        else:
+            dy = dhn
+        return dm, dy, None, dW_ih, dW_hh, db_ih, db_hh, dweight, dbias, None, None, None, None, None, None
+
+
+def gru_update_norm_in(m, y_prev, mask, W_ih, W_hh, b_ih, b_hh, moments=None, weight=None, bias=None, eps=1e-6,
+                       flags=BN_EPS_INSIDE, count=None):
+    """-> (y, OutputMoments of y).  `moments`: OutputMoments of y_prev when y_prev is to be normalised on the way in."""
+    if count is None:
+        count = moments.count if moments is not None else (mask.sum().reshape(1) if mask is not None else
+                                                            torch.full((1,), float(y_prev.shape[0]), device=m.device))
+    mean, var = moments.mean_var() if moments is not None else (None, None)
+    y, sums = GRUUpdateNormIn.apply(m, y_prev, mask, W_ih, W_hh, b_ih, b_hh, weight, bias, mean, var, count, eps, flags,
+                                    torch.is_grad_enabled())
+    return y, OutputMoments(sums, count)
+
+
+class MaskedBatchNormGiven(torch.autograd.Function):
+    """Masked batch norm whose batch statistics were taken elsewhere (the producing update's epilogue): the forward is
+    the apply pass alone, the backward the full batch-statistics backward (the statistics depend on x)."""
+
+    @staticmethod
+    def forward(ctx, x, mask, weight, bias, mean, var, count, eps, flags):
+        lib = _lib.load()
+        x = x.contiguous()
+        V, F = int(x.shape[0]), int(x.shape[1])
+        y = _empty((V, F), x)
+        mean_c, var_c = mean.contiguous().clone(), var.contiguous().clone()
+        ws_bytes = lib.mpnn_masked_bn_workspace_bytes(F)
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+        _lib.check(lib.mpnn_masked_bn_fwd_f32(_lib.fptr(x), _lib.fptr(mask), _lib.fptr(weight), _lib.fptr(bias), _lib.fptr(y),
+                                              _lib.fptr(mean_c), _lib.fptr(var_c), None, V, F, float(eps),
+                                              int(flags) | BN_USE_STATS, _lib.ptr(ws), ws_bytes, _lib.stream()),
+                   "mpnn_masked_bn_fwd_f32")
+        ctx.save_for_backward(x, mask, weight, mean_c, var_c, count)
+        ctx.eps, ctx.flags = float(eps), int(flags)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, mask, w, mean, var, count = ctx.saved_tensors
+        V, F = int(x.shape[0]), int(x.shape[1])
+        dx = _empty((V, F), x)
+        dweight = _empty((F,), x) if w is not None else None
+        dbias = _empty((F,), x) if w is not None else None
+        ws_bytes = lib.mpnn_masked_bn_workspace_bytes(F)
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+        _lib.check(lib.mpnn_masked_bn_bwd_f32(_lib.fptr(dy.contiguous()), _lib.fptr(x), _lib.fptr(mask), _lib.fptr(w),
+                                              _lib.fptr(mean), _lib.fptr(var), _lib.fptr(dx), _lib.fptr(dweight),
+                                              _lib.fptr(dbias), V, F, ctx.eps, ctx.flags, _lib.fptr(count), _lib.ptr(ws),
+                                              ws_bytes, _lib.stream()), "mpnn_masked_bn_bwd_f32")
+        return dx, None, dweight, dbias, None, None, None, None, None
+
+
+def masked_batch_norm_given(x, mask, moments, weight=None, bias=None, eps=1e-6, flags=BN_EPS_INSIDE):
+    mean, var = moments.mean_var()
+    return MaskedBatchNormGiven.apply(x, mask, weight, bias, mean, var, moments.count, eps, flags)
+
+
 def segsum(msg, row_ptr, w=None, num_rows=None):
     return SegSum.apply(msg, row_ptr, w, int(row_ptr.shape[0]) - 1 if num_rows is None else num_rows)
 
