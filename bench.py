@@ -629,7 +629,8 @@ def main():
                 "train_ms_per_step": unfused_norm[1] / args.steps * 1e3, "forward_ms_per_step": unfused_norm[0] / args.steps * 1e3,
                 "note": "NOT the headline: the same model with fuse_norm=False -- the masked norm after every update as "
                         "reduction + apply passes of its own (the headline takes the norm's moments in the update kernel's "
-                        "epilogue and applies it where the next update reads its state, mpnn_gru_update_norm_f32)"}
+                        "epilogue, applies it where the next update reads its state, and runs the norms' backward inside the "
+                        "GRU backward kernels: mpnn_gru_update_norm_f32 / mpnn_gru_update_norm_bwd_f32)"}
         if hoisted is not None:
             out["hoisted_message"] = {
                 "train_ms_per_step": hoisted[1] / args.steps * 1e3, "forward_ms_per_step": hoisted[0] / args.steps * 1e3,

@@ -280,6 +280,25 @@ int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const float* h, c
                             float* dm, float* dh, float* dW_ih, float* dW_hh,
                             float* db_ih, float* db_hh, void* workspace, size_t workspace_bytes,
                             int64_t V, int H, void* stream);
+/*
+ * Backward of mpnn_gru_update_norm_f32 with BOTH masked-norm backward passes fused in (models/mask_batch_norm.py:5-38
+ * differentiated).  Same outputs and accumulation rules as mpnn_gru_update_bwd_f32 on h = h_norm, plus:
+ *   out_norm_k [3H] = k1 | k2 | k4, or NULL.  Non-NULL: `dout` is the gradient of norm(out) (out = this update's raw
+ *     output y), and the gate-gradient kernel forms  dy = dout * k1 + y * k2 + k4  on rows with mask 1 from the saved
+ *     gates (y is not read).  For a norm with scale s (sqrt(var + eps), or sqrt(var) + eps), weight g, bias b, batch
+ *     mean, count n and the column sums S_b = sum dout, S_h = sum dout * norm(out):
+ *       S_g = (S_h - b S_b) s / g;  dvar = -g S_g / (2 s^2 root)  (root = s, or sqrt(var) with eps outside);
+ *       k1 = g / s;  k2 = 2 dvar / n;  k4 = -g S_b / (s n) - mean k2          (ops.GRUNormChain has it in torch ops).
+ *   in_norm_sums [2H] doubles, ACCUMULATED (caller zeroes), or NULL.  Non-NULL: h_norm = norm(y_prev); the dm | dh
+ *     kernel adds the column sums of dh_norm and of dh_norm * h_norm -- S_b and S_h of THAT norm -- so the update before
+ *     this one can be called with their out_norm_k and no norm-backward pass runs at all.
+ * Widths and workspace as mpnn_gru_update_norm_f32 / mpnn_gru_bwd_workspace_bytes.
+ */
+int mpnn_gru_update_norm_bwd_f32(const float* dout, const float* m, const float* h_norm, const float* mask,
+                                 const float* W_ih, const float* W_hh, const float* saved, const float* out_norm_k,
+                                 float* dm, float* dh_norm, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh,
+                                 double* in_norm_sums, void* workspace, size_t workspace_bytes, int64_t V, int H,
+                                 void* stream);
 
 /* ------------------------------------------------------------------ masked batch norm */
 /*
@@ -301,6 +320,22 @@ int mpnn_masked_bn_bwd_f32(const float* dout, const float* x, const float* mask,
                            const float* mean, const float* var, float* dx, float* dweight, float* dbias,
                            int64_t V, int F, float eps, int flags, const float* count, void* workspace,
                            size_t workspace_bytes, void* stream);
+
+/*
+ * Per-column constants of the norm fused into the update (row f2): tiny kernels, one launch each.
+ * mpnn_norm_fold_f32: moments [2F] doubles (sum y | sum y^2 from mpnn_gru_update_norm_f32), count [1] = sum(mask) ->
+ *   mean, var [F] (biased variance, as mask_batch_norm.py:14,31), h_scale, h_shift [F] of the norm selected by
+ *   (weight, bias, eps, flags: the MPNN masked-norm flags of mpnn_masked_bn_fwd_f32), and W_hh_folded [F,3F],
+ *   b_hh_folded [3F] as mpnn_gru_update_norm_f32 takes them.  F <= 256.
+ * mpnn_norm_bwd_consts_f32: sums [2F] doubles (in_norm_sums of mpnn_gru_update_norm_bwd_f32) + the norm's statistics
+ *   -> out_norm_k [3F] for the update in front of that norm; dweight / dbias [F] (affine norms) are ACCUMULATED.
+ */
+int mpnn_norm_fold_f32(const double* moments, const float* count, const float* weight, const float* bias,
+                       const float* W_hh, const float* b_hh, float* mean, float* var, float* h_scale, float* h_shift,
+                       float* W_hh_folded, float* b_hh_folded, int F, float eps, int flags, void* stream);
+int mpnn_norm_bwd_consts_f32(const double* sums, const float* mean, const float* var, const float* count,
+                             const float* weight, const float* bias, float* out_norm_k, float* dweight, float* dbias,
+                             int F, float eps, int flags, void* stream);
 
 #ifdef __cplusplus
 }

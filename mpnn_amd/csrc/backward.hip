@@ -647,7 +647,8 @@ namespace mpnn {
 size_t gru_bwd_f16_workspace_bytes(int64_t V, int H);                      // gru_bwd128_f16.hip (H = 128, 256)
 int launch_gru_bwd_f16_wide(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
                             const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
-                            float* db_ih, float* db_hh, void* workspace, int64_t V, int H, hipStream_t s);
+                            float* db_ih, float* db_hh, void* workspace, int64_t V, int H, const float* out_norm_k,
+                            double* in_norm_sums, hipStream_t s);
 }  // namespace mpnn
 
 extern "C" size_t mpnn_gru_bwd_workspace_bytes(int64_t V, int H) {
@@ -684,7 +685,7 @@ extern "C" int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const 
     // widths: elementwise gate gradients into a (V, 6H) workspace + generic fp32 contractions below
     if ((H == 128 || H == 256) && !fp32_only)
         return launch_gru_bwd_f16_wide(dout, m, h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, workspace, V, H,
-                                       s);
+                                       nullptr, nullptr, s);
     hipLaunchKernelGGL(gru_gate_grad_kernel<false>, dim3((unsigned)g), dim3(256), 0, s, dout, h, mask, saved, ws, dh, V,
                        H);
     rc = launch_status("mpnn_gru_update_bwd_f32(gates)");
@@ -770,4 +771,26 @@ extern "C" int mpnn_edge_message_agg_bwd_da_f32(const float* dagg, const float* 
     else { if (gate) MPNN_DA64(false, true); else MPNN_DA64(false, false); }
 #undef MPNN_DA64
     return launch_status("mpnn_edge_message_agg_bwd_da_f32");
+}
+
+int mpnn_gru_update_norm_supported(int H);
+
+extern "C" int mpnn_gru_update_norm_bwd_f32(const float* dout, const float* m, const float* h_norm, const float* mask,
+                                            const float* W_ih, const float* W_hh, const float* saved,
+                                            const float* out_norm_k, float* dm, float* dh_norm, float* dW_ih,
+                                            float* dW_hh, float* db_ih, float* db_hh, double* in_norm_sums,
+                                            void* workspace, size_t workspace_bytes, int64_t V, int H, void* stream) {
+    MPNN_REQUIRE(mpnn_gru_update_norm_supported(H), "mpnn_gru_update_norm_bwd_f32: no fused-norm kernels at H=%d%s", H,
+                 switches().math_fp32 ? " under MPNN_GRU_MATH=fp32" : "");
+    MPNN_REQUIRE(V >= 0, "mpnn_gru_update_norm_bwd_f32: V=%lld out of range", (long long)V);
+    if (V == 0) return MPNN_OK;
+    MPNN_REQUIRE(dout && m && h_norm && W_ih && W_hh && saved && dm && dh_norm && dW_ih && dW_hh && db_ih && db_hh,
+                 "mpnn_gru_update_norm_bwd_f32: NULL buffer");
+    if (!workspace || workspace_bytes < mpnn_gru_bwd_workspace_bytes(V, H)) {
+        set_error("mpnn_gru_update_norm_bwd_f32: workspace %zu < %zu", workspace_bytes, mpnn_gru_bwd_workspace_bytes(V, H));
+        return MPNN_EWORKSPACE;
+    }
+    MPNN_REQUIRE(V * 6 * (int64_t)H < (1ll << 40), "mpnn_gru_update_norm_bwd_f32: V too large");
+    return launch_gru_bwd_f16_wide(dout, m, h_norm, mask, W_ih, W_hh, saved, dm, dh_norm, dW_ih, dW_hh, db_ih, db_hh, workspace,
+                                   V, H, out_norm_k, in_norm_sums, (hipStream_t)stream);
 }

@@ -91,11 +91,18 @@ __device__ __forceinline__ h16x8 g_tr8(const char* a0, const char* a1) {
 // ------------------------------------------------------------------------------------------------ gate gradients
 // Block = one 32-atom tile per iteration; thread = (row tid >> 4, column groups c16 + 16 j (8 columns each) of every
 // segment, j < H / 128).  The tile's values stay in registers between the maximum and the split.
-template <int H, bool HAS_MASK>
+// NORM (the backward of the masked batch norm that follows this update, fused): `dout` is then the
+// gradient of the NORMALISED state hn' = norm(y), y = this update's own output, and the gradient of y is
+//     dy = dout * k1[col] + y * k2[col] + k4[col]                       (rows with mask 1; the others get none)
+// with column constants the caller derives from the norm's statistics and from the column sums of dout and dout * hn'
+// (which the dm | dh kernel of the FOLLOWING update took in its epilogue).  y is not read: it is (1-z) n + z h of the saved
+// gates and the h this kernel reads anyway.  kn = k1 | k2 | k4, 3 H floats.
+template <int H, bool HAS_MASK, bool NORM = false>
 __global__ void __launch_bounds__(512) gru_gate_f16_kernel(const float* __restrict__ dout, const float* __restrict__ h,
                                                            const float* __restrict__ mask, const float* __restrict__ saved,
                                                            char* __restrict__ pieces, float* __restrict__ inv_scale,
-                                                           float* __restrict__ dh, float* db_ih, float* db_hh, int64_t V) {
+                                                           float* __restrict__ dh, float* db_ih, float* db_hh, int64_t V,
+                                                           const float* __restrict__ kn) {
     constexpr int NG = H / 128;                            // column groups per thread
     constexpr int TILE_BYTES = 32 * 4 * H * 4;
     constexpr int SEG_BYTES = (H / 16) * 2048;             // ksteps of one segment
@@ -113,6 +120,8 @@ __global__ void __launch_bounds__(512) gru_gate_f16_kernel(const float* __restri
         const bool ok = row < V;
         if (!ok) row = V - 1;
         const float mk = ok ? (HAS_MASK ? mask[row] : 1.0f) : 0.0f;
+        unsigned kofs = 0;
+        if (NORM) asm volatile("" : "+v"(kofs));
         f32x4 seg[NG][4][2], gz[NG][2];
         float mx = 0.f;
 #pragma unroll
@@ -128,7 +137,17 @@ __global__ void __launch_bounds__(512) gru_gate_f16_kernel(const float* __restri
                 const f32x4 z = *reinterpret_cast<const f32x4*>(sv + H);
                 const f32x4 n = *reinterpret_cast<const f32x4*>(sv + 2 * H);
                 const f32x4 nh = *reinterpret_cast<const f32x4*>(sv + 3 * H);
-                const f32x4 g = v_do * mk;                 // through the final "* mask"
+                f32x4 g = v_do * mk;                       // through the final "* mask"
+                if (NORM) {
+                    // (column constants re-read per tile behind an opaque offset: as loop invariants they would take
+                    // 24 registers per column group and spill at H = 256)
+                    const float* kp = kn + kofs + c8 + 4 * q;
+                    const f32x4 k1 = *reinterpret_cast<const f32x4*>(kp);
+                    const f32x4 k2 = *reinterpret_cast<const f32x4*>(kp + H);
+                    const f32x4 k4 = *reinterpret_cast<const f32x4*>(kp + 2 * H);
+                    const f32x4 y = ((1.0f - z) * n + z * vh) * mk;
+                    g = (v_do * k1 + y * k2 + k4) * mk;
+                }
                 const f32x4 dn = g * (1.0f - z);
                 const f32x4 dz = g * (vh - n);
                 const f32x4 dan = dn * mk * (1.0f - n * n);    // n = tanh(.)*mask
@@ -254,19 +273,25 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_presplit_kernel(const float* _
         }
 }
 
-template <int H, bool WS = false>
+// NORM: `h` entered the update as hn = norm(y_prev); the backward of that norm needs the column sums of dh and of
+// dh * hn over all atoms.  They are taken here, where dh is final: `hn` is read in the accumulator layout, the sums go
+// to `sums` (2 H doubles, accumulated; per wave in LDS across its tiles, one atomic per column and block at the end).
+template <int H, bool WS = false, bool NORM = false>
 __global__ void __launch_bounds__(512) gru_bwd_dx_wide_f16_kernel(const char* __restrict__ pieces,
                                                                   const float* __restrict__ inv_scale,
                                                                   const float* __restrict__ W_ih,
                                                                   const float* __restrict__ W_hh, float* __restrict__ dm,
                                                                   float* __restrict__ dh, int64_t V,
-                                                                  const char* __restrict__ wws) {
+                                                                  const char* __restrict__ wws,
+                                                                  const float* __restrict__ hn, double* sums) {
+    static_assert(!NORM || WS, "the fused norm rides on the pre-split kernel");
     constexpr int NS = H / 128, CPS = H / 32, NCT = 4 * CPS;
     constexpr int TILE_BYTES = 32 * 4 * H * 4;
     constexpr int IMGC = 128 * 64;             // one (matrix, piece) chunk image: 128 output rows x 32 k fp16
     constexpr int BUF = 4 * IMGC;              // 32 KB
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float redw[8];
+    __shared__ double stat_s[NORM ? 8 : 1][2][128];            // NORM: per wave, column sums of dh | dh * hn
 
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
     const int slice = jb % NS;
@@ -278,6 +303,8 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_wide_f16_kernel(const char* __
     const int64_t rounds_total = (V + 255) / 256;              // a round = 256 rows: every wave its own 32-row tile
     if (pblock >= rounds_total) return;
     const int64_t nrounds = (rounds_total - pblock + pblocks - 1) / pblocks;
+    if (NORM)
+        for (int i = tid; i < 8 * 2 * 128; i += 512) (&stat_s[0][0][0])[i] = 0.0;   // (published by the first chunk's barrier)
 
     // one scale for the block's weights: largest magnitude of its 128 rows of both matrices
     float inv_sw = 1.0f, sw = 1.0f;
@@ -424,29 +451,54 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_wide_f16_kernel(const char* __
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
                 const int fcol = 128 * slice + 32 * nb + r;
+                float sum_d = 0.0f, sum_dh = 0.0f;
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    float prev[4];
+                    float prev[4], hv[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         int64_t row = tile * 32 + 8 * g4 + 4 * hi + u;
                         if (row >= V) row = V - 1;
                         prev[u] = dh[row * H + fcol];
+                        if (NORM) hv[u] = hn[row * H + fcol];
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int i = 4 * g4 + u;
                         const int64_t row = tile * 32 + 8 * g4 + 4 * hi + u;
                         if (row < V) {
+                            const float dhv = d_h[nb][i] * un + prev[u];
                             dm[row * H + fcol] = d_m[nb][i] * un;
-                            dh[row * H + fcol] = d_h[nb][i] * un + prev[u];
+                            dh[row * H + fcol] = dhv;
+                            if (NORM) {
+                                sum_d += dhv;
+                                sum_dh = fmaf(dhv, hv[u], sum_dh);
+                            }
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if (NORM) {
+                    sum_d += __shfl_xor(sum_d, 32);
+                    sum_dh += __shfl_xor(sum_dh, 32);
+                    if (hi == 0) {
+                        stat_s[wv][0][32 * nb + r] += (double)sum_d;
+                        stat_s[wv][1][32 * nb + r] += (double)sum_dh;
+                    }
+                }
             }
         }
         tile = tile_next;
+    }
+    if (NORM) {
+        __syncthreads();
+        if (tid < 256) {
+            const int k = tid >> 7, cl = tid & 127;
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) t += stat_s[w][k][cl];
+            atomicAdd(sums + k * H + 128 * slice + cl, t);
+        }
     }
 }
 
@@ -657,10 +709,13 @@ size_t gru_bwd_f16_workspace_bytes(int64_t V, int H) {
     return (size_t)tiles * (32 * 4 * H * 4) + (size_t)((tiles + 63) / 64 * 64) * sizeof(float) + gru_bwd_f16_dxw_bytes(H);
 }
 
+// out_norm_k != NULL: dout is the gradient of norm(out), the gate kernel turns it into the gradient of out (NORM there);
+// in_norm_sums != NULL: h = hn = norm(y_prev), the dm | dh kernel also takes the column sums the backward of THAT norm needs
 template <int H>
 static int launch_gru_bwd_f16_t(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
                                 const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
-                                float* db_ih, float* db_hh, void* workspace, int64_t V, hipStream_t s) {
+                                float* db_ih, float* db_hh, void* workspace, int64_t V, const float* out_norm_k,
+                                double* in_norm_sums, hipStream_t s) {
     const int64_t tiles = (V + 31) / 32;
     char* pieces = (char*)workspace;
     float* inv_scale = (float*)(pieces + (size_t)tiles * (32 * 4 * H * 4));
@@ -669,6 +724,7 @@ static int launch_gru_bwd_f16_t(const float* dout, const float* m, const float* 
     static const hipError_t attr_done = [&] {   // once per process, thread-safe (C++11 static initialisation)
         LdsOptIn opt_in_;
         opt_in_((const void*)gru_bwd_dx_wide_f16_kernel<H, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64);
+        opt_in_((const void*)gru_bwd_dx_wide_f16_kernel<H, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64);
         opt_in_((const void*)gru_bwd_dw_f16_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dw);
         return opt_in_.err;
     }();
@@ -676,12 +732,18 @@ static int launch_gru_bwd_f16_t(const float* dout, const float* m, const float* 
 
     int64_t gg = H == 128 ? 1024 : 512;
     if (gg > tiles) gg = tiles;
-    if (mask)
+    if (mask && out_norm_k)
+        hipLaunchKernelGGL((gru_gate_f16_kernel<H, true, true>), dim3((unsigned)gg), dim3(512), 0, s, dout, h, mask, saved,
+                           pieces, inv_scale, dh, db_ih, db_hh, V, out_norm_k);
+    else if (out_norm_k)
+        hipLaunchKernelGGL((gru_gate_f16_kernel<H, false, true>), dim3((unsigned)gg), dim3(512), 0, s, dout, h, mask, saved,
+                           pieces, inv_scale, dh, db_ih, db_hh, V, out_norm_k);
+    else if (mask)
         hipLaunchKernelGGL((gru_gate_f16_kernel<H, true>), dim3((unsigned)gg), dim3(512), 0, s, dout, h, mask, saved, pieces,
-                           inv_scale, dh, db_ih, db_hh, V);
+                           inv_scale, dh, db_ih, db_hh, V, out_norm_k);
     else
         hipLaunchKernelGGL((gru_gate_f16_kernel<H, false>), dim3((unsigned)gg), dim3(512), 0, s, dout, h, mask, saved, pieces,
-                           inv_scale, dh, db_ih, db_hh, V);
+                           inv_scale, dh, db_ih, db_hh, V, out_norm_k);
     int rc = launch_status("mpnn_gru_update_bwd_f32(gates, fp16 pieces)");
     if (rc) return rc;
 
@@ -692,8 +754,14 @@ static int launch_gru_bwd_f16_t(const float* dout, const float* m, const float* 
         if (pblocks > rounds) pblocks = rounds;
         pblocks = (pblocks + 7) / 8 * 8;
         hipLaunchKernelGGL(gru_bwd_dx_presplit_kernel<H>, dim3((unsigned)(NS * 4 * (H / 32))), dim3(512), 0, s, W_ih, W_hh, dxw);
-        hipLaunchKernelGGL((gru_bwd_dx_wide_f16_kernel<H, true>), dim3((unsigned)(pblocks * NS)), dim3(512),
-                           (size_t)2 * 4 * 128 * 64, s, pieces, inv_scale, W_ih, W_hh, dm, dh, V, (const char*)dxw);
+        if (in_norm_sums)
+            hipLaunchKernelGGL((gru_bwd_dx_wide_f16_kernel<H, true, true>), dim3((unsigned)(pblocks * NS)), dim3(512),
+                               (size_t)2 * 4 * 128 * 64, s, pieces, inv_scale, W_ih, W_hh, dm, dh, V, (const char*)dxw, h,
+                               in_norm_sums);
+        else
+            hipLaunchKernelGGL((gru_bwd_dx_wide_f16_kernel<H, true>), dim3((unsigned)(pblocks * NS)), dim3(512),
+                               (size_t)2 * 4 * 128 * 64, s, pieces, inv_scale, W_ih, W_hh, dm, dh, V, (const char*)dxw,
+                               (const float*)nullptr, (double*)nullptr);
     }
     rc = launch_status("mpnn_gru_update_bwd_f32(dx, fp16 pieces)");
     if (rc) return rc;
@@ -708,10 +776,13 @@ static int launch_gru_bwd_f16_t(const float* dout, const float* m, const float* 
 
 int launch_gru_bwd_f16_wide(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
                             const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
-                            float* db_ih, float* db_hh, void* workspace, int64_t V, int H, hipStream_t s) {
+                            float* db_ih, float* db_hh, void* workspace, int64_t V, int H, const float* out_norm_k,
+                            double* in_norm_sums, hipStream_t s) {
     if (H == 128)
-        return launch_gru_bwd_f16_t<128>(dout, m, h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, workspace, V, s);
-    return launch_gru_bwd_f16_t<256>(dout, m, h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, workspace, V, s);
+        return launch_gru_bwd_f16_t<128>(dout, m, h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, workspace, V,
+                                         out_norm_k, in_norm_sums, s);
+    return launch_gru_bwd_f16_t<256>(dout, m, h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, workspace, V,
+                                     out_norm_k, in_norm_sums, s);
 }
 
 }  // namespace mpnn

@@ -271,6 +271,74 @@ static int bn_grid(int64_t V, int F) {
     return (int)g;
 }
 
+// ---- the norm fused into the GRU update (gru_split.hip NORM, gru_bwd128_f16.hip NORM): per-column constants ----
+// moments (2F doubles: sum y | sum y^2 over the masked atoms) -> mean, var (biased, as the reference), the affine map
+// hn = y * hs + ht of the norm, and the hidden weights / biases with that map folded in:
+//   Wf[k, :] = hs[k] * W_hh[k, :],  bf = b_hh + ht W_hh.          One thread per gate column j < 3F.
+__global__ void __launch_bounds__(256) bn_fold_kernel(const double* __restrict__ moments, const float* __restrict__ count,
+                                                      const float* __restrict__ weight, const float* __restrict__ bias,
+                                                      const float* __restrict__ W_hh, const float* __restrict__ b_hh,
+                                                      float* __restrict__ mean, float* __restrict__ var,
+                                                      float* __restrict__ hs, float* __restrict__ ht,
+                                                      float* __restrict__ Wf, float* __restrict__ bf, int F, float eps,
+                                                      int flags) {
+    __shared__ float s_hs[256], s_ht[256];
+    const double n = (double)*count;
+    for (int c = threadIdx.x; c < F; c += 256) {
+        const double mu = moments[c] / n;
+        double v = moments[F + c] / n - mu * mu;
+        v = v > 0.0 ? v : 0.0;
+        const float vf = (float)v, mf = (float)mu;
+        const float g = weight ? weight[c] : 1.0f, b = weight ? bias[c] : 0.0f;
+        const float sc = g / bn_scale(vf, eps, flags);
+        s_hs[c] = sc;
+        s_ht[c] = b - mf * sc;
+        if (blockIdx.x == 0) {
+            mean[c] = mf;
+            var[c] = vf;
+            hs[c] = sc;
+            ht[c] = b - mf * sc;
+        }
+    }
+    __syncthreads();
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= 3 * F) return;
+    float acc = b_hh[j];
+    for (int k = 0; k < F; ++k) {
+        const float w = W_hh[(int64_t)k * 3 * F + j];
+        Wf[(int64_t)k * 3 * F + j] = w * s_hs[k];
+        acc = fmaf(s_ht[k], w, acc);
+    }
+    bf[j] = acc;
+}
+
+// column sums of d hn and d hn * hn (2F doubles, from the dm | dh kernel's epilogue) + the norm's statistics -> the three
+// constants of  dy = d hn * k1 + y * k2 + k4  (include/mpnn_amd.h has the derivation), and the norm's own parameter
+// gradients, accumulated
+__global__ void __launch_bounds__(256) bn_bwd_consts_kernel(const double* __restrict__ sums, const float* __restrict__ mean,
+                                                            const float* __restrict__ var, const float* __restrict__ count,
+                                                            const float* __restrict__ weight, const float* __restrict__ bias,
+                                                            float* __restrict__ kn, float* __restrict__ dweight,
+                                                            float* __restrict__ dbias, int F, float eps, int flags) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= F) return;
+    const double n = (double)*count;
+    const double g = weight ? (double)weight[c] : 1.0, b = weight ? (double)bias[c] : 0.0;
+    const double s = (double)bn_scale(var[c], eps, flags), rs = 1.0 / s;
+    const double Sb = sums[c], Sh = sums[F + c];
+    const double Sg = g != 0.0 ? (Sh - b * Sb) * s / g : 0.0;          // sum d hn * mask * (y - mean)
+    const double root = (flags & kBnEpsInside) ? s : sqrt((double)var[c]);
+    const double dvar = root > 0.0 ? (-g * Sg * rs * rs) / (2.0 * root) : 0.0;
+    const double k2 = 2.0 * dvar / n;
+    kn[c] = (float)(g * rs);
+    kn[F + c] = (float)k2;
+    kn[2 * F + c] = (float)(-g * Sb * rs / n - (double)mean[c] * k2);
+    if (dweight) {
+        dweight[c] += (float)(Sg * rs);
+        dbias[c] += (float)Sb;
+    }
+}
+
 }  // namespace mpnn
 
 using namespace mpnn;
@@ -343,4 +411,29 @@ extern "C" int mpnn_masked_bn_bwd_f32(const float* dout, const float* x, const f
                            dweight, dbias, V, F, eps, flags, count);
     }
     return launch_status("mpnn_masked_bn_bwd_f32");
+}
+
+extern "C" int mpnn_norm_fold_f32(const double* moments, const float* count, const float* weight, const float* bias,
+                                  const float* W_hh, const float* b_hh, float* mean, float* var, float* h_scale,
+                                  float* h_shift, float* W_hh_folded, float* b_hh_folded, int F, float eps, int flags,
+                                  void* stream) {
+    MPNN_REQUIRE(F > 0 && F <= 256, "mpnn_norm_fold_f32: F=%d out of range (<= 256)", F);
+    MPNN_REQUIRE(moments && count && W_hh && b_hh && mean && var && h_scale && h_shift && W_hh_folded && b_hh_folded,
+                 "mpnn_norm_fold_f32: NULL buffer");
+    MPNN_REQUIRE((weight == nullptr) == (bias == nullptr), "mpnn_norm_fold_f32: weight and bias go together");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((unsigned)((3 * F + 255) / 256)), dim3(256), 0, (hipStream_t)stream, moments, count,
+                       weight, bias, W_hh, b_hh, mean, var, h_scale, h_shift, W_hh_folded, b_hh_folded, F, eps, flags);
+    return launch_status("mpnn_norm_fold_f32");
+}
+
+extern "C" int mpnn_norm_bwd_consts_f32(const double* sums, const float* mean, const float* var, const float* count,
+                                        const float* weight, const float* bias, float* out_norm_k, float* dweight,
+                                        float* dbias, int F, float eps, int flags, void* stream) {
+    MPNN_REQUIRE(F > 0 && F <= 1024, "mpnn_norm_bwd_consts_f32: F=%d out of range", F);
+    MPNN_REQUIRE(sums && mean && var && count && out_norm_k, "mpnn_norm_bwd_consts_f32: NULL buffer");
+    MPNN_REQUIRE((weight == nullptr) == (bias == nullptr) && (weight == nullptr) == (dweight == nullptr) &&
+                 (dweight == nullptr) == (dbias == nullptr), "mpnn_norm_bwd_consts_f32: weight, bias and their gradients go together");
+    hipLaunchKernelGGL(bn_bwd_consts_kernel, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sums, mean,
+                       var, count, weight, bias, out_norm_k, dweight, dbias, F, eps, flags);
+    return launch_status("mpnn_norm_bwd_consts_f32");
 }

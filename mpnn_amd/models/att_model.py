@@ -10,10 +10,10 @@ from .mask_batch_norm import MaskBatchNorm
 
 
 class BasicModel(nn.Module):
-    # True: where the library has the kernel (hidden 128 / 256), the parameter-free masked norm after each update is not
-    # run as passes of its own -- its moments come out of the update kernel's epilogue and it is applied where the NEXT
-    # update reads its state (ops.gru_update_norm_in).  Same function of the inputs; False = the
-    # standalone norm kernels, as at every other width.
+    # True: where the library has the kernels (hidden 128 / 256), the parameter-free masked norm after each update is not
+    # run as passes of its own -- its moments come out of the update kernel's epilogue, it is applied where the NEXT
+    # update reads its state, and its backward rides on the GRU backward kernels the same way (ops.GRUNormChain;
+    # SURVEY 8 row f2).  Same function of the inputs; False = the standalone norm kernels, as at every other width.
     fuse_norm = True
 
     def __init__(self, node_features, edge_features, message_features, adjacency_dim, output_dim,
@@ -48,22 +48,19 @@ class BasicModel(nn.Module):
                 and ops.gru_norm_applies(self.uf.nf, afm))
 
     def _message_passing_fused_norm(self, afm, bfm, adj, mask, graph):
-        """models/att_model.py:57-58 with bn(uf(...)) evaluated as: update t takes the RAW output of update t-1 plus its
-        moments, normalises it on the way in, and emits its own moments; only the last norm (whose output the readout
-        reads) is an apply pass of its own."""
+        """models/att_model.py:57-58.  The messages depend on the atom features only (`mf(afm, bfm)`), so all of them are
+        formed first; the T updates and norms then run as one chain (ops.GRUNormChain): update t reads the RAW output
+        of update t-1 with the norm folded in and emits the moments of its own output, the backward kernels do the
+        same for the norms' backward; only the last norm (whose output the readout reads) has passes of its own."""
         cell = self.uf.gru_cell
-        mk = mask.reshape(-1)
-        count = mk.sum().reshape(1)
-        y, moments = afm.reshape(-1, cell.nf), None
+        msgs = []
         for mf in self.mfs:
             if hasattr(mf, "bind_graph"):
                 mf.bind_graph(graph)
-            msg = self.ma(mf(afm, bfm), adj).reshape(-1, cell.mf)
-            y, moments = ops.gru_update_norm_in(msg, y, mk, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh,
-                                                moments=moments, eps=1e-6, flags=ops.BN_EPS_INSIDE, count=count)
-        if moments is None:
-            return afm
-        return ops.masked_batch_norm_given(y, mk, moments, eps=1e-6, flags=ops.BN_EPS_INSIDE).view(afm.shape)
+            msgs.append(self.ma(mf(afm, bfm), adj).reshape(-1, cell.mf))
+        out = ops.gru_norm_chain(afm.reshape(-1, cell.nf), msgs, mask.reshape(-1), cell.weight_ih, cell.weight_hh,
+                                 cell.bias_ih, cell.bias_hh, eps=1e-6, flags=ops.BN_EPS_INSIDE)
+        return out.view(afm.shape)
 
     def message_passing(self, afm, bfm, adj, mask):
         graph = graph_of(afm, bfm, adj)

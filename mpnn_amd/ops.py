@@ -573,6 +573,135 @@ def gru_update_norm_in(m, y_prev, mask, W_ih, W_hh, b_ih, b_hh, moments=None, we
     return y, OutputMoments(sums, count)
 
 
+def _norm_fold(sums, count, weight, bias, W_hh, b_hh, eps, flags):
+    """moments of an update's output -> (mean, var, hs, ht, W_hh with the norm folded in, b_hh likewise): one launch."""
+    lib = _lib.load()
+    H = int(W_hh.shape[0])
+    dev = W_hh.device
+    mean, var, hs, ht = (torch.empty(H, dtype=torch.float32, device=dev) for _ in range(4))
+    Wf, bf = torch.empty_like(W_hh), torch.empty_like(b_hh)
+    _lib.check(lib.mpnn_norm_fold_f32(_lib.ptr(sums), _lib.fptr(count), _lib.fptr(weight), _lib.fptr(bias), _lib.fptr(W_hh),
+                                      _lib.fptr(b_hh), _lib.fptr(mean), _lib.fptr(var), _lib.fptr(hs), _lib.fptr(ht),
+                                      _lib.fptr(Wf), _lib.fptr(bf), H, float(eps), int(flags), _lib.stream()),
+               "mpnn_norm_fold_f32")
+    return mean, var, hs, ht, Wf, bf
+
+
+class GRUNormChain(torch.autograd.Function):
+    """state_t = norm(update(m_t, state_{t-1})), t = 1..T, state_0 = h0  (models/att_model.py:57-58 with the messages
+    m_t given: there they depend on the atom features only).  No norm runs as passes of its own except the apply pass
+    of the LAST one (its output is what the caller reads) and that norm's backward:
+      forward   update t takes the raw output of update t-1 with the norm folded in (mpnn_gru_update_norm_f32) and emits
+                the moments of its own output;
+      backward  the dm | dh kernel of update t emits the column sums the backward of the norm in front of it needs, and
+                the gate-gradient kernel of update t-1 applies that backward to its incoming gradient in registers
+                (mpnn_gru_update_norm_bwd_f32)."""
+
+    @staticmethod
+    def forward(ctx, h0, mask, W_ih, W_hh, b_ih, b_hh, weight, bias, eps, flags, grad_mode, *msgs):
+        lib = _lib.load()
+        y = h0.contiguous()
+        V, H = int(y.shape[0]), int(y.shape[1])
+        dev = y.device
+        mask = mask.contiguous() if mask is not None else None
+        W_ih, W_hh, b_ih, b_hh = W_ih.contiguous(), W_hh.contiguous(), b_ih.contiguous(), b_hh.contiguous()
+        weight = weight.contiguous() if weight is not None else None
+        bias = bias.contiguous() if bias is not None else None
+        count = (mask.sum() if mask is not None else torch.tensor(float(V), device=dev)).reshape(1).float()
+        need = grad_mode and any(ctx.needs_input_grad)
+        hs = torch.ones(H, dtype=torch.float32, device=dev)
+        ht = torch.zeros(H, dtype=torch.float32, device=dev)
+        Wf, bf = W_hh, b_hh
+        ws_bytes = lib.mpnn_gru_fwd_workspace_bytes(V, H)
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
+        msgs = [m.contiguous() for m in msgs]
+        hns, saveds, stats = [], [], []
+        mean = var = None
+        for m in msgs:
+            out = _empty((V, H), y)
+            saved = _empty((V, 4 * H), y) if need else None
+            hn = _empty((V, H), y) if need else None
+            sums = torch.zeros(2 * H, dtype=torch.float64, device=dev)
+            _lib.check(_timed("gru_update", lambda: lib.mpnn_gru_update_norm_f32(
+                _lib.fptr(m), _lib.fptr(y), _lib.fptr(mask), _lib.fptr(W_ih), _lib.fptr(Wf), _lib.fptr(b_ih), _lib.fptr(bf),
+                _lib.fptr(hs), _lib.fptr(ht), _lib.fptr(out), _lib.fptr(saved), _lib.fptr(hn), _lib.ptr(sums),
+                _lib.ptr(ws), ws_bytes, V, H, _lib.stream())), "mpnn_gru_update_norm_f32")
+            mean, var, hs, ht, Wf, bf = _norm_fold(sums, count, weight, bias, W_hh, b_hh, eps, flags)
+            hns.append(hn)
+            saveds.append(saved)
+            stats.append((mean, var))
+            y = out
+        if not msgs:
+            return y
+        final = _empty((V, H), y)
+        bws_bytes = lib.mpnn_masked_bn_workspace_bytes(H)
+        bws = torch.empty(bws_bytes // 4, dtype=torch.float32, device=dev)
+        _lib.check(lib.mpnn_masked_bn_fwd_f32(_lib.fptr(y), _lib.fptr(mask), _lib.fptr(weight), _lib.fptr(bias),
+                                              _lib.fptr(final), _lib.fptr(mean), _lib.fptr(var), None, V, H, float(eps),
+                                              int(flags) | BN_USE_STATS, _lib.ptr(bws), bws_bytes, _lib.stream()),
+                   "mpnn_masked_bn_fwd_f32")
+        if need:
+            ctx.save_for_backward(y, mask, W_ih, W_hh, weight, bias, count, *msgs, *hns, *saveds, *[t for mv in stats for t in mv])
+        ctx.T, ctx.eps, ctx.flags = len(msgs), float(eps), int(flags)
+        return final
+
+    @staticmethod
+    def backward(ctx, dfinal):
+        lib = _lib.load()
+        T = ctx.T
+        sv = ctx.saved_tensors
+        y_last, mask, W_ih, W_hh, weight, bias, count = sv[:7]
+        msgs, hns, saveds = sv[7:7 + T], sv[7 + T:7 + 2 * T], sv[7 + 2 * T:7 + 3 * T]
+        stats = sv[7 + 3 * T:]
+        V, H = int(y_last.shape[0]), int(y_last.shape[1])
+        dev = y_last.device
+        affine = weight is not None
+        dweight = torch.zeros(H, dtype=torch.float32, device=dev) if affine else None
+        dbias = torch.zeros(H, dtype=torch.float32, device=dev) if affine else None
+        # the last norm: its output left this function, so its backward is the standalone reduction + apply
+        dy = _empty((V, H), y_last)
+        dw_l = _empty((H,), y_last) if affine else None
+        db_l = _empty((H,), y_last) if affine else None
+        bws_bytes = lib.mpnn_masked_bn_workspace_bytes(H)
+        bws = torch.empty(bws_bytes // 4, dtype=torch.float32, device=dev)
+        _lib.check(lib.mpnn_masked_bn_bwd_f32(_lib.fptr(dfinal.contiguous()), _lib.fptr(y_last), _lib.fptr(mask),
+                                              _lib.fptr(weight), _lib.fptr(stats[2 * T - 2]), _lib.fptr(stats[2 * T - 1]),
+                                              _lib.fptr(dy), _lib.fptr(dw_l), _lib.fptr(db_l), V, H, ctx.eps, ctx.flags,
+                                              _lib.fptr(count), _lib.ptr(bws), bws_bytes, _lib.stream()),
+                   "mpnn_masked_bn_bwd_f32")
+        if affine:
+            dweight += dw_l
+            dbias += db_l
+        dW_ih, dW_hh = torch.zeros_like(W_ih), torch.zeros_like(W_hh)
+        db_ih = torch.zeros(3 * H, dtype=torch.float32, device=dev)
+        db_hh = torch.zeros(3 * H, dtype=torch.float32, device=dev)
+        ws_bytes = lib.mpnn_gru_bwd_workspace_bytes(V, H)
+        ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=dev)
+        dms = [None] * T
+        dout, kn = dy, None
+        for t in range(T - 1, -1, -1):
+            dm, dhn = _empty((V, H), y_last), _empty((V, H), y_last)
+            sums = torch.zeros(2 * H, dtype=torch.float64, device=dev) if t > 0 else None
+            _lib.check(_timed("gru_update_bwd", lambda: lib.mpnn_gru_update_norm_bwd_f32(
+                _lib.fptr(dout), _lib.fptr(msgs[t]), _lib.fptr(hns[t]), _lib.fptr(mask), _lib.fptr(W_ih), _lib.fptr(W_hh),
+                _lib.fptr(saveds[t]), _lib.fptr(kn), _lib.fptr(dm), _lib.fptr(dhn), _lib.fptr(dW_ih), _lib.fptr(dW_hh),
+                _lib.fptr(db_ih), _lib.fptr(db_hh), _lib.ptr(sums), _lib.ptr(ws), ws_bytes, V, H, _lib.stream())),
+                "mpnn_gru_update_norm_bwd_f32")
+            dms[t] = dm
+            if t > 0:                                   # constants of the norm between update t-1 and update t
+                kn = torch.empty(3 * H, dtype=torch.float32, device=dev)
+                _lib.check(lib.mpnn_norm_bwd_consts_f32(_lib.ptr(sums), _lib.fptr(stats[2 * t - 2]), _lib.fptr(stats[2 * t - 1]),
+                                                        _lib.fptr(count), _lib.fptr(weight), _lib.fptr(bias), _lib.fptr(kn),
+                                                        _lib.fptr(dweight), _lib.fptr(dbias), H, ctx.eps, ctx.flags,
+                                                        _lib.stream()), "mpnn_norm_bwd_consts_f32")
+            dout = dhn
+        return (dout, None, dW_ih, dW_hh, db_ih, db_hh, dweight, dbias, None, None, None) + tuple(dms)
+
+
+def gru_norm_chain(h0, msgs, mask, W_ih, W_hh, b_ih, b_hh, weight=None, bias=None, eps=1e-6, flags=BN_EPS_INSIDE):
+    return GRUNormChain.apply(h0, mask, W_ih, W_hh, b_ih, b_hh, weight, bias, eps, flags, torch.is_grad_enabled(), *msgs)
+
+
 class MaskedBatchNormGiven(torch.autograd.Function):
     """Masked batch norm whose batch statistics were taken elsewhere (the producing update's epilogue): the forward is
     the apply pass alone, the backward the full batch-statistics backward (the statistics depend on x)."""

@@ -91,6 +91,20 @@ def test_two_updates_with_the_norm_between_them(dev, H, V, affine, partial_mask)
     for k in leaves:
         assert _rel(t[k].grad, ref[k].grad) < 1e-4, (k, _rel(t[k].grad, ref[k].grad))
 
+    # the whole chain as ONE autograd node: the norms' backward passes fused into the GRU backward kernels as well
+    c = {k: v.to(dev).requires_grad_(True) for k, v in leaves.items()}
+    w, b = (c["gamma"], c["beta"]) if affine else (None, None)
+    chain = ops.gru_norm_chain(c["h0"], [c["m1"], c["m2"]], mkd, c["W_ih"], c["W_hh"], c["b_ih"], c["b_hh"], weight=w,
+                               bias=b, eps=eps, flags=flags)
+    (chain * cot.to(dev)).sum().backward()
+    assert _rel(chain, out64.detach()) < 2e-5
+    for k in leaves:
+        assert _rel(c[k].grad, ref[k].grad) < 1e-4, ("chain", k, _rel(c[k].grad, ref[k].grad))
+    with torch.no_grad():
+        inf = ops.gru_norm_chain(c["h0"], [c["m1"], c["m2"]], mkd, c["W_ih"], c["W_hh"], c["b_ih"], c["b_hh"], weight=w,
+                                 bias=b, eps=eps, flags=flags)
+    assert torch.equal(inf, chain.detach())
+
     # the standalone kernels on the same inputs (what runs at every other width)
     s = {k: v.to(dev).requires_grad_(True) for k, v in leaves.items()}
     w, b = (s["gamma"], s["beta"]) if affine else (None, None)
@@ -130,6 +144,72 @@ def test_attention_model_fused_norm_equals_the_standalone_norm_kernels(dev):
     assert len(res[0][1]) == len(res[1][1]) >= 20
     for k, gr in res[0][1].items():
         assert _rel(gr, res[1][1][k]) < 2e-4, (k, _rel(gr, res[1][1][k]))
+
+
+def test_three_step_chain_with_small_gradients(dev):
+    """Three updates (two fused norm backward passes in a row), cotangent of order 1e-6, hidden 256."""
+    from mpnn_amd import ops
+    H, V, T = 256, 1500, 3
+    g = torch.Generator().manual_seed(9)
+    mk = (torch.rand(V, generator=g) > 0.1).float()
+    leaves = dict(h0=torch.randn(V, H, generator=g) * mk.unsqueeze(1), W_ih=torch.randn(H, 3 * H, generator=g) / H ** 0.5,
+                  W_hh=torch.randn(H, 3 * H, generator=g) / H ** 0.5, b_ih=torch.randn(3 * H, generator=g) * 0.1,
+                  b_hh=torch.randn(3 * H, generator=g) * 0.1)
+    for t in range(T):
+        leaves["m%d" % t] = torch.randn(V, H, generator=g) * (0.5 + t)
+    cot = torch.randn(V, H, generator=g) * 1e-6
+    ref = {k: v.double().requires_grad_(True) for k, v in leaves.items()}
+    st = ref["h0"]
+    for t in range(T):
+        st = _norm64(_gru64(ref["m%d" % t], st, mk.double(), ref["W_ih"], ref["W_hh"], ref["b_ih"], ref["b_hh"]),
+                     mk.double(), None, None, 1e-6, False, True)
+    (st * cot.double()).sum().backward()
+    c = {k: v.to(dev).requires_grad_(True) for k, v in leaves.items()}
+    out = ops.gru_norm_chain(c["h0"], [c["m%d" % t] for t in range(T)], mk.to(dev), c["W_ih"], c["W_hh"], c["b_ih"], c["b_hh"])
+    (out * cot.to(dev)).sum().backward()
+    assert _rel(out, st.detach()) < 3e-5
+    for k in leaves:
+        assert _rel(c[k].grad, ref[k].grad) < 2e-4, (k, _rel(c[k].grad, ref[k].grad))
+
+
+def test_norm_constant_kernels_against_torch(dev):
+    """mpnn_norm_fold_f32 / mpnn_norm_bwd_consts_f32 against the same formulas in float64 torch ops."""
+    from mpnn_amd import _lib, ops
+    lib = _lib.load()
+    H, n = 128, 1000.0
+    g = torch.Generator().manual_seed(4)
+    y = torch.randn(int(n), H, generator=g).double() * 0.7 + 0.3
+    sums = torch.cat([y.sum(0), (y * y).sum(0)]).to(dev)
+    count = torch.tensor([n], device=dev)
+    gamma, beta = (torch.rand(H, generator=g) + 0.5).to(dev), (torch.randn(H, generator=g) * 0.2).to(dev)
+    W, b = torch.randn(H, 3 * H, generator=g).to(dev), torch.randn(3 * H, generator=g).to(dev)
+    for weight, bias, eps, flags in ((None, None, 1e-6, ops.BN_EPS_INSIDE), (gamma, beta, 1e-5, ops.BN_MASKED_MEAN)):
+        mean, var, hs, ht, Wf, bf = ops._norm_fold(sums, count, weight, bias, W, b, eps, flags)
+        mu = y.mean(0)
+        v = (y * y).mean(0) - mu * mu
+        s = torch.sqrt(v + eps) if flags & ops.BN_EPS_INSIDE else torch.sqrt(v) + eps
+        g64 = weight.double().cpu() if weight is not None else torch.ones(H, dtype=torch.float64)
+        b64 = bias.double().cpu() if bias is not None else torch.zeros(H, dtype=torch.float64)
+        assert _rel(mean, mu) < 1e-6 and _rel(var, v) < 1e-6
+        assert _rel(hs, g64 / s) < 1e-6 and _rel(ht, b64 - mu * g64 / s) < 1e-6
+        assert _rel(Wf, W.double().cpu() * (g64 / s).unsqueeze(1)) < 1e-6
+        assert _rel(bf, b.double().cpu() + (b64 - mu * g64 / s) @ W.double().cpu()) < 1e-5
+        d = torch.randn(int(n), H, generator=g).double()
+        hn = (y - mu) / s * g64 + b64
+        bs = torch.cat([d.sum(0), (d * hn).sum(0)]).to(dev)
+        kn = torch.empty(3 * H, device=dev)
+        dw = torch.zeros(H, device=dev) if weight is not None else None
+        db = torch.zeros(H, device=dev) if weight is not None else None
+        _lib.check(lib.mpnn_norm_bwd_consts_f32(_lib.ptr(bs), _lib.fptr(mean), _lib.fptr(var), _lib.fptr(count),
+                                                _lib.fptr(weight), _lib.fptr(bias), _lib.fptr(kn), _lib.fptr(dw),
+                                                _lib.fptr(db), H, eps, flags, _lib.stream()), "consts")
+        yl = y.clone().requires_grad_(True)
+        m2 = yl.mean(0)
+        v2 = ((yl - m2) ** 2).mean(0)
+        s2 = torch.sqrt(v2 + eps) if flags & ops.BN_EPS_INSIDE else torch.sqrt(v2) + eps
+        (((yl - m2) / s2 * g64 + b64) * d).sum().backward()
+        k1, k2, k4 = kn[:H].double().cpu(), kn[H:2 * H].double().cpu(), kn[2 * H:].double().cpu()
+        assert _rel(d * k1 + y * k2 + k4, yl.grad) < 2e-5
 
 
 def test_unsupported_width_is_refused(dev):
