@@ -329,7 +329,12 @@ int mpnn_masked_bn_bwd_f32(const float* dout, const float* x, const float* mask,
  *   b_hh_folded [3F] as mpnn_gru_update_norm_f32 takes them.  F <= 256.
  * mpnn_norm_bwd_consts_f32: sums [2F] doubles (in_norm_sums of mpnn_gru_update_norm_bwd_f32) + the norm's statistics
  *   -> out_norm_k [3F] for the update in front of that norm; dweight / dbias [F] (affine norms) are ACCUMULATED.
+ * mpnn_norm_bwd_sums_f32: the same two sums for a norm whose output left the chain (no dm | dh kernel behind it):
+ *   sums [2F] doubles += (sum dout * mask | sum dout * mask * h_norm), one read of dout and of the norm's output.
+ *   F = 4 * 2^k <= 1024.
  */
+int mpnn_norm_bwd_sums_f32(const float* dout, const float* h_norm, const float* mask, double* sums, int64_t V, int F,
+                           void* stream);
 int mpnn_norm_fold_f32(const double* moments, const float* count, const float* weight, const float* bias,
                        const float* W_hh, const float* b_hh, float* mean, float* var, float* h_scale, float* h_shift,
                        float* W_hh_folded, float* b_hh_folded, int F, float eps, int flags, void* stream);

@@ -312,6 +312,49 @@ __global__ void __launch_bounds__(256) bn_fold_kernel(const double* __restrict__
     bf[j] = acc;
 }
 
+// S_b = sum d * mask and S_h = sum d * mask * hn over all rows (2F doubles, accumulated): the sums of the norm backward
+// for a norm whose output hn left the chain (the last one), where no dm | dh epilogue produces them.  One read of d and hn.
+__global__ void __launch_bounds__(256) bn_bwd_sums_kernel(const float* __restrict__ d, const float* __restrict__ hn,
+                                                          const float* __restrict__ mask, double* __restrict__ sums,
+                                                          int64_t V, int F) {
+    __shared__ float red[2][256][4];
+    const int tpr = F / 4, rpb = 256 / tpr;                // F = 4 * 2^k <= 1024 (checked by the caller)
+    const int c = 4 * (threadIdx.x % tpr), rsub = threadIdx.x / tpr;
+    f32x4 sb = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    double db[4] = {0.0, 0.0, 0.0, 0.0}, dh[4] = {0.0, 0.0, 0.0, 0.0};
+    int n = 0;
+    for (int64_t row = (int64_t)blockIdx.x * rpb + rsub; row < V; row += (int64_t)gridDim.x * rpb) {
+        const float mk = mask ? mask[row] : 1.0f;
+        const f32x4 dv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(d + row * F + c)) * mk;
+        const f32x4 hv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(hn + row * F + c));
+        sb += dv;
+        sh += dv * hv;
+        if (++n == 64) {                                   // fp32 over 64 rows, float64 beyond
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { db[u] += (double)sb[u]; dh[u] += (double)sh[u]; sb[u] = 0.f; sh[u] = 0.f; }
+            n = 0;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        red[0][threadIdx.x][u] = (float)(db[u] + (double)sb[u]);
+        red[1][threadIdx.x][u] = (float)(dh[u] + (double)sh[u]);
+    }
+    __syncthreads();
+    if (rsub == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            double a = 0.0, b = 0.0;
+            for (int q = 0; q < rpb; ++q) {
+                a += (double)red[0][q * tpr + threadIdx.x][u];
+                b += (double)red[1][q * tpr + threadIdx.x][u];
+            }
+            atomicAdd(sums + c + u, a);
+            atomicAdd(sums + F + c + u, b);
+        }
+    }
+}
+
 // column sums of d hn and d hn * hn (2F doubles, from the dm | dh kernel's epilogue) + the norm's statistics -> the three
 // constants of  dy = d hn * k1 + y * k2 + k4  (include/mpnn_amd.h has the derivation), and the norm's own parameter
 // gradients, accumulated
@@ -436,4 +479,19 @@ extern "C" int mpnn_norm_bwd_consts_f32(const double* sums, const float* mean, c
     hipLaunchKernelGGL(bn_bwd_consts_kernel, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sums, mean,
                        var, count, weight, bias, out_norm_k, dweight, dbias, F, eps, flags);
     return launch_status("mpnn_norm_bwd_consts_f32");
+}
+
+extern "C" int mpnn_norm_bwd_sums_f32(const float* dout, const float* h_norm, const float* mask, double* sums, int64_t V,
+                                      int F, void* stream) {
+    MPNN_REQUIRE(V >= 0 && bn_vectorisable(F), "mpnn_norm_bwd_sums_f32: V=%lld F=%d (F must be 4 * 2^k <= 1024)",
+                 (long long)V, F);
+    if (V == 0) return MPNN_OK;
+    MPNN_REQUIRE(dout && h_norm && sums, "mpnn_norm_bwd_sums_f32: NULL buffer");
+    MPNN_REQUIRE((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(h_norm)) % 16 == 0,
+                 "mpnn_norm_bwd_sums_f32: buffers must be 16-byte aligned");
+    int64_t vg = ceil_div(V, (int64_t)(256 / (F / 4)) * 16);
+    if (vg > 2048) vg = 2048;
+    if (vg < 1) vg = 1;
+    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((unsigned)vg), dim3(256), 0, (hipStream_t)stream, dout, h_norm, mask, sums, V, F);
+    return launch_status("mpnn_norm_bwd_sums_f32");
 }

@@ -43,7 +43,7 @@ class BasicModel(nn.Module):
         self.bn = MaskBatchNorm()
 
     def _norm_fusable(self, afm):
-        return (self.fuse_norm and type(self.bn) is MaskBatchNorm and not self.bn.sync_stats
+        return (self.fuse_norm and type(self.bn) is MaskBatchNorm
                 and type(self.uf) is GRUUpdate and self.uf.mf == self.uf.nf == afm.shape[-1]
                 and ops.gru_norm_applies(self.uf.nf, afm))
 
@@ -59,7 +59,8 @@ class BasicModel(nn.Module):
                 mf.bind_graph(graph)
             msgs.append(self.ma(mf(afm, bfm), adj).reshape(-1, cell.mf))
         out = ops.gru_norm_chain(afm.reshape(-1, cell.nf), msgs, mask.reshape(-1), cell.weight_ih, cell.weight_hh,
-                                 cell.bias_ih, cell.bias_hh, eps=1e-6, flags=ops.BN_EPS_INSIDE)
+                                 cell.bias_ih, cell.bias_hh, eps=1e-6, flags=ops.BN_EPS_INSIDE,
+                                 sync=self.bn.sync_stats)
         return out.view(afm.shape)
 
     def message_passing(self, afm, bfm, adj, mask):

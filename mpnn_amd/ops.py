@@ -590,15 +590,17 @@ def _norm_fold(sums, count, weight, bias, W_hh, b_hh, eps, flags):
 class GRUNormChain(torch.autograd.Function):
     """state_t = norm(update(m_t, state_{t-1})), t = 1..T, state_0 = h0  (models/att_model.py:57-58 with the messages
     m_t given: there they depend on the atom features only).  No norm runs as passes of its own except the apply pass
-    of the LAST one (its output is what the caller reads) and that norm's backward:
+    of the LAST one (its output is what the caller reads) and one two-sum reduction for that norm's backward:
       forward   update t takes the raw output of update t-1 with the norm folded in (mpnn_gru_update_norm_f32) and emits
                 the moments of its own output;
       backward  the dm | dh kernel of update t emits the column sums the backward of the norm in front of it needs, and
                 the gate-gradient kernel of update t-1 applies that backward to its incoming gradient in registers
-                (mpnn_gru_update_norm_bwd_f32)."""
+                (mpnn_gru_update_norm_bwd_f32).
+    sync=True: the statistics span all ranks of the default process group (the batch is sharded by graph): the
+    2H moments, the count and the 2H backward sums are all-reduced -- five tiny collectives per step, no extra pass."""
 
     @staticmethod
-    def forward(ctx, h0, mask, W_ih, W_hh, b_ih, b_hh, weight, bias, eps, flags, grad_mode, *msgs):
+    def forward(ctx, h0, mask, W_ih, W_hh, b_ih, b_hh, weight, bias, eps, flags, sync, grad_mode, *msgs):
         lib = _lib.load()
         y = h0.contiguous()
         V, H = int(y.shape[0]), int(y.shape[1])
@@ -608,6 +610,9 @@ class GRUNormChain(torch.autograd.Function):
         weight = weight.contiguous() if weight is not None else None
         bias = bias.contiguous() if bias is not None else None
         count = (mask.sum() if mask is not None else torch.tensor(float(V), device=dev)).reshape(1).float()
+        sync = bool(sync) and _dist_world() > 1
+        if sync:
+            _all_reduce(count)
         need = grad_mode and any(ctx.needs_input_grad)
         hs = torch.ones(H, dtype=torch.float32, device=dev)
         ht = torch.zeros(H, dtype=torch.float32, device=dev)
@@ -626,6 +631,8 @@ class GRUNormChain(torch.autograd.Function):
                 _lib.fptr(m), _lib.fptr(y), _lib.fptr(mask), _lib.fptr(W_ih), _lib.fptr(Wf), _lib.fptr(b_ih), _lib.fptr(bf),
                 _lib.fptr(hs), _lib.fptr(ht), _lib.fptr(out), _lib.fptr(saved), _lib.fptr(hn), _lib.ptr(sums),
                 _lib.ptr(ws), ws_bytes, V, H, _lib.stream())), "mpnn_gru_update_norm_f32")
+            if sync:
+                _all_reduce(sums)
             mean, var, hs, ht, Wf, bf = _norm_fold(sums, count, weight, bias, W_hh, b_hh, eps, flags)
             hns.append(hn)
             saveds.append(saved)
@@ -641,8 +648,8 @@ class GRUNormChain(torch.autograd.Function):
                                               int(flags) | BN_USE_STATS, _lib.ptr(bws), bws_bytes, _lib.stream()),
                    "mpnn_masked_bn_fwd_f32")
         if need:
-            ctx.save_for_backward(y, mask, W_ih, W_hh, weight, bias, count, *msgs, *hns, *saveds, *[t for mv in stats for t in mv])
-        ctx.T, ctx.eps, ctx.flags = len(msgs), float(eps), int(flags)
+            ctx.save_for_backward(final, mask, W_ih, W_hh, weight, bias, count, *msgs, *hns, *saveds, *[t for mv in stats for t in mv])
+        ctx.T, ctx.eps, ctx.flags, ctx.sync = len(msgs), float(eps), int(flags), sync
         return final
 
     @staticmethod
@@ -650,37 +657,52 @@ class GRUNormChain(torch.autograd.Function):
         lib = _lib.load()
         T = ctx.T
         sv = ctx.saved_tensors
-        y_last, mask, W_ih, W_hh, weight, bias, count = sv[:7]
+        final, mask, W_ih, W_hh, weight, bias, count = sv[:7]
         msgs, hns, saveds = sv[7:7 + T], sv[7 + T:7 + 2 * T], sv[7 + 2 * T:7 + 3 * T]
         stats = sv[7 + 3 * T:]
-        V, H = int(y_last.shape[0]), int(y_last.shape[1])
-        dev = y_last.device
+        V, H = int(final.shape[0]), int(final.shape[1])
+        dev = final.device
         affine = weight is not None
         dweight = torch.zeros(H, dtype=torch.float32, device=dev) if affine else None
         dbias = torch.zeros(H, dtype=torch.float32, device=dev) if affine else None
-        # the last norm: its output left this function, so its backward is the standalone reduction + apply
-        dy = _empty((V, H), y_last)
-        dw_l = _empty((H,), y_last) if affine else None
-        db_l = _empty((H,), y_last) if affine else None
-        bws_bytes = lib.mpnn_masked_bn_workspace_bytes(H)
-        bws = torch.empty(bws_bytes // 4, dtype=torch.float32, device=dev)
-        _lib.check(lib.mpnn_masked_bn_bwd_f32(_lib.fptr(dfinal.contiguous()), _lib.fptr(y_last), _lib.fptr(mask),
-                                              _lib.fptr(weight), _lib.fptr(stats[2 * T - 2]), _lib.fptr(stats[2 * T - 1]),
-                                              _lib.fptr(dy), _lib.fptr(dw_l), _lib.fptr(db_l), V, H, ctx.eps, ctx.flags,
-                                              _lib.fptr(count), _lib.ptr(bws), bws_bytes, _lib.stream()),
-                   "mpnn_masked_bn_bwd_f32")
-        if affine:
-            dweight += dw_l
-            dbias += db_l
+
+        def consts(sums, t):
+            """out_norm_k of the norm after update t (0-based) from its two backward sums; parameter gradients from the
+            LOCAL sums (the caller's gradient all-reduce adds the ranks)."""
+            kn = torch.empty(3 * H, dtype=torch.float32, device=dev)
+            mean, var = stats[2 * t], stats[2 * t + 1]
+
+            def run(sm, dw, db, out):
+                _lib.check(lib.mpnn_norm_bwd_consts_f32(_lib.ptr(sm), _lib.fptr(mean), _lib.fptr(var), _lib.fptr(count),
+                                                        _lib.fptr(weight), _lib.fptr(bias), _lib.fptr(out), _lib.fptr(dw),
+                                                        _lib.fptr(db), H, ctx.eps, ctx.flags, _lib.stream()),
+                           "mpnn_norm_bwd_consts_f32")
+            if not ctx.sync:
+                run(sums, dweight, dbias, kn)
+                return kn
+            if affine:                                  # parameter gradients: this rank's terms only
+                run(sums, dweight, dbias, torch.empty_like(kn))
+            _all_reduce(sums)
+            scratch = (torch.zeros(H, dtype=torch.float32, device=dev),) * 2 if affine else (None, None)
+            run(sums, scratch[0], scratch[1], kn)
+            return kn
+
+        # the last norm's output left this function: its two sums take one pass over (dfinal, final); its apply happens in
+        # the gate-gradient kernel of the last update like every other norm's
+        dfinal = dfinal.contiguous()
+        lsums = torch.zeros(2 * H, dtype=torch.float64, device=dev)
+        _lib.check(lib.mpnn_norm_bwd_sums_f32(_lib.fptr(dfinal), _lib.fptr(final), _lib.fptr(mask), _lib.ptr(lsums), V, H,
+                                              _lib.stream()), "mpnn_norm_bwd_sums_f32")
+        kn = consts(lsums, T - 1)
         dW_ih, dW_hh = torch.zeros_like(W_ih), torch.zeros_like(W_hh)
         db_ih = torch.zeros(3 * H, dtype=torch.float32, device=dev)
         db_hh = torch.zeros(3 * H, dtype=torch.float32, device=dev)
         ws_bytes = lib.mpnn_gru_bwd_workspace_bytes(V, H)
         ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=dev)
         dms = [None] * T
-        dout, kn = dy, None
+        dout = dfinal
         for t in range(T - 1, -1, -1):
-            dm, dhn = _empty((V, H), y_last), _empty((V, H), y_last)
+            dm, dhn = _empty((V, H), final), _empty((V, H), final)
             sums = torch.zeros(2 * H, dtype=torch.float64, device=dev) if t > 0 else None
             _lib.check(_timed("gru_update_bwd", lambda: lib.mpnn_gru_update_norm_bwd_f32(
                 _lib.fptr(dout), _lib.fptr(msgs[t]), _lib.fptr(hns[t]), _lib.fptr(mask), _lib.fptr(W_ih), _lib.fptr(W_hh),
@@ -689,17 +711,30 @@ class GRUNormChain(torch.autograd.Function):
                 "mpnn_gru_update_norm_bwd_f32")
             dms[t] = dm
             if t > 0:                                   # constants of the norm between update t-1 and update t
-                kn = torch.empty(3 * H, dtype=torch.float32, device=dev)
-                _lib.check(lib.mpnn_norm_bwd_consts_f32(_lib.ptr(sums), _lib.fptr(stats[2 * t - 2]), _lib.fptr(stats[2 * t - 1]),
-                                                        _lib.fptr(count), _lib.fptr(weight), _lib.fptr(bias), _lib.fptr(kn),
-                                                        _lib.fptr(dweight), _lib.fptr(dbias), H, ctx.eps, ctx.flags,
-                                                        _lib.stream()), "mpnn_norm_bwd_consts_f32")
+                kn = consts(sums, t - 1)
             dout = dhn
-        return (dout, None, dW_ih, dW_hh, db_ih, db_hh, dweight, dbias, None, None, None) + tuple(dms)
+        return (dout, None, dW_ih, dW_hh, db_ih, db_hh, dweight, dbias, None, None, None, None) + tuple(dms)
 
 
-def gru_norm_chain(h0, msgs, mask, W_ih, W_hh, b_ih, b_hh, weight=None, bias=None, eps=1e-6, flags=BN_EPS_INSIDE):
-    return GRUNormChain.apply(h0, mask, W_ih, W_hh, b_ih, b_hh, weight, bias, eps, flags, torch.is_grad_enabled(), *msgs)
+def _dist_world():
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _all_reduce(t):
+    import torch.distributed as dist
+    if dist.get_backend() == "gloo" and t.is_cuda:      # rehearsal on one GPU: gloo reduces host tensors
+        c = t.cpu()
+        dist.all_reduce(c)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t)
+
+
+def gru_norm_chain(h0, msgs, mask, W_ih, W_hh, b_ih, b_hh, weight=None, bias=None, eps=1e-6, flags=BN_EPS_INSIDE,
+                   sync=False):
+    return GRUNormChain.apply(h0, mask, W_ih, W_hh, b_ih, b_hh, weight, bias, eps, flags, sync, torch.is_grad_enabled(),
+                              *msgs)
 
 
 class MaskedBatchNormGiven(torch.autograd.Function):

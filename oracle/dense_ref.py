@@ -306,18 +306,6 @@ def att_model_forward(params, afm, bfm, adj, mask, steps, return_state=False):
     return (out, h) if return_state else out
 
 
-def normed_basic_model_forward(params, afm, bfm, adj, mask, steps, return_state=False):
-    """models/normed_basic_model.py:56-59: like att_model_forward with plain EdgeNetwork modules mf0..mf{T-1}
-    (per-pair messages, the contract AdjMsgAgg documents)."""
-    ufp, ofp = sub(params, "uf."), sub(params, "of.")
-    h = afm
-    for i in range(steps):
-        pair = edge_network_pair(sub(params, "mf%d." % i), afm, bfm)
-        h = mask_bn(gru_update(ufp, agg_adj(pair, adj), h, mask), mask)
-    out = graph_level_output(ofp, torch.cat([h, afm], dim=-1), mask)
-    return (out, h) if return_state else out
-
-
 # ----------------------------------------------------------------------------- index oracle
 def dense_to_csr(adj):
     """Bit-exact index oracle: rows = b*N+i, columns = b*N+j, in adj.nonzero() order."""

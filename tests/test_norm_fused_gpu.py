@@ -41,7 +41,8 @@ def _norm64(y, mask, weight, bias, eps, masked_mean, eps_inside):
 
 
 def _rel(a, b):
-    return float((a.double().cpu() - b.double().cpu()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
 @pytest.mark.parametrize("H,V,affine,partial_mask", [(128, 1000, False, True), (128, 4096, True, False),

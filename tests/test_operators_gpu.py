@@ -332,35 +332,3 @@ def test_batch_norm_graph_wrapper(dev):
     assert max_err(out_compact.cpu(), ref) < 5e-5
 
 
-def test_normed_basic_model(dev):
-    """models/normed_basic_model.py: a separate EdgeNetwork per step + masked norm after each update, dense batch
-    against the oracle, forward and gradients of every parameter."""
-    from mpnn_amd import synth
-    from mpnn_amd.models.normed_basic_model import BasicModel
-    H, T = 16, 3
-    mb = synth.make_molecules(30, H, seed=12)
-    dense = {k: torch.from_numpy(v) for k, v in synth.to_dense(mb).items()}
-    torch.manual_seed(4)
-    model = BasicModel(H, 4, H, 50, 5, message_opts={}, agg_opts={}, update_opts={}, readout_opts={}, message_steps=T)
-    assert sorted(k.split(".")[0] for k in model.state_dict() if k.startswith("mf"))[0] == "mf0"
-    with torch.no_grad():
-        for k, p in model.named_parameters():
-            if "bias" in k:
-                p.uniform_(-0.1, 0.1)
-    leaves, params = {}, {}
-    for k, v in model.state_dict(keep_vars=True).items():
-        if id(v) not in leaves:
-            leaves[id(v)] = v.detach().clone().requires_grad_(v.is_floating_point())
-        params[k] = leaves[id(v)]
-    cot = torch.rand(mb.num_mols, 5) - 0.5
-    ref = O.normed_basic_model_forward(params, dense["afm"], dense["bfm"], dense["adj"], dense["mask"], T)
-    (ref * cot).sum().backward()
-    model = model.to(dev)
-    out = model(*(dense[k].to(dev) for k in ("afm", "bfm", "adj", "mask")))
-    (out * cot.to(dev)).sum().backward()
-    assert max_err(out.detach().cpu(), ref) < 5e-5
-    for k, p in model.named_parameters():
-        if params[k].grad is None:
-            continue
-        scale = max(1.0, float(params[k].grad.abs().max()))
-        assert max_err(p.grad.cpu(), params[k].grad) / scale < 3e-4, k

@@ -93,6 +93,79 @@ def test_two_rank_hip_gradient_equals_single_process():
     assert np.abs(got - ref).max() / scale < 2e-5        # same terms, summed in two parts
 
 
+def _att_model(dev, sync):
+    from mpnn_amd.models.att_model import BasicModel as AttModel
+    from mpnn_amd.mpnn_functions import GraphLevelOutput
+    torch.manual_seed(29)
+    model = AttModel(128, 4, 128, 50, 8, message_opts={}, agg_opts={}, update_opts={}, readout_opts={}, message_steps=3,
+                     readout_func=GraphLevelOutput).to(dev)
+    model.bn.sync_stats = sync
+    return model
+
+
+def _att_loss_grad(model, mb, dev, total_mols, rows):
+    """rows = the GLOBAL atom ids of this batch's atoms: the cotangent is a fixed function of (global atom, column), so
+    shards and the whole batch differentiate the same loss (a sum of squares would be constant under the norm)."""
+    from mpnn_amd import parallel
+    from mpnn_amd.graph import MolGraph
+    hot = [p for n, p in model.named_parameters() if not n.startswith("of.")]
+    bucket = parallel.GradientBucket(hot)
+    bucket.zero()
+    g = MolGraph.from_molbatch(mb, dev)
+    afm = torch.from_numpy(mb.atom_feat).to(dev)
+    state, _ = model.message_passing(afm, g, g, torch.ones(mb.num_atoms, 1, device=dev))
+    r = torch.from_numpy(np.asarray(rows, dtype=np.float64)).to(dev)
+    cot = torch.sin(0.37 * r[:, None] + 1.3 * torch.arange(128, device=dev, dtype=torch.float64)[None, :]).float()
+    ((state * cot).sum() / total_mols).backward()
+    return bucket, state.detach()
+
+
+def _att_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from mpnn_amd import parallel, synth
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    mb = synth.make_molecules(400, 128, seed=43)
+    per_mol = np.add.reduceat(np.diff(mb.row_ptr), mb.atom_ptr[:-1])
+    ids = np.sort(parallel.shard_by_edges(per_mol, world)[rank])
+    model = _att_model(dev, True)
+    assert model._norm_fusable(torch.zeros(1, 128, device=dev))
+    rows = np.concatenate([np.arange(mb.atom_ptr[i], mb.atom_ptr[i + 1]) for i in ids])
+    bucket, state = _att_loss_grad(model, synth.select(mb, ids), dev, 400.0, rows)
+    flat = bucket.all_reduce().detach().cpu().numpy()
+    out.put((rank, flat, rows, state.cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_fused_norm_chain_with_synced_statistics():
+    """The attention model at hidden 128 sharded by graph over 2 ranks with `bn.sync_stats`: the fused update + norm chain
+    all-reduces its moments and backward sums, so node states and the summed gradient equal the single-process run over
+    the whole batch (the norms couple every atom of the batch)."""
+    from mpnn_amd import synth
+    dev = torch.device("cuda:0")
+    mb = synth.make_molecules(400, 128, seed=43)
+    ref_bucket, ref_state = _att_loss_grad(_att_model(dev, False), mb, dev, 400.0, np.arange(mb.num_atoms))
+    ref = ref_bucket.flat.detach().cpu().numpy()
+    ref_state = ref_state.cpu().numpy()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_att_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    scale = max(1e-6, float(np.abs(ref).max()))
+    for rank, flat, rows, state in got:
+        assert np.abs(state - ref_state[rows]).max() < 5e-5, rank
+        assert np.abs(flat - ref).max() / scale < 1e-4, rank
+
+
 def _run_bench(extra):
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
