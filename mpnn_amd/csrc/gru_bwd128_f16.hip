@@ -276,8 +276,11 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_presplit_kernel(const float* _
 // NORM: `h` entered the update as hn = norm(y_prev); the backward of that norm needs the column sums of dh and of
 // dh * hn over all atoms.  They are taken here, where dh is final: `hn` is read in the accumulator layout, the sums go
 // to `sums` (2 H doubles, accumulated; per wave in LDS across its tiles, one atomic per column and block at the end).
-template <int H, bool WS = false, bool NORM = false>
-__global__ void __launch_bounds__(512) gru_bwd_dx_wide_f16_kernel(const char* __restrict__ pieces,
+// NW = waves per block.  8: one block per CU, a round = 256 rows.  4: TWO independent blocks per CU (64 KB of LDS and four
+// 256-register waves each), a round = 128 rows: the blocks are not in step, so one block's epilogue (memory round trips,
+// no matrix work) runs under the other's K loop; the weight chunks are streamed twice as often (L2 -> LDS).
+template <int H, bool WS = false, bool NORM = false, int NW = 8>
+__global__ void __launch_bounds__(64 * NW) gru_bwd_dx_wide_f16_kernel(const char* __restrict__ pieces,
                                                                   const float* __restrict__ inv_scale,
                                                                   const float* __restrict__ W_ih,
                                                                   const float* __restrict__ W_hh, float* __restrict__ dm,
@@ -285,13 +288,14 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_wide_f16_kernel(const char* __
                                                                   const char* __restrict__ wws,
                                                                   const float* __restrict__ hn, double* sums) {
     static_assert(!NORM || WS, "the fused norm rides on the pre-split kernel");
-    constexpr int NS = H / 128, CPS = H / 32, NCT = 4 * CPS;
+    static_assert(NW == 8 || (NW == 4 && WS), "four-wave blocks exist on the pre-split kernel only");
+    constexpr int NS = H / 128, CPS = H / 32, NCT = 4 * CPS, NT = 64 * NW;
     constexpr int TILE_BYTES = 32 * 4 * H * 4;
     constexpr int IMGC = 128 * 64;             // one (matrix, piece) chunk image: 128 output rows x 32 k fp16
     constexpr int BUF = 4 * IMGC;              // 32 KB
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float redw[8];
-    __shared__ double stat_s[NORM ? 8 : 1][2][128];            // NORM: per wave, column sums of dh | dh * hn
+    __shared__ double stat_s[NORM ? NW : 1][2][128];           // NORM: per wave, column sums of dh | dh * hn
 
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
     const int slice = jb % NS;
@@ -300,11 +304,11 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_wide_f16_kernel(const char* __
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hi = lane >> 5;
 
-    const int64_t rounds_total = (V + 255) / 256;              // a round = 256 rows: every wave its own 32-row tile
+    const int64_t rounds_total = (V + 32 * NW - 1) / (32 * NW);   // a round: every wave its own 32-row tile
     if (pblock >= rounds_total) return;
     const int64_t nrounds = (rounds_total - pblock + pblocks - 1) / pblocks;
     if (NORM)
-        for (int i = tid; i < 8 * 2 * 128; i += 512) (&stat_s[0][0][0])[i] = 0.0;   // (published by the first chunk's barrier)
+        for (int i = tid; i < NW * 2 * 128; i += NT) (&stat_s[0][0][0])[i] = 0.0;   // (published by the first chunk's barrier)
 
     // one scale for the block's weights: largest magnitude of its 128 rows of both matrices
     float inv_sw = 1.0f, sw = 1.0f;
@@ -312,7 +316,7 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_wide_f16_kernel(const char* __
         inv_sw = reinterpret_cast<const float*>(wws)[slice];
     } else {
         float mx = 0.f;
-        for (int idx = tid; idx < 2 * 128 * (3 * H / 4); idx += 512) {
+        for (int idx = tid; idx < 2 * 128 * (3 * H / 4); idx += NT) {
             const int mat = idx / (128 * (3 * H / 4)), rem = idx % (128 * (3 * H / 4));
             const f32x4 w4 = *reinterpret_cast<const f32x4*>((mat ? W_hh : W_ih) + (int64_t)(128 * slice) * 3 * H + 4 * rem);
 #pragma unroll
@@ -369,6 +373,9 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_wide_f16_kernel(const char* __
     };
     // this lane's two (hi, lo) fragment pairs of chunk ct for row tile `tile`
     auto load_rows = [&](int64_t tile, int ct, h16x8 (&f)[4]) {
+#ifdef MPNN_ABL_HOT_ROWS        // timing experiment only: every wave re-reads one L2-resident tile (wrong results)
+        tile = wv;
+#endif
         const char* p = pieces + tile * (int64_t)TILE_BYTES + (chunk_seg(ct) * (H / 16) + 2 * chunk_cc(ct)) * 2048 + r * 32 + hi * 16;
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
@@ -380,22 +387,30 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_wide_f16_kernel(const char* __
     f32x16 d_m[4], d_h[4];                                 // 32 rows x 128 features of dm and of dh per wave
     h16x8 a0[4], a1[4];
     int cur = 0;
-    int64_t tile = (int64_t)pblock * 8 + wv;
+    int64_t tile = (int64_t)pblock * NW + wv;
     const int64_t tiles = (V + 31) / 32;
 
+    // the weight fragments of the second pair of column blocks are read before the MFMAs of the first pair are issued:
+    // that LDS round trip hides under six MFMAs
     auto product = [&](f32x16 (&d)[4], int mat, int st, const h16x8& ah, const h16x8& al) {
-#pragma unroll
-        for (int nb = 0; nb < 4; nb += 2) {
-            const h16x8 w0h = bfrag(cur, mat, 0, nb, st), w0l = bfrag(cur, mat, 1, nb, st);
-            const h16x8 w1h = bfrag(cur, mat, 0, nb + 1, st), w1l = bfrag(cur, mat, 1, nb + 1, st);
-            d[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, w0h, d[nb], 0, 0, 0);
-            d[nb + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, w1h, d[nb + 1], 0, 0, 0);
-            d[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w0l, d[nb], 0, 0, 0);
-            d[nb + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w1l, d[nb + 1], 0, 0, 0);
-            d[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w0h, d[nb], 0, 0, 0);
-            d[nb + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w1h, d[nb + 1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        const h16x8 w0h = bfrag(cur, mat, 0, 0, st), w0l = bfrag(cur, mat, 1, 0, st);
+        const h16x8 w1h = bfrag(cur, mat, 0, 1, st), w1l = bfrag(cur, mat, 1, 1, st);
+        const h16x8 v0h = bfrag(cur, mat, 0, 2, st), v0l = bfrag(cur, mat, 1, 2, st);
+        const h16x8 v1h = bfrag(cur, mat, 0, 3, st), v1l = bfrag(cur, mat, 1, 3, st);
+        __builtin_amdgcn_sched_barrier(0);                 // (without it the compiler sinks the second set below the first MFMAs)
+        d[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, w0h, d[0], 0, 0, 0);
+        d[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, w1h, d[1], 0, 0, 0);
+        d[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w0l, d[0], 0, 0, 0);
+        d[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w1l, d[1], 0, 0, 0);
+        d[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w0h, d[0], 0, 0, 0);
+        d[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w1h, d[1], 0, 0, 0);
+        d[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, v0h, d[2], 0, 0, 0);
+        d[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, v1h, d[3], 0, 0, 0);
+        d[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, v0l, d[2], 0, 0, 0);
+        d[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, v1l, d[3], 0, 0, 0);
+        d[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, v0h, d[2], 0, 0, 0);
+        d[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, v1h, d[3], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     };
     // WS: chunk ct's image comes verbatim from the pre-split workspace (32 x 1 KB; chunks of the third gate block: the 16
     // of their one matrix)
@@ -404,16 +419,18 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_wide_f16_kernel(const char* __
         const char* src = wws + 64 + (int64_t)(slice * NCT + ct) * BUF + lane * 16;
         const char* dst = smem + buf * BUF;
         const int first = seg == 3 ? 16 : 0, count = seg < 2 ? 32 : 16;
-        for (int i = first + wv; i < first + count; i += 8) g_copy_to_lds(src + i * 1024, dst + i * 1024);
+        for (int i = first + wv; i < first + count; i += NW) g_copy_to_lds(src + i * 1024, dst + i * 1024);
     };
     auto chunk = [&](int ct, int64_t tile_next, h16x8 (&xa)[4], h16x8 (&na)[4]) {
         __syncthreads();
         const int cn = (ct + 1) % NCT;
+#ifndef MPNN_ABL_NO_WCOPY       // timing experiment only: the weight chunks are never refreshed (wrong results)
         if (WS) stage_copy(cn, cur ^ 1);
         else stage_load(cn);
+#endif
         load_rows(cn == 0 ? tile_next : tile, cn, na);
         __builtin_amdgcn_sched_barrier(0);
-        const int seg = chunk_seg(ct);                     // compile-time after unrolling? no: uniform, cheap branches
+        const int seg = chunk_seg(ct);                     // block-uniform
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             if (seg != 3) product(d_m, 0, st, xa[2 * st], xa[2 * st + 1]);
@@ -434,9 +451,9 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_wide_f16_kernel(const char* __
     if (tile >= tiles) tile = tiles - 1;                   // a wave past the end repeats the last tile and stores nothing
     load_rows(tile, 0, a0);
     for (int64_t rd = 0; rd < nrounds; ++rd) {
-        int64_t tile_next = rd + 1 < nrounds ? (int64_t)(pblock + (rd + 1) * pblocks) * 8 + wv : tile;
+        int64_t tile_next = rd + 1 < nrounds ? (int64_t)(pblock + (rd + 1) * pblocks) * NW + wv : tile;
         if (tile_next >= tiles) tile_next = tiles - 1;
-        const bool live_tile = (int64_t)(pblock + rd * pblocks) * 8 + wv < tiles;
+        const bool live_tile = (int64_t)(pblock + rd * pblocks) * NW + wv < tiles;
         const float un = inv_scale[tile] * inv_sw;
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
@@ -447,46 +464,69 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_wide_f16_kernel(const char* __
             chunk(ct, tile_next, a0, a1);
             chunk(ct + 1, tile_next, a1, a0);
         }
-        if (live_tile) {
+        // Epilogue.  Every load of a pass (the g * z part of dh that the gate kernel left in place; NORM: hn) goes out before
+        // the pass's first store: vmcnt retires in order and counts a store until it is acknowledged, so a load behind stores
+        // waits for all of them -- with one load group per four rows the tile paid sixteen memory round trips in a row, every
+        // wave of the block in the same phase.  A full tile is one base + lane offset +
+        // compile-time offsets and takes two column blocks per pass (NORM: one, with its hn values): 32 values in the
+        // registers the K loop has freed; the ragged last tile goes row group by row group with clamped rows.
+        auto epilogue = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            constexpr int PASSES = FULL ? (NORM ? 4 : 2) : 16, NBP = FULL ? 4 / PASSES : 1, RPP = FULL ? 16 : 4;
+            unsigned ln = (unsigned)lane;                  // opaque: keeps the lane offsets from becoming loop invariants
+            asm volatile("" : "+v"(ln));
+            const unsigned lo = ((ln >> 5) << 2) * H + 128 * slice + (ln & 31u);
+            float* dhb = dh + tile * 32 * H + lo;
+            float* dmb = dm + tile * 32 * H + lo;
+            const float* hnb = NORM ? hn + tile * 32 * H + lo : nullptr;
+            const int64_t row0 = tile * 32 + 4 * hi;
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                const int fcol = 128 * slice + 32 * nb + r;
-                float sum_d = 0.0f, sum_dh = 0.0f;
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const int nb0 = FULL ? NBP * ps : ps >> 2, i0 = FULL ? 0 : 4 * (ps & 3);
+                float prev[NBP][RPP], hv[NBP][RPP];
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    float prev[4], hv[4];
+                for (int b = 0; b < NBP; ++b)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        int64_t row = tile * 32 + 8 * g4 + 4 * hi + u;
-                        if (row >= V) row = V - 1;
-                        prev[u] = dh[row * H + fcol];
-                        if (NORM) hv[u] = hn[row * H + fcol];
+                    for (int q = 0; q < RPP; ++q) {
+                        const int i = i0 + q, dr = 8 * (i >> 2) + (i & 3);
+                        int ro = dr * H + 32 * (nb0 + b);
+                        if (!FULL && row0 + dr >= V) ro = (int)(V - 1 - row0) * H + 32 * (nb0 + b);   // (clamped: value unused)
+                        prev[b][q] = dhb[ro];
+                        if (NORM) hv[b][q] = hnb[ro];
                     }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int i = 4 * g4 + u;
-                        const int64_t row = tile * 32 + 8 * g4 + 4 * hi + u;
-                        if (row < V) {
-                            const float dhv = d_h[nb][i] * un + prev[u];
-                            dm[row * H + fcol] = d_m[nb][i] * un;
-                            dh[row * H + fcol] = dhv;
+                for (int b = 0; b < NBP; ++b) {
+                    const int nb = nb0 + b;
+                    float sum_d = 0.0f, sum_dh = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < RPP; ++q) {
+                        const int i = i0 + q, dr = 8 * (i >> 2) + (i & 3);
+                        if (FULL || row0 + dr < V) {
+                            const float dhv = d_h[nb][i] * un + prev[b][q];
+                            dmb[dr * H + 32 * nb] = d_m[nb][i] * un;
+                            dhb[dr * H + 32 * nb] = dhv;
                             if (NORM) {
                                 sum_d += dhv;
-                                sum_dh = fmaf(dhv, hv[u], sum_dh);
+                                sum_dh = fmaf(dhv, hv[b][q], sum_dh);
                             }
                         }
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (NORM) {
-                    sum_d += __shfl_xor(sum_d, 32);
-                    sum_dh += __shfl_xor(sum_dh, 32);
-                    if (hi == 0) {
-                        stat_s[wv][0][32 * nb + r] += (double)sum_d;
-                        stat_s[wv][1][32 * nb + r] += (double)sum_dh;
+                    if (NORM) {
+                        sum_d += __shfl_xor(sum_d, 32);
+                        sum_dh += __shfl_xor(sum_dh, 32);
+                        if (hi == 0) {
+                            stat_s[wv][0][32 * nb + r] += (double)sum_d;
+                            stat_s[wv][1][32 * nb + r] += (double)sum_dh;
+                        }
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        if (live_tile) {
+            if (tile * 32 + 32 <= V) epilogue(std::true_type{});
+            else epilogue(std::false_type{});
         }
         tile = tile_next;
     }
@@ -496,7 +536,7 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_wide_f16_kernel(const char* __
             const int k = tid >> 7, cl = tid & 127;
             double t = 0.0;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) t += stat_s[w][k][cl];
+            for (int w = 0; w < NW; ++w) t += stat_s[w][k][cl];
             atomicAdd(sums + k * H + 128 * slice + cl, t);
         }
     }
@@ -711,6 +751,11 @@ size_t gru_bwd_f16_workspace_bytes(int64_t V, int H) {
 
 // out_norm_k != NULL: dout is the gradient of norm(out), the gate kernel turns it into the gradient of out (NORM there);
 // in_norm_sums != NULL: h = hn = norm(y_prev), the dm | dh kernel also takes the column sums the backward of THAT norm needs
+#ifndef MPNN_DX_NW
+#define MPNN_DX_NW 8
+#endif
+constexpr int DX_NW = MPNN_DX_NW;                           // waves per block of the dm | dh kernel
+
 template <int H>
 static int launch_gru_bwd_f16_t(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
                                 const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
@@ -723,8 +768,8 @@ static int launch_gru_bwd_f16_t(const float* dout, const float* m, const float* 
     const size_t lds_dw = (size_t)2 * 8 * G_IMG + 64;
     static const hipError_t attr_done = [&] {   // once per process, thread-safe (C++11 static initialisation)
         LdsOptIn opt_in_;
-        opt_in_((const void*)gru_bwd_dx_wide_f16_kernel<H, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64);
-        opt_in_((const void*)gru_bwd_dx_wide_f16_kernel<H, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64);
+        opt_in_((const void*)gru_bwd_dx_wide_f16_kernel<H, true, false, DX_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64);
+        opt_in_((const void*)gru_bwd_dx_wide_f16_kernel<H, true, true, DX_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64);
         opt_in_((const void*)gru_bwd_dw_f16_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dw);
         return opt_in_.err;
     }();
@@ -749,17 +794,17 @@ static int launch_gru_bwd_f16_t(const float* dout, const float* m, const float* 
 
     {   // dm | dh: streamed pre-split weights, 128-column slices
         constexpr int NS = H / 128;
-        const int64_t rounds = (V + 255) / 256;
-        int64_t pblocks = 256 / NS;
+        const int64_t rounds = (V + 32 * DX_NW - 1) / (32 * DX_NW);
+        int64_t pblocks = (256 / NS) * (8 / DX_NW);         // 8 / DX_NW blocks per CU
         if (pblocks > rounds) pblocks = rounds;
         pblocks = (pblocks + 7) / 8 * 8;
         hipLaunchKernelGGL(gru_bwd_dx_presplit_kernel<H>, dim3((unsigned)(NS * 4 * (H / 32))), dim3(512), 0, s, W_ih, W_hh, dxw);
         if (in_norm_sums)
-            hipLaunchKernelGGL((gru_bwd_dx_wide_f16_kernel<H, true, true>), dim3((unsigned)(pblocks * NS)), dim3(512),
+            hipLaunchKernelGGL((gru_bwd_dx_wide_f16_kernel<H, true, true, DX_NW>), dim3((unsigned)(pblocks * NS)), dim3(64 * DX_NW),
                                (size_t)2 * 4 * 128 * 64, s, pieces, inv_scale, W_ih, W_hh, dm, dh, V, (const char*)dxw, h,
                                in_norm_sums);
         else
-            hipLaunchKernelGGL((gru_bwd_dx_wide_f16_kernel<H, true>), dim3((unsigned)(pblocks * NS)), dim3(512),
+            hipLaunchKernelGGL((gru_bwd_dx_wide_f16_kernel<H, true, false, DX_NW>), dim3((unsigned)(pblocks * NS)), dim3(64 * DX_NW),
                                (size_t)2 * 4 * 128 * 64, s, pieces, inv_scale, W_ih, W_hh, dm, dh, V, (const char*)dxw,
                                (const float*)nullptr, (double*)nullptr);
     }

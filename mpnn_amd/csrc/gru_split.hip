@@ -631,6 +631,9 @@ __global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
     auto load_rows = [&](const float* __restrict__ X, int64_t tile, int c, f32x4 (&f)[4]) {
         int64_t row = tile * 32 + r;
         if (row >= V) row = V - 1;
+#ifdef MPNN_ABL_HOT_ROWS        // timing experiment only: every wave re-reads one L2-resident tile (wrong results)
+        row = wv * 32 + r;
+#endif
         const float* p = X + row * H + 32 * c + 16 * hi;
 #pragma unroll
         for (int q = 0; q < 4; ++q) f[q] = *reinterpret_cast<const f32x4*>(p + 4 * q);
@@ -681,7 +684,9 @@ __global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
     auto half = [&](int hc, int64_t tile_next, f32x4 (&x)[4], f32x4 (&nx)[4]) {
         const int c = hc >> 1, mat = hc & 1;
         if (mat == 0) __syncthreads();                     // buffer `cur` is complete, `cur ^ 1` is free
+#ifndef MPNN_ABL_NO_WCOPY       // timing experiment only: the weight chunks are never refreshed (wrong results)
         if (WS && mat == 0) stage_copy((c + 1) % NCHUNK, cur ^ 1);   // lands while this chunk multiplies
+#endif
         const int hn = (hc + 1) % (2 * NCHUNK);
         load_rows((hn & 1) ? h : m, hn == 0 ? tile_next : tile, hn >> 1, nx);
         const int cn = (c + 1) % NCHUNK;

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Timing of the wide GRU kernels (tools/bench_gru_bwd.py under rocprofv3) in the product build and in builds with extra
+# compiler flags, one run per flag set:
+#   bash tools/abl_gru.sh <H> [flagset ...]        e.g.  bash tools/abl_gru.sh 128 -DMPNN_DX_NW=4 -DMPNN_ABL_HOT_ROWS
+# Experiment macros (wrong results, timing only): MPNN_ABL_HOT_ROWS = row operands read from one L2-resident tile,
+# MPNN_ABL_NO_WCOPY = weight chunks never refreshed.  Structure macros (correct results): MPNN_DX_NW=4|8.
+cd "$GRAFT_REPO_ROOT" || exit 1
+H=$1; shift
+bash tools/prof_kernels.sh abl_base_$H "gru_(update|bwd_d|gate)" -- python3 tools/bench_gru_bwd.py $H time
+i=0
+for f in "$@"; do
+  i=$((i+1))
+  echo "== $f"
+  MPNN_EXTRA_HIPCC_FLAGS="$f" python3 -m mpnn_amd.build > gpurun_out/abl_build.log 2>&1 || { tail -5 gpurun_out/abl_build.log; exit 1; }
+  MPNN_EXTRA_HIPCC_FLAGS="$f" bash tools/prof_kernels.sh abl_${i}_$H "gru_(update|bwd_d|gate)" -- python3 tools/bench_gru_bwd.py $H time
+done
