@@ -542,6 +542,237 @@ __global__ void __launch_bounds__(64 * NW) gru_bwd_dx_wide_f16_kernel(const char
     }
 }
 
+// ------------------------------------------------ dm | dh, loads two chunks ahead (the default since round 3)
+// The kernel above requests chunk c + 1's operands -- the block's weight image (global -> LDS copy) and the wave's row
+// fragments -- at the start of chunk c and waits for them at its end.  Measured (tools/abl_gru.sh): with BOTH served from
+// nowhere / from L2 the kernel takes 2.08 instead of 3.0 ms at c4's size, with either one alone it does not move -- a chunk
+// lasts as long as the slower of its two loads, not as long as its 48 MFMAs.  Here both run TWO chunks ahead: a ring of
+// three weight images (96 KB) and three row-fragment register sets, the chunk loop unrolled by three so that every
+// set has a fixed role per body.  vmcnt retires in order and the compiler counts only the loads it can see, so ALL
+// loads of the loop are inline assembly (it inserts no wait of its own for them) and the one wait per chunk,
+// "everything but what this chunk issued", is written out -- tied to the registers of the NEXT chunk's row set so that
+// nothing that reads them can move above it.
+template <int H, bool NORM>
+__global__ void __launch_bounds__(512) gru_bwd_dx_deep_f16_kernel(const char* __restrict__ pieces,
+                                                                  const float* __restrict__ inv_scale,
+                                                                  float* __restrict__ dm, float* __restrict__ dh, int64_t V,
+                                                                  const char* __restrict__ wws,
+                                                                  const float* __restrict__ hn, double* sums) {
+    constexpr int NS = H / 128, CPS = H / 32, NCT = 4 * CPS;
+    constexpr int TILE_BYTES = 32 * 4 * H * 4;
+    constexpr int IMGC = 128 * 64;             // one (matrix, piece) chunk image: 128 output rows x 32 k fp16
+    constexpr int BUF = 4 * IMGC;              // 32 KB
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // three chunk images
+    __shared__ double stat_s[NORM ? 8 : 1][2][128];            // NORM: per wave, column sums of dh | dh * hn
+
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int slice = jb % NS;
+    const int pblock = (jb / NS) * 8 + xcd, pblocks = gridDim.x / NS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hi = lane >> 5;
+
+    const int64_t rounds_total = (V + 255) / 256;              // a round = 256 rows: every wave its own 32-row tile
+    if (pblock >= rounds_total) return;
+    const int64_t nrounds = (rounds_total - pblock + pblocks - 1) / pblocks;
+    if (NORM)
+        for (int i = tid; i < 8 * 2 * 128; i += 512) (&stat_s[0][0][0])[i] = 0.0;   // (published by the first chunk's barrier)
+    const float inv_sw = reinterpret_cast<const float*>(wws)[slice];
+
+    // chunk ct: gate blocks 0, 1 with both matrices, then block 2 as (dan, W_ih), then as (dnh, W_hh)
+    auto chunk_seg = [](int ct) { return ct < 2 * CPS ? ct / CPS : (ct < 3 * CPS ? 2 : 3); };
+    auto chunk_cc = [](int ct) { return ct % CPS; };
+    auto bfrag = [&](const char* wb, int mat, int piece, int nb, int st) {
+        const int n = 32 * nb + r;
+        const int o = 2 * st + hi;
+        return *reinterpret_cast<const h16x8*>(wb + (mat * 2 + piece) * IMGC + n * 64 + ((o ^ ((n >> 2) & 3)) << 4));
+    };
+    f32x16 d_m[4], d_h[4];                                 // 32 rows x 128 features of dm and of dh per wave
+    auto product = [&](f32x16 (&d)[4], const char* wb, int mat, int st, const h16x8& ah, const h16x8& al) {
+#pragma unroll
+        for (int nb = 0; nb < 4; nb += 2) {
+            const h16x8 w0h = bfrag(wb, mat, 0, nb, st), w0l = bfrag(wb, mat, 1, nb, st);
+            const h16x8 w1h = bfrag(wb, mat, 0, nb + 1, st), w1l = bfrag(wb, mat, 1, nb + 1, st);
+            d[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, w0h, d[nb], 0, 0, 0);
+            d[nb + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, w1h, d[nb + 1], 0, 0, 0);
+            d[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w0l, d[nb], 0, 0, 0);
+            d[nb + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w1l, d[nb + 1], 0, 0, 0);
+            d[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w0h, d[nb], 0, 0, 0);
+            d[nb + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w1h, d[nb + 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // this wave's share of chunk ct's weight image -> ring buffer `buf`: four 1 KB copies (two for the one-matrix chunks)
+    auto w_issue = [&](int ct, int buf) {
+        const int seg = chunk_seg(ct);
+        const char* src = wws + 64 + (int64_t)(slice * NCT + ct) * BUF + lane * 16;
+        const char* dst = smem + buf * BUF;
+        const int first = seg == 3 ? 16 : 0, count = seg < 2 ? 32 : 16;
+        for (int i = first + wv; i < first + count; i += 8) g_copy_to_lds(src + i * 1024, dst + i * 1024);
+    };
+    auto rows_ptr = [&](int64_t tile, int ct) {
+        return pieces + tile * (int64_t)TILE_BYTES + (chunk_seg(ct) * (H / 16) + 2 * chunk_cc(ct)) * 2048 + r * 32 + hi * 16;
+    };
+    // a row set = (K step 0: hi, lo piece; K step 1: hi, lo piece) of the wave's 32 rows for one chunk
+#define DX_ROWS(S0, S1, S2, S3, PTR)                                                                                      \
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:1024\n\t"                    \
+                 "global_load_dwordx4 %2, %4, off offset:2048\n\tglobal_load_dwordx4 %3, %4, off offset:3072"             \
+                 : "=&v"(S0), "=&v"(S1), "=&v"(S2), "=&v"(S3)                                                             \
+                 : "v"(PTR)                                                                                               \
+                 : "memory")
+    // the wait itself carries no operands (nothing has to be moved into place in front of it); the empty statement behind
+    // it re-defines the set, so every reader -- and every copy the register allocator may want -- comes after the wait
+#define DX_LANDED(S0, S1, S2, S3) asm volatile("" : "+v"(S0), "+v"(S1), "+v"(S2), "+v"(S3))
+#define DX_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+
+    const int64_t tiles = (V + 31) / 32;
+    int64_t rd = 0;
+    int64_t tile = (int64_t)pblock * 8 + wv;
+    bool live_tile = tile < tiles;
+    if (tile >= tiles) tile = tiles - 1;                   // a wave past the end repeats the last tile and stores nothing
+    int64_t tile_next = nrounds > 1 ? (int64_t)(pblock + pblocks) * 8 + wv : tile;
+    if (tile_next >= tiles) tile_next = tiles - 1;
+    float un = inv_scale[tile] * inv_sw;
+    int ct = 0;
+
+    auto epilogue = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        constexpr int PASSES = FULL ? (NORM ? 4 : 2) : 16, NBP = FULL ? 4 / PASSES : 1, RPP = FULL ? 16 : 4;
+        unsigned ln = (unsigned)lane;                      // opaque: keeps the lane offsets from becoming loop invariants
+        asm volatile("" : "+v"(ln));
+        const unsigned lo = ((ln >> 5) << 2) * H + 128 * slice + (ln & 31u);
+        float* dhb = dh + tile * 32 * H + lo;
+        float* dmb = dm + tile * 32 * H + lo;
+        const float* hnb = NORM ? hn + tile * 32 * H + lo : nullptr;
+        const int64_t row0 = tile * 32 + 4 * hi;
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int nb0 = FULL ? NBP * ps : ps >> 2, i0 = FULL ? 0 : 4 * (ps & 3);
+            float prev[NBP][RPP], hv[NBP][RPP];
+#pragma unroll
+            for (int b = 0; b < NBP; ++b)
+#pragma unroll
+                for (int q = 0; q < RPP; ++q) {
+                    const int i = i0 + q, dr = 8 * (i >> 2) + (i & 3);
+                    int ro = dr * H + 32 * (nb0 + b);
+                    if (!FULL && row0 + dr >= V) ro = (int)(V - 1 - row0) * H + 32 * (nb0 + b);   // (clamped: value unused)
+                    prev[b][q] = dhb[ro];
+                    if (NORM) hv[b][q] = hnb[ro];
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < NBP; ++b) {
+                const int nb = nb0 + b;
+                float sum_d = 0.0f, sum_dh = 0.0f;
+#pragma unroll
+                for (int q = 0; q < RPP; ++q) {
+                    const int i = i0 + q, dr = 8 * (i >> 2) + (i & 3);
+                    if (FULL || row0 + dr < V) {
+                        const float dhv = d_h[nb][i] * un + prev[b][q];
+                        dmb[dr * H + 32 * nb] = d_m[nb][i] * un;
+                        dhb[dr * H + 32 * nb] = dhv;
+                        if (NORM) {
+                            sum_d += dhv;
+                            sum_dh = fmaf(dhv, hv[b][q], sum_dh);
+                        }
+                    }
+                }
+                if (NORM) {
+                    sum_d += __shfl_xor(sum_d, 32);
+                    sum_dh += __shfl_xor(sum_dh, 32);
+                    if (hi == 0) {
+                        stat_s[wv][0][32 * nb + r] += (double)sum_d;
+                        stat_s[wv][1][32 * nb + r] += (double)sum_dh;
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // One chunk.  X = row set of this chunk, Z = of the next one (in flight since the previous body), Y = the set that is
+    // free (last chunk's) and receives chunk + 2; BI = ring buffer of this chunk's weight image.
+#define DX_BODY(X0, X1, X2, X3, Y0, Y1, Y2, Y3, Z0, Z1, Z2, Z3, BI)                                                       \
+    {                                                                                                                     \
+        if (ct == 0) {                                                                                                    \
+            _Pragma("unroll") for (int nb = 0; nb < 4; ++nb)                                                              \
+                _Pragma("unroll") for (int i = 0; i < 16; ++i) { d_m[nb][i] = 0.f; d_h[nb][i] = 0.f; }                    \
+        }                                                                                                                 \
+        g_barrier_lds(); /* every wave's share of this chunk's image has landed; last chunk's buffer is free */          \
+        const int ct2 = ct + 2 >= NCT ? ct + 2 - NCT : ct + 2;                                                            \
+        const char* rp = rows_ptr(ct + 2 >= NCT ? tile_next : tile, ct2);                                                 \
+        DX_ROWS(Y0, Y1, Y2, Y3, rp);                                                                                      \
+        w_issue(ct2, (BI + 2) % 3);                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                                \
+        {                                                                                                                 \
+            const char* wb = smem + BI * BUF;                                                                             \
+            const int seg = chunk_seg(ct);                                                                                \
+            if (seg != 3) product(d_m, wb, 0, 0, X0, X1);                                                                 \
+            if (seg != 2) product(d_h, wb, 1, 0, X0, X1);                                                                 \
+            if (seg != 3) product(d_m, wb, 0, 1, X2, X3);                                                                 \
+            if (seg != 2) product(d_h, wb, 1, 1, X2, X3);                                                                 \
+        }                                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                                \
+        /* all but this chunk's requests (four row loads + four or two copies) have landed */                             \
+        if (chunk_seg(ct2) < 2) DX_WAIT(8);                                                                               \
+        else DX_WAIT(6);                                                                                                  \
+        DX_LANDED(Z0, Z1, Z2, Z3);                                                                                        \
+        if (ct == NCT - 1) {                                                                                              \
+            if (live_tile) {                                                                                              \
+                if (tile * 32 + 32 <= V) epilogue(std::true_type{});                                                      \
+                else epilogue(std::false_type{});                                                                         \
+            }                                                                                                             \
+            ++rd;                                                                                                         \
+            tile = tile_next;                                                                                             \
+            live_tile = (int64_t)(pblock + rd * pblocks) * 8 + wv < tiles;                                                \
+            tile_next = rd + 1 < nrounds ? (int64_t)(pblock + (rd + 1) * pblocks) * 8 + wv : tile;                        \
+            if (tile_next >= tiles) tile_next = tiles - 1;                                                                \
+            un = inv_scale[tile] * inv_sw;                                                                                \
+            ct = 0;                                                                                                       \
+        } else {                                                                                                          \
+            ++ct;                                                                                                         \
+        }                                                                                                                 \
+    }
+
+    h16x8 a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3;
+    {
+        w_issue(0, 0);
+        w_issue(1, 1);
+        const char* p0 = rows_ptr(tile, 0);
+        const char* p1 = rows_ptr(tile, 1);
+        DX_ROWS(a0, a1, a2, a3, p0);
+        DX_ROWS(b0, b1, b2, b3, p1);
+        DX_WAIT(0);
+        DX_LANDED(a0, a1, a2, a3);
+        DX_LANDED(b0, b1, b2, b3);
+        c0 = a0; c1 = a0; c2 = a0; c3 = a0;                 // (defined before the first body overwrites it)
+    }
+    const int64_t total = nrounds * NCT;
+#pragma unroll 1
+    for (int64_t g = 0; g < total; g += 3) {
+        DX_BODY(a0, a1, a2, a3, c0, c1, c2, c3, b0, b1, b2, b3, 0)
+        if (g + 1 >= total) break;
+        DX_BODY(b0, b1, b2, b3, a0, a1, a2, a3, c0, c1, c2, c3, 1)
+        if (g + 2 >= total) break;
+        DX_BODY(c0, c1, c2, c3, b0, b1, b2, b3, a0, a1, a2, a3, 2)
+    }
+#undef DX_BODY
+#undef DX_ROWS
+#undef DX_WAIT
+#undef DX_LANDED
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last two bodies' requests (clamped repeats) before the block ends
+    if (NORM) {
+        __syncthreads();
+        if (tid < 256) {
+            const int k = tid >> 7, cl = tid & 127;
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) t += stat_s[w][k][cl];
+            atomicAdd(sums + k * H + 128 * slice + cl, t);
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------------------------------------- dW
 // H = 128: blockIdx.y = matrix: dW_ih = m^T [dar daz dan], dW_hh = h^T [dar daz dnh] (128 x 384 each = 4 x 12 tiles of
 //          32 x 32; wave = 2 a-tiles x 3 b-tiles); LDS images per buffer: three gate segments + X.
@@ -754,7 +985,11 @@ size_t gru_bwd_f16_workspace_bytes(int64_t V, int H) {
 #ifndef MPNN_DX_NW
 #define MPNN_DX_NW 8
 #endif
-constexpr int DX_NW = MPNN_DX_NW;                           // waves per block of the dm | dh kernel
+constexpr int DX_NW = MPNN_DX_NW;                           // waves per block of the one-chunk-ahead dm | dh kernel
+#ifndef MPNN_DX_DEEP
+#define MPNN_DX_DEEP 1
+#endif
+constexpr bool DX_DEEP = MPNN_DX_DEEP != 0 && DX_NW == 8;   // the two-chunks-ahead kernel (default)
 
 template <int H>
 static int launch_gru_bwd_f16_t(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
@@ -770,6 +1005,8 @@ static int launch_gru_bwd_f16_t(const float* dout, const float* m, const float* 
         LdsOptIn opt_in_;
         opt_in_((const void*)gru_bwd_dx_wide_f16_kernel<H, true, false, DX_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64);
         opt_in_((const void*)gru_bwd_dx_wide_f16_kernel<H, true, true, DX_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64);
+        opt_in_((const void*)gru_bwd_dx_deep_f16_kernel<H, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 4 * 128 * 64);
+        opt_in_((const void*)gru_bwd_dx_deep_f16_kernel<H, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 4 * 128 * 64);
         opt_in_((const void*)gru_bwd_dw_f16_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dw);
         return opt_in_.err;
     }();
@@ -799,7 +1036,14 @@ static int launch_gru_bwd_f16_t(const float* dout, const float* m, const float* 
         if (pblocks > rounds) pblocks = rounds;
         pblocks = (pblocks + 7) / 8 * 8;
         hipLaunchKernelGGL(gru_bwd_dx_presplit_kernel<H>, dim3((unsigned)(NS * 4 * (H / 32))), dim3(512), 0, s, W_ih, W_hh, dxw);
-        if (in_norm_sums)
+        if (DX_DEEP && in_norm_sums)
+            hipLaunchKernelGGL((gru_bwd_dx_deep_f16_kernel<H, true>), dim3((unsigned)(pblocks * NS)), dim3(512),
+                               (size_t)3 * 4 * 128 * 64, s, pieces, inv_scale, dm, dh, V, (const char*)dxw, h, in_norm_sums);
+        else if (DX_DEEP)
+            hipLaunchKernelGGL((gru_bwd_dx_deep_f16_kernel<H, false>), dim3((unsigned)(pblocks * NS)), dim3(512),
+                               (size_t)3 * 4 * 128 * 64, s, pieces, inv_scale, dm, dh, V, (const char*)dxw,
+                               (const float*)nullptr, (double*)nullptr);
+        else if (in_norm_sums)
             hipLaunchKernelGGL((gru_bwd_dx_wide_f16_kernel<H, true, true, DX_NW>), dim3((unsigned)(pblocks * NS)), dim3(64 * DX_NW),
                                (size_t)2 * 4 * 128 * 64, s, pieces, inv_scale, W_ih, W_hh, dm, dh, V, (const char*)dxw, h,
                                in_norm_sums);
