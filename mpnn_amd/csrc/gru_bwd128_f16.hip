@@ -774,9 +774,9 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_deep_f16_kernel(const char* __
 }
 
 // ----------------------------------------------------------------------------------------------------------- dW
-// H = 128: blockIdx.y = matrix: dW_ih = m^T [dar daz dan], dW_hh = h^T [dar daz dnh] (128 x 384 each = 4 x 12 tiles of
+// H = 128: block type = matrix: dW_ih = m^T [dar daz dan], dW_hh = h^T [dar daz dnh] (128 x 384 each = 4 x 12 tiles of
 //          32 x 32; wave = 2 a-tiles x 3 b-tiles); LDS images per buffer: three gate segments + X.
-// H = 256: blockIdx.y = 3 * matrix + gate: one 256 x 256 block of dW_matrix (8 x 8 tiles; wave = 2 a-tiles x 4 b-tiles);
+// H = 256: block type = 3 * matrix + gate: one 256 x 256 block of dW_matrix (8 x 8 tiles; wave = 2 a-tiles x 4 b-tiles);
 //          LDS images per buffer: the two halves of the gate segment + the two halves of X.
 // An image = 8 ksteps = 128 columns of the 32-atom tile, as the workspace has it ([kstep][32 rows][16 columns], 8 KB per
 // piece); a buffer = 4 images x 2 pieces = 64 KB, double-buffered.  The gate pieces need no processing, so they go from
@@ -802,11 +802,19 @@ __global__ void __launch_bounds__(512) gru_bwd_dw_f16_kernel(const float* __rest
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31;
-    const int mat = H == 128 ? blockIdx.y : blockIdx.y / 3;
-    const int gate = H == 128 ? 0 : blockIdx.y % 3;            // H = 256: the gate block of dW this block owns
+    // The NY blocks that walk the SAME tiles (one per matrix, or per (matrix, gate)) share operands -- the gate pieces
+    // between the two matrices, m | h between the gates -- so they are numbered onto one XCD, next to each other: launched
+    // together and working at the same pace, all but the first find a tile's bytes in that XCD's L2 (PMC at width 256:
+    // 12 H floats per atom from HBM when every block read for itself).  gridDim.x = NY * (tile streams, a multiple of 8).
+    constexpr int NY = H == 128 ? 2 : 6;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int by = jb % NY;
+    const int mat = H == 128 ? by : by / 3;
+    const int gate = H == 128 ? 0 : by % 3;                    // H = 256: the gate block of dW this block owns
     const float* X = mat == 0 ? m : h;
     const int64_t tiles = (V + 31) / 32;
-    const int64_t t0 = blockIdx.x, tstep = gridDim.x;      // the launch keeps gridDim.x <= tiles
+    const int64_t t0 = (jb / NY) * 8 + xcd, tstep = gridDim.x / NY;
+    if (t0 >= tiles) return;                                // (block-uniform; only when the batch has fewer tiles than streams)
 
     // wave wv copies blocks (NGB / 8) wv ... of the tile's NGB (slot, kstep, piece) gate blocks
     auto issue_gates = [&](int64_t t, char* T) {
@@ -1056,10 +1064,10 @@ static int launch_gru_bwd_f16_t(const float* dout, const float* m, const float* 
     if (rc) return rc;
 
     constexpr int NY = H == 128 ? 2 : 6;                    // block types: matrix, or (matrix, gate)
-    int64_t gx = 256 / NY;                                  // one block per CU (128 KB of LDS)
-    if (gx > tiles) gx = tiles;
-    hipLaunchKernelGGL(gru_bwd_dw_f16_kernel<H>, dim3((unsigned)gx, NY), dim3(512), lds_dw, s, m, h, pieces, inv_scale, dW_ih,
-                       dW_hh, V);
+    int64_t gx = (256 / NY) / 8 * 8;                        // tile streams: one block per CU (128 KB of LDS), whole XCD groups
+    while (gx > 8 && gx - 8 >= tiles) gx -= 8;
+    hipLaunchKernelGGL(gru_bwd_dw_f16_kernel<H>, dim3((unsigned)(gx * NY)), dim3(512), lds_dw, s, m, h, pieces, inv_scale,
+                       dW_ih, dW_hh, V);
     return launch_status("mpnn_gru_update_bwd_f32(dW, fp16 pieces)");
 }
 
