@@ -802,10 +802,17 @@ __global__ void __launch_bounds__(512) gru_update_stream_wide_kernel(
                         const float u_lo = readlane_f(row_inv, dr), u_hi = readlane_f(row_inv, 4 + dr);
                         un = (hi ? u_hi : u_lo) * w_inv;
                     }
+#ifdef MPNN_ABL_NO_EPI_MATH     // timing experiment only: the gate nonlinearities left out (wrong results)
+                    const float rg = (acc_r[nb][i] * un + br) * mk;
+                    const float zg = (acc_z[nb][i] * un + bz) * mk;
+                    const float nh = acc_nh[nb][i] * un + bnh;
+                    const float ng = (acc_ni[nb][i] * un + bni + rg * nh) * mk;
+#else
                     const float rg = sigmoid_fast(acc_r[nb][i] * un + br) * mk;
                     const float zg = sigmoid_fast(acc_z[nb][i] * un + bz) * mk;
                     const float nh = acc_nh[nb][i] * un + bnh;
                     const float ng = tanh_fast(acc_ni[nb][i] * un + bni + rg * nh) * mk;
+#endif
                     float hval = FULL ? hv[nb][i] : (row0 + dr < V ? hb[dr * H + 32 * nb] : 0.f);
                     if (NORM) hval = fmaf(hval, hsc, hsh) * mk;
                     const float o = ((1.0f - zg) * ng + zg * hval) * mk;

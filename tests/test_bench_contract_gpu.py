@@ -35,6 +35,7 @@ def test_bench_contract_tiny_workload():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == d["unit"]
     assert d["forward"]["value"] > d["value"]                      # inference pass is faster than the training step
     assert d["cold_batch"]["total_ms"] > 0                          # CSR + plan build per new batch, beside the step time
-    assert d["fp32_pipe"]["ms_per_step"] > 0                        # strict fp32 MFMA step (child process)
+    if os.environ.get("MPNN_GRU_MATH") != "fp32":                   # (a run that is on the fp32 pipe already has no side leg)
+        assert d["fp32_pipe"]["ms_per_step"] > 0                    # strict fp32 MFMA step (child process)
     assert cb["host_cpu_count"] >= cb["cores"] and cb["extrapolated_seconds_for_2k_molecules"] > 0
     assert all(v is None or v > 0 for v in d["kernels_ms"].values())

@@ -13,7 +13,11 @@ pytestmark = pytest.mark.gpu
 def dev():
     if not torch.cuda.is_available():
         pytest.skip("needs the GPU")
-    return torch.device("cuda:0")
+    d = torch.device("cuda:0")
+    from mpnn_amd import ops
+    if not ops.gru_norm_applies(128, torch.zeros(1, device=d)):
+        pytest.skip("the fused update + norm kernels are split-precision kernels (not under MPNN_GRU_MATH=fp32)")
+    return d
 
 
 def _gru64(m, h, mask, W_ih, W_hh, b_ih, b_hh):
@@ -213,8 +217,11 @@ def test_norm_constant_kernels_against_torch(dev):
         assert _rel(d * k1 + y * k2 + k4, yl.grad) < 2e-5
 
 
-def test_unsupported_width_is_refused(dev):
+def test_unsupported_width_is_refused():
     from mpnn_amd import _lib, ops
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU")
+    dev = torch.device("cuda:0")
     assert not ops.gru_norm_applies(64, torch.zeros(1, device=dev))
     assert not ops.gru_norm_applies(128, torch.zeros(1))
     x = torch.zeros(8, 64, device=dev)

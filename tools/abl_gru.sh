@@ -3,7 +3,7 @@
 # compiler flags, one run per flag set:
 #   bash tools/abl_gru.sh <H> [flagset ...]        e.g.  bash tools/abl_gru.sh 128 -DMPNN_DX_NW=4 -DMPNN_ABL_HOT_ROWS
 # Experiment macros (wrong results, timing only): MPNN_ABL_HOT_ROWS = row operands read from one L2-resident tile,
-# MPNN_ABL_NO_WCOPY = weight chunks never refreshed.  Structure macros (correct results): MPNN_DX_NW=4|8.
+# MPNN_ABL_NO_WCOPY = weight chunks never refreshed, MPNN_ABL_NO_EPI_MATH = forward gate nonlinearities left out.  Structure macros (correct results): MPNN_DX_NW=4|8.
 cd "$GRAFT_REPO_ROOT" || exit 1
 H=$1; shift
 bash tools/prof_kernels.sh abl_base_$H "gru_(update|bwd_d|gate)" -- python3 tools/bench_gru_bwd.py $H time
