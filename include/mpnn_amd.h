@@ -269,10 +269,12 @@ int mpnn_gru_update_norm_f32(const float* m, const float* h_raw, const float* ma
  * dW_ih, dW_hh [H,3H], db_ih, db_hh [3H] (caller zeroes them).  `workspace`: mpnn_gru_bwd_workspace_bytes(V, H)
  * bytes.  At H = 64 the backward is one kernel that keeps the gate gradients in LDS and needs NO workspace (the
  * function returns a token 16 bytes); at H = 128 / 256 it holds the compact gate gradients
- * (d a_r | d a_z | d a_n | r * d a_n), 4H values per atom, that the dm/dh and dW kernels read -- at H = 128 as two
- * fp16 pieces per value behind one power-of-two scale per 32-atom tile (the same 16 H bytes per atom, V rounded up to
- * 32, plus the scales), at H = 256 as floats; at other widths (and with MPNN_GRU_MATH=fp32) the pre-activation
- * gradients [V,6H] = (dgi | dgh).
+ * (d a_r | d a_z | d a_n | r * d a_n), 4H values per atom, that the dm/dh and dW kernels read -- as two fp16 pieces
+ * per value behind one power-of-two scale per ATOM (16 H bytes per atom, V rounded up to 32, plus one float per atom),
+ * followed by the dm/dh kernel's pre-split weight images; at other widths (and with MPNN_GRU_MATH=fp32) the
+ * pre-activation gradients [V,6H] = (dgi | dgh).  Precision: an atom's dm / dh rows keep the float32 bar whatever the
+ * gradient magnitudes of its neighbours in memory are (tests/test_backward_gpu.py::test_gru_backward_range_guards,
+ * profiles rows_1e6_in_tile / rows_1e8_in_tile).
  */
 size_t mpnn_gru_bwd_workspace_bytes(int64_t V, int H);
 int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const float* h, const float* mask,

@@ -78,6 +78,17 @@ __device__ __forceinline__ void g_copy_to_lds(const char* src, const char* lds_d
                  : "memory");
 }
 
+// the same for one dword per lane: lane L's 4 bytes at `src` land at lds_dst + 4 L
+__device__ __forceinline__ void g_copy_dword_to_lds(const float* src, const float* lds_dst) {
+    typedef __attribute__((address_space(3))) const float lds_float;
+    const unsigned dst = (unsigned)(uintptr_t)(lds_float*)lds_dst;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(dst)
+                 : "memory");
+}
+
 __device__ __forceinline__ h16x8 g_tr8(const char* a0, const char* a1) {
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
@@ -106,7 +117,6 @@ __global__ void __launch_bounds__(512) gru_gate_f16_kernel(const float* __restri
     constexpr int NG = H / 128;                            // column groups per thread
     constexpr int TILE_BYTES = 32 * 4 * H * 4;
     constexpr int SEG_BYTES = (H / 16) * 2048;             // ksteps of one segment
-    __shared__ float red[2][8];
     __shared__ float bsum[8][16][32 * NG + 1];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int srow = tid >> 4, c16 = tid & 15;
@@ -114,8 +124,7 @@ __global__ void __launch_bounds__(512) gru_gate_f16_kernel(const float* __restri
     float cs[32 * NG];                                     // column sums: [group][segment][column]
 #pragma unroll
     for (int k = 0; k < 32 * NG; ++k) cs[k] = 0.f;
-    int par = 0;
-    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x, par ^= 1) {
+    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
         int64_t row = t * 32 + srow;
         const bool ok = row < V;
         if (!ok) row = V - 1;
@@ -167,15 +176,15 @@ __global__ void __launch_bounds__(512) gru_gate_f16_kernel(const float* __restri
                         mx = fmaxf(mx, fabsf(seg[j][s][q][u]));
                     }
         }
-        mx = g_wave_max(mx);
-        if (lane == 0) red[par][wv] = mx;
-        __syncthreads();
-        float gm = red[par][0];
+        // one power-of-two scale per ROW (a row = one atom's 4H gate gradients, held by 16 neighbouring lanes): a row scale
+        // factors out of dm | dh, whose rows are atoms, and the dW kernel folds it into that atom's m | h row -- so an atom
+        // keeps its 22 bits whatever its tile-mates' magnitudes are (one scale per tile left an atom 1e6 below its
+        // neighbours with ~15 bits), and the tile needs no block-wide maximum
 #pragma unroll
-        for (int u = 1; u < 8; ++u) gm = fmaxf(gm, red[par][u]);
+        for (int o = 8; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
         float sg, inv_sg;
-        g_guard_scale<90>(gm, sg, inv_sg);
-        if (tid == 0) inv_scale[t] = inv_sg;
+        g_guard_scale<90>(mx, sg, inv_sg);
+        if (c16 == 0) inv_scale[t * 32 + srow] = inv_sg;
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
             // kstep inside the segment = (c16 + 16 j) >> 1; inside its 1 KB block: row srow, 16-byte half c16 & 1
@@ -232,7 +241,7 @@ __global__ void __launch_bounds__(512) gru_gate_f16_kernel(const float* __restri
 // walked twice, once as (dan, W_ih) -> dm and once as (dnh, W_hh) -> dh, so that no second operand set is ever live.
 // ---- pre-split weights of the 128-column dm | dh kernel: one workspace region per launch ----
 // [0, 64): inverse weight scale of slice s at float s; then the LDS image of (slice, chunk ct) at 64 + (slice * NCT + ct) * 32 KB,
-// [matrix][piece][128 output rows][32 k] exactly as gru_bwd_dx_wide_f16_kernel reads it, so that a chunk is copied
+// [matrix][piece][128 output rows][32 k] exactly as gru_bwd_dx_deep_f16_kernel reads it, so that a chunk is copied
 // global -> LDS verbatim (no vector work, no registers).  Chunks of the third gate block carry one matrix only.
 template <int H>
 __global__ void __launch_bounds__(512) gru_bwd_dx_presplit_kernel(const float* __restrict__ W_ih, const float* __restrict__ W_hh,
@@ -273,280 +282,15 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_presplit_kernel(const float* _
         }
 }
 
+// ------------------------------------------------ dm | dh, loads two chunks ahead
 // NORM: `h` entered the update as hn = norm(y_prev); the backward of that norm needs the column sums of dh and of
 // dh * hn over all atoms.  They are taken here, where dh is final: `hn` is read in the accumulator layout, the sums go
 // to `sums` (2 H doubles, accumulated; per wave in LDS across its tiles, one atomic per column and block at the end).
-// NW = waves per block.  8: one block per CU, a round = 256 rows.  4: TWO independent blocks per CU (64 KB of LDS and four
-// 256-register waves each), a round = 128 rows: the blocks are not in step, so one block's epilogue (memory round trips,
-// no matrix work) runs under the other's K loop; the weight chunks are streamed twice as often (L2 -> LDS).
-template <int H, bool WS = false, bool NORM = false, int NW = 8>
-__global__ void __launch_bounds__(64 * NW) gru_bwd_dx_wide_f16_kernel(const char* __restrict__ pieces,
-                                                                  const float* __restrict__ inv_scale,
-                                                                  const float* __restrict__ W_ih,
-                                                                  const float* __restrict__ W_hh, float* __restrict__ dm,
-                                                                  float* __restrict__ dh, int64_t V,
-                                                                  const char* __restrict__ wws,
-                                                                  const float* __restrict__ hn, double* sums) {
-    static_assert(!NORM || WS, "the fused norm rides on the pre-split kernel");
-    static_assert(NW == 8 || (NW == 4 && WS), "four-wave blocks exist on the pre-split kernel only");
-    constexpr int NS = H / 128, CPS = H / 32, NCT = 4 * CPS, NT = 64 * NW;
-    constexpr int TILE_BYTES = 32 * 4 * H * 4;
-    constexpr int IMGC = 128 * 64;             // one (matrix, piece) chunk image: 128 output rows x 32 k fp16
-    constexpr int BUF = 4 * IMGC;              // 32 KB
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ float redw[8];
-    __shared__ double stat_s[NORM ? NW : 1][2][128];           // NORM: per wave, column sums of dh | dh * hn
-
-    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    const int slice = jb % NS;
-    const int pblock = (jb / NS) * 8 + xcd, pblocks = gridDim.x / NS;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, hi = lane >> 5;
-
-    const int64_t rounds_total = (V + 32 * NW - 1) / (32 * NW);   // a round: every wave its own 32-row tile
-    if (pblock >= rounds_total) return;
-    const int64_t nrounds = (rounds_total - pblock + pblocks - 1) / pblocks;
-    if (NORM)
-        for (int i = tid; i < NW * 2 * 128; i += NT) (&stat_s[0][0][0])[i] = 0.0;   // (published by the first chunk's barrier)
-
-    // one scale for the block's weights: largest magnitude of its 128 rows of both matrices
-    float inv_sw = 1.0f, sw = 1.0f;
-    if (WS) {
-        inv_sw = reinterpret_cast<const float*>(wws)[slice];
-    } else {
-        float mx = 0.f;
-        for (int idx = tid; idx < 2 * 128 * (3 * H / 4); idx += NT) {
-            const int mat = idx / (128 * (3 * H / 4)), rem = idx % (128 * (3 * H / 4));
-            const f32x4 w4 = *reinterpret_cast<const f32x4*>((mat ? W_hh : W_ih) + (int64_t)(128 * slice) * 3 * H + 4 * rem);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fabsf(w4[u]));
-        }
-        mx = g_wave_max(mx);
-        if (lane == 0) redw[wv] = mx;
-        __syncthreads();
-        mx = redw[0];
-#pragma unroll
-        for (int u = 1; u < 8; ++u) mx = fmaxf(mx, redw[u]);
-        g_guard_scale<30>(mx, sw, inv_sw);
-    }
-
-    // staging unit = (matrix, output row n, k-octet of the chunk): 1024 units, unit j of a thread belongs to matrix j
-    const float* wsrc[2];
-    int ldst[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = tid >> 2, o = tid & 3;
-        wsrc[j] = (j ? W_hh : W_ih) + (int64_t)(128 * slice + n) * 3 * H + 8 * o;
-        ldst[j] = j * 2 * IMGC + n * 64 + ((o ^ ((n >> 2) & 3)) << 4);
-    }
-    // chunk ct: gate blocks 0, 1 with both matrices, then block 2 as (dan, W_ih), then as (dnh, W_hh)
-    auto chunk_seg = [](int ct) { return ct < 2 * CPS ? ct / CPS : (ct < 3 * CPS ? 2 : 3); };
-    auto chunk_cc = [](int ct) { return ct % CPS; };
-    f32x4 raw[2][2];
-    auto stage_load = [&](int ct) {
-        const int seg = chunk_seg(ct);
-        const int off = (seg == 3 ? 2 : seg) * H + 32 * chunk_cc(ct);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            if (seg < 2 || seg - 2 == j) {
-                raw[j][0] = *reinterpret_cast<const f32x4*>(wsrc[j] + off);
-                raw[j][1] = *reinterpret_cast<const f32x4*>(wsrc[j] + off + 4);
-            }
-    };
-    auto stage_write = [&](int ct, int buf) {
-        const int seg = chunk_seg(ct);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            if (seg < 2 || seg - 2 == j) {
-                h16x8 ph, pl;
-                g_split8(raw[j][0], raw[j][1], sw, ph, pl);
-                char* base = smem + buf * BUF + ldst[j];
-                *reinterpret_cast<h16x8*>(base) = ph;
-                *reinterpret_cast<h16x8*>(base + IMGC) = pl;
-            }
-    };
-    auto bfrag = [&](int buf, int mat, int piece, int nb, int st) {
-        const int n = 32 * nb + r;
-        const int o = 2 * st + hi;
-        return *reinterpret_cast<const h16x8*>(smem + buf * BUF + (mat * 2 + piece) * IMGC + n * 64 + ((o ^ ((n >> 2) & 3)) << 4));
-    };
-    // this lane's two (hi, lo) fragment pairs of chunk ct for row tile `tile`
-    auto load_rows = [&](int64_t tile, int ct, h16x8 (&f)[4]) {
-#ifdef MPNN_ABL_HOT_ROWS        // timing experiment only: every wave re-reads one L2-resident tile (wrong results)
-        tile = wv;
-#endif
-        const char* p = pieces + tile * (int64_t)TILE_BYTES + (chunk_seg(ct) * (H / 16) + 2 * chunk_cc(ct)) * 2048 + r * 32 + hi * 16;
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            f[2 * st] = *reinterpret_cast<const h16x8*>(p + st * 2048);
-            f[2 * st + 1] = *reinterpret_cast<const h16x8*>(p + st * 2048 + 1024);
-        }
-    };
-
-    f32x16 d_m[4], d_h[4];                                 // 32 rows x 128 features of dm and of dh per wave
-    h16x8 a0[4], a1[4];
-    int cur = 0;
-    int64_t tile = (int64_t)pblock * NW + wv;
-    const int64_t tiles = (V + 31) / 32;
-
-    // the weight fragments of the second pair of column blocks are read before the MFMAs of the first pair are issued:
-    // that LDS round trip hides under six MFMAs
-    auto product = [&](f32x16 (&d)[4], int mat, int st, const h16x8& ah, const h16x8& al) {
-        const h16x8 w0h = bfrag(cur, mat, 0, 0, st), w0l = bfrag(cur, mat, 1, 0, st);
-        const h16x8 w1h = bfrag(cur, mat, 0, 1, st), w1l = bfrag(cur, mat, 1, 1, st);
-        const h16x8 v0h = bfrag(cur, mat, 0, 2, st), v0l = bfrag(cur, mat, 1, 2, st);
-        const h16x8 v1h = bfrag(cur, mat, 0, 3, st), v1l = bfrag(cur, mat, 1, 3, st);
-        __builtin_amdgcn_sched_barrier(0);                 // (without it the compiler sinks the second set below the first MFMAs)
-        d[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, w0h, d[0], 0, 0, 0);
-        d[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, w1h, d[1], 0, 0, 0);
-        d[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w0l, d[0], 0, 0, 0);
-        d[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w1l, d[1], 0, 0, 0);
-        d[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w0h, d[0], 0, 0, 0);
-        d[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w1h, d[1], 0, 0, 0);
-        d[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, v0h, d[2], 0, 0, 0);
-        d[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, v1h, d[3], 0, 0, 0);
-        d[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, v0l, d[2], 0, 0, 0);
-        d[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, v1l, d[3], 0, 0, 0);
-        d[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, v0h, d[2], 0, 0, 0);
-        d[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, v1h, d[3], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    // WS: chunk ct's image comes verbatim from the pre-split workspace (32 x 1 KB; chunks of the third gate block: the 16
-    // of their one matrix)
-    auto stage_copy = [&](int ct, int buf) {
-        const int seg = chunk_seg(ct);
-        const char* src = wws + 64 + (int64_t)(slice * NCT + ct) * BUF + lane * 16;
-        const char* dst = smem + buf * BUF;
-        const int first = seg == 3 ? 16 : 0, count = seg < 2 ? 32 : 16;
-        for (int i = first + wv; i < first + count; i += NW) g_copy_to_lds(src + i * 1024, dst + i * 1024);
-    };
-    auto chunk = [&](int ct, int64_t tile_next, h16x8 (&xa)[4], h16x8 (&na)[4]) {
-        __syncthreads();
-        const int cn = (ct + 1) % NCT;
-#ifndef MPNN_ABL_NO_WCOPY       // timing experiment only: the weight chunks are never refreshed (wrong results)
-        if (WS) stage_copy(cn, cur ^ 1);
-        else stage_load(cn);
-#endif
-        load_rows(cn == 0 ? tile_next : tile, cn, na);
-        __builtin_amdgcn_sched_barrier(0);
-        const int seg = chunk_seg(ct);                     // block-uniform
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            if (seg != 3) product(d_m, 0, st, xa[2 * st], xa[2 * st + 1]);
-            if (seg != 2) product(d_h, 1, st, xa[2 * st], xa[2 * st + 1]);
-        }
-        if (WS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my part of the next chunk's image has landed
-        else stage_write(cn, cur ^ 1);
-        cur ^= 1;
-    };
-
-    if (WS) {
-        stage_copy(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        stage_load(0);
-        stage_write(0, 0);
-    }
-    if (tile >= tiles) tile = tiles - 1;                   // a wave past the end repeats the last tile and stores nothing
-    load_rows(tile, 0, a0);
-    for (int64_t rd = 0; rd < nrounds; ++rd) {
-        int64_t tile_next = rd + 1 < nrounds ? (int64_t)(pblock + (rd + 1) * pblocks) * NW + wv : tile;
-        if (tile_next >= tiles) tile_next = tiles - 1;
-        const bool live_tile = (int64_t)(pblock + rd * pblocks) * NW + wv < tiles;
-        const float un = inv_scale[tile] * inv_sw;
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { d_m[nb][i] = 0.f; d_h[nb][i] = 0.f; }
-#pragma unroll 1
-        for (int ct = 0; ct < NCT; ct += 2) {
-            chunk(ct, tile_next, a0, a1);
-            chunk(ct + 1, tile_next, a1, a0);
-        }
-        // Epilogue.  Every load of a pass (the g * z part of dh that the gate kernel left in place; NORM: hn) goes out before
-        // the pass's first store: vmcnt retires in order and counts a store until it is acknowledged, so a load behind stores
-        // waits for all of them -- with one load group per four rows the tile paid sixteen memory round trips in a row, every
-        // wave of the block in the same phase.  A full tile is one base + lane offset +
-        // compile-time offsets and takes two column blocks per pass (NORM: one, with its hn values): 32 values in the
-        // registers the K loop has freed; the ragged last tile goes row group by row group with clamped rows.
-        auto epilogue = [&](auto full_tag) {
-            constexpr bool FULL = decltype(full_tag)::value;
-            constexpr int PASSES = FULL ? (NORM ? 4 : 2) : 16, NBP = FULL ? 4 / PASSES : 1, RPP = FULL ? 16 : 4;
-            unsigned ln = (unsigned)lane;                  // opaque: keeps the lane offsets from becoming loop invariants
-            asm volatile("" : "+v"(ln));
-            const unsigned lo = ((ln >> 5) << 2) * H + 128 * slice + (ln & 31u);
-            float* dhb = dh + tile * 32 * H + lo;
-            float* dmb = dm + tile * 32 * H + lo;
-            const float* hnb = NORM ? hn + tile * 32 * H + lo : nullptr;
-            const int64_t row0 = tile * 32 + 4 * hi;
-#pragma unroll
-            for (int ps = 0; ps < PASSES; ++ps) {
-                const int nb0 = FULL ? NBP * ps : ps >> 2, i0 = FULL ? 0 : 4 * (ps & 3);
-                float prev[NBP][RPP], hv[NBP][RPP];
-#pragma unroll
-                for (int b = 0; b < NBP; ++b)
-#pragma unroll
-                    for (int q = 0; q < RPP; ++q) {
-                        const int i = i0 + q, dr = 8 * (i >> 2) + (i & 3);
-                        int ro = dr * H + 32 * (nb0 + b);
-                        if (!FULL && row0 + dr >= V) ro = (int)(V - 1 - row0) * H + 32 * (nb0 + b);   // (clamped: value unused)
-                        prev[b][q] = dhb[ro];
-                        if (NORM) hv[b][q] = hnb[ro];
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int b = 0; b < NBP; ++b) {
-                    const int nb = nb0 + b;
-                    float sum_d = 0.0f, sum_dh = 0.0f;
-#pragma unroll
-                    for (int q = 0; q < RPP; ++q) {
-                        const int i = i0 + q, dr = 8 * (i >> 2) + (i & 3);
-                        if (FULL || row0 + dr < V) {
-                            const float dhv = d_h[nb][i] * un + prev[b][q];
-                            dmb[dr * H + 32 * nb] = d_m[nb][i] * un;
-                            dhb[dr * H + 32 * nb] = dhv;
-                            if (NORM) {
-                                sum_d += dhv;
-                                sum_dh = fmaf(dhv, hv[b][q], sum_dh);
-                            }
-                        }
-                    }
-                    if (NORM) {
-                        sum_d += __shfl_xor(sum_d, 32);
-                        sum_dh += __shfl_xor(sum_dh, 32);
-                        if (hi == 0) {
-                            stat_s[wv][0][32 * nb + r] += (double)sum_d;
-                            stat_s[wv][1][32 * nb + r] += (double)sum_dh;
-                        }
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        if (live_tile) {
-            if (tile * 32 + 32 <= V) epilogue(std::true_type{});
-            else epilogue(std::false_type{});
-        }
-        tile = tile_next;
-    }
-    if (NORM) {
-        __syncthreads();
-        if (tid < 256) {
-            const int k = tid >> 7, cl = tid & 127;
-            double t = 0.0;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) t += stat_s[w][k][cl];
-            atomicAdd(sums + k * H + 128 * slice + cl, t);
-        }
-    }
-}
-
-// ------------------------------------------------ dm | dh, loads two chunks ahead (the default since round 3)
-// The kernel above requests chunk c + 1's operands -- the block's weight image (global -> LDS copy) and the wave's row
-// fragments -- at the start of chunk c and waits for them at its end.  Measured (tools/abl_gru.sh): with BOTH served from
-// nowhere / from L2 the kernel takes 2.08 instead of 3.0 ms at c4's size, with either one alone it does not move -- a chunk
-// lasts as long as the slower of its two loads, not as long as its 48 MFMAs.  Here both run TWO chunks ahead: a ring of
+// Rounds 2-3 had a form of this kernel that requested chunk c + 1's operands -- the block's weight image (global -> LDS
+// copy) and the wave's row fragments -- at the start of chunk c and waited for them at its end.  Measured on it
+// (DESIGN 3c): with BOTH served from nowhere / from L2 it took 2.08 instead of 3.0 ms at c4's size, with either one alone
+// it did not move -- a chunk lasted as long as the slower of its two loads, not as long as its 48 MFMAs.  Here both run
+// TWO chunks ahead: a ring of
 // three weight images (96 KB) and three row-fragment register sets, the chunk loop unrolled by three so that every
 // set has a fixed role per body.  vmcnt retires in order and the compiler counts only the loads it can see, so ALL
 // loads of the loop are inline assembly (it inserts no wait of its own for them) and the one wait per chunk,
@@ -564,6 +308,7 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_deep_f16_kernel(const char* __
     constexpr int BUF = 4 * IMGC;              // 32 KB
     extern __shared__ __attribute__((aligned(16))) char smem[];          // three chunk images
     __shared__ double stat_s[NORM ? 8 : 1][2][128];            // NORM: per wave, column sums of dh | dh * hn
+    __shared__ float rs_s[8][64];                              // per wave: 1 / (gate-gradient scale) of its tile's rows
 
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
     const int slice = jb % NS;
@@ -632,12 +377,18 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_deep_f16_kernel(const char* __
     if (tile >= tiles) tile = tiles - 1;                   // a wave past the end repeats the last tile and stores nothing
     int64_t tile_next = nrounds > 1 ? (int64_t)(pblock + pblocks) * 8 + wv : tile;
     if (tile_next >= tiles) tile_next = tiles - 1;
-    float un = inv_scale[tile] * inv_sw;
     int ct = 0;
+    // the rows' inverse scales travel global -> LDS like every other load of the loop (no register across the K loop, no
+    // load the compiler would wait for): requested when a round begins, read in its epilogue sixteen or more chunks later
+#ifndef MPNN_ABL_DX_NOSCALE
+    g_copy_dword_to_lds(inv_scale + tile * 32 + r, rs_s[wv]);
+#endif
 
     auto epilogue = [&](auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
-        constexpr int PASSES = FULL ? (NORM ? 4 : 2) : 16, NBP = FULL ? 4 / PASSES : 1, RPP = FULL ? 16 : 4;
+        // pass = (column blocks, rows): full tile 2 x 16 (NORM: 1 x 8, its hn values need the registers); ragged tile 1 x 4
+        constexpr int RPP = FULL ? (NORM ? 8 : 16) : 4, NBP = FULL && !NORM ? 2 : 1, PASSES = 64 / (RPP * NBP);
+        constexpr int PPB = 16 / RPP;                      // passes per column block (NBP == 1)
         unsigned ln = (unsigned)lane;                      // opaque: keeps the lane offsets from becoming loop invariants
         asm volatile("" : "+v"(ln));
         const unsigned lo = ((ln >> 5) << 2) * H + 128 * slice + (ln & 31u);
@@ -645,10 +396,21 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_deep_f16_kernel(const char* __
         float* dmb = dm + tile * 32 * H + lo;
         const float* hnb = NORM ? hn + tile * 32 * H + lo : nullptr;
         const int64_t row0 = tile * 32 + 4 * hi;
+        // rs_s[wv][row]: 1 / (scale of the tile's row).  Accumulator entry i of a lane is row 8 (i >> 2) + 4 hi + (i & 3):
+        // four consecutive rows per i >> 2, one 16-byte LDS read each (per pass: nothing is kept across passes)
+        const float* rsp = rs_s[wv] + ((ln >> 5) << 2);
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
-            const int nb0 = FULL ? NBP * ps : ps >> 2, i0 = FULL ? 0 : 4 * (ps & 3);
+            const int nb0 = NBP == 2 ? 2 * ps : ps / PPB, i0 = NBP == 2 ? 0 : RPP * (ps % PPB);
             float prev[NBP][RPP], hv[NBP][RPP];
+            f32x4 un4[RPP / 4];
+#pragma unroll
+            for (int g4 = 0; g4 < RPP / 4; ++g4)
+#ifdef MPNN_ABL_DX_NOSCALE      // timing experiment only: the rows' scales are not undone (wrong results)
+                un4[g4] = f32x4{inv_sw, inv_sw, inv_sw, inv_sw};
+#else
+                un4[g4] = *reinterpret_cast<const f32x4*>(rsp + 8 * ((i0 >> 2) + g4)) * inv_sw;
+#endif
 #pragma unroll
             for (int b = 0; b < NBP; ++b)
 #pragma unroll
@@ -668,6 +430,7 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_deep_f16_kernel(const char* __
                 for (int q = 0; q < RPP; ++q) {
                     const int i = i0 + q, dr = 8 * (i >> 2) + (i & 3);
                     if (FULL || row0 + dr < V) {
+                        const float un = un4[q >> 2][q & 3];
                         const float dhv = d_h[nb][i] * un + prev[b][q];
                         dmb[dr * H + 32 * nb] = d_m[nb][i] * un;
                         dhb[dr * H + 32 * nb] = dhv;
@@ -692,6 +455,11 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_deep_f16_kernel(const char* __
 
     // One chunk.  X = row set of this chunk, Z = of the next one (in flight since the previous body), Y = the set that is
     // free (last chunk's) and receives chunk + 2; BI = ring buffer of this chunk's weight image.
+#ifdef MPNN_ABL_DX_NOSCALE
+#define DX_RS_COPY() ((void)0)
+#else
+#define DX_RS_COPY() g_copy_dword_to_lds(inv_scale + tile * 32 + r, rs_s[wv])
+#endif
 #define DX_BODY(X0, X1, X2, X3, Y0, Y1, Y2, Y3, Z0, Z1, Z2, Z3, BI)                                                       \
     {                                                                                                                     \
         if (ct == 0) {                                                                                                    \
@@ -727,7 +495,7 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_deep_f16_kernel(const char* __
             live_tile = (int64_t)(pblock + rd * pblocks) * 8 + wv < tiles;                                                \
             tile_next = rd + 1 < nrounds ? (int64_t)(pblock + (rd + 1) * pblocks) * 8 + wv : tile;                        \
             if (tile_next >= tiles) tile_next = tiles - 1;                                                                \
-            un = inv_scale[tile] * inv_sw;                                                                                \
+            DX_RS_COPY();                                                                                                 \
             ct = 0;                                                                                                       \
         } else {                                                                                                          \
             ++ct;                                                                                                         \
@@ -757,6 +525,7 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_deep_f16_kernel(const char* __
         DX_BODY(c0, c1, c2, c3, b0, b1, b2, b3, a0, a1, a2, a3, 2)
     }
 #undef DX_BODY
+#undef DX_RS_COPY
 #undef DX_ROWS
 #undef DX_WAIT
 #undef DX_LANDED
@@ -843,7 +612,7 @@ __global__ void __launch_bounds__(512) gru_bwd_dw_f16_kernel(const float* __rest
             q.x[j][0] = *reinterpret_cast<const f32x4*>(X + row * H + 128 * j + c16 * 8);
             q.x[j][1] = *reinterpret_cast<const f32x4*>(X + row * H + 128 * j + c16 * 8 + 4);
         }
-        q.inv_sg = inv_scale[t];
+        q.inv_sg = inv_scale[t * 32 + srow];               // this row's gate-gradient scale (inverse)
         return q;
     };
     auto publish = [&](const XRows& q, int par) {
@@ -853,16 +622,20 @@ __global__ void __launch_bounds__(512) gru_bwd_dw_f16_kernel(const float* __rest
 #pragma unroll
             for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fmaxf(fabsf(q.x[j][0][u]), fabsf(q.x[j][1][u])));
         mx = g_wave_max(mx * q.live);
-        if (lane == 0) red[8 * par + wv] = mx;
+        const float iv = g_wave_max(q.inv_sg);             // largest inverse = the scale of the tile's largest row
+        if (lane == 0) { red[8 * par + wv] = mx; red[16 + 8 * par + wv] = iv; }
     };
     float C_run = 3.0e38f;
     auto park_x = [&](const XRows& q, char* T, int par) {  // after the barrier that follows publish()
-        float xm = red[8 * par];
+        float xm = red[8 * par], ivm = red[16 + 8 * par];
 #pragma unroll
-        for (int u = 1; u < 8; ++u) xm = fmaxf(xm, red[8 * par + u]);
+        for (int u = 1; u < 8; ++u) { xm = fmaxf(xm, red[8 * par + u]); ivm = fmaxf(ivm, red[16 + 8 * par + u]); }
         float sxo, inv_sxo;
         g_guard_scale<30>(xm, sxo, inv_sxo);
-        const float sg = __int_as_float((254 - ((__float_as_int(q.inv_sg) >> 23) & 0xff)) << 23);
+        // the gate pieces of row r carry s_r; its m | h row is split behind C / s_r, so every product of the tile carries C.
+        // C <= (smallest s_r of the tile) * sxo keeps the largest-gradient row's m | h below the fp16 range; rows with
+        // smaller gradients get m | h pieces below their best precision by exactly the factor their contribution is small
+        const float sg = __int_as_float((254 - ((__float_as_int(ivm) >> 23) & 0xff)) << 23);
         C_run = fminf(C_run, sg * sxo);
         const float sx = C_run * q.inv_sg;
 #pragma unroll
@@ -981,24 +754,15 @@ __global__ void __launch_bounds__(512) gru_bwd_dw_f16_kernel(const float* __rest
         }
 }
 
-// pieces | tile scales | pre-split weight images of the dm | dh kernel
+// pieces | one scale per row | pre-split weight images of the dm | dh kernel
 static size_t gru_bwd_f16_dxw_bytes(int H) { return 64 + (size_t)(H / 128) * (4 * H / 32) * (4 * 128 * 64); }
 size_t gru_bwd_f16_workspace_bytes(int64_t V, int H) {
     const int64_t tiles = (V + 31) / 32;
-    return (size_t)tiles * (32 * 4 * H * 4) + (size_t)((tiles + 63) / 64 * 64) * sizeof(float) + gru_bwd_f16_dxw_bytes(H);
+    return (size_t)tiles * (32 * 4 * H * 4) + (size_t)(tiles * 32) * sizeof(float) + gru_bwd_f16_dxw_bytes(H);
 }
 
 // out_norm_k != NULL: dout is the gradient of norm(out), the gate kernel turns it into the gradient of out (NORM there);
 // in_norm_sums != NULL: h = hn = norm(y_prev), the dm | dh kernel also takes the column sums the backward of THAT norm needs
-#ifndef MPNN_DX_NW
-#define MPNN_DX_NW 8
-#endif
-constexpr int DX_NW = MPNN_DX_NW;                           // waves per block of the one-chunk-ahead dm | dh kernel
-#ifndef MPNN_DX_DEEP
-#define MPNN_DX_DEEP 1
-#endif
-constexpr bool DX_DEEP = MPNN_DX_DEEP != 0 && DX_NW == 8;   // the two-chunks-ahead kernel (default)
-
 template <int H>
 static int launch_gru_bwd_f16_t(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
                                 const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
@@ -1007,12 +771,10 @@ static int launch_gru_bwd_f16_t(const float* dout, const float* m, const float* 
     const int64_t tiles = (V + 31) / 32;
     char* pieces = (char*)workspace;
     float* inv_scale = (float*)(pieces + (size_t)tiles * (32 * 4 * H * 4));
-    char* dxw = (char*)(inv_scale + (tiles + 63) / 64 * 64);             // pre-split weights of the dm | dh kernel
-    const size_t lds_dw = (size_t)2 * 8 * G_IMG + 64;
+    char* dxw = (char*)(inv_scale + tiles * 32);                         // (one scale per row) pre-split weights of the dm | dh kernel
+    const size_t lds_dw = (size_t)2 * 8 * G_IMG + 128;       // two double-buffered tiles + the per-wave maxima of two tiles
     static const hipError_t attr_done = [&] {   // once per process, thread-safe (C++11 static initialisation)
         LdsOptIn opt_in_;
-        opt_in_((const void*)gru_bwd_dx_wide_f16_kernel<H, true, false, DX_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64);
-        opt_in_((const void*)gru_bwd_dx_wide_f16_kernel<H, true, true, DX_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64);
         opt_in_((const void*)gru_bwd_dx_deep_f16_kernel<H, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 4 * 128 * 64);
         opt_in_((const void*)gru_bwd_dx_deep_f16_kernel<H, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 4 * 128 * 64);
         opt_in_((const void*)gru_bwd_dw_f16_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dw);
@@ -1039,25 +801,17 @@ static int launch_gru_bwd_f16_t(const float* dout, const float* m, const float* 
 
     {   // dm | dh: streamed pre-split weights, 128-column slices
         constexpr int NS = H / 128;
-        const int64_t rounds = (V + 32 * DX_NW - 1) / (32 * DX_NW);
-        int64_t pblocks = (256 / NS) * (8 / DX_NW);         // 8 / DX_NW blocks per CU
+        const int64_t rounds = (V + 255) / 256;
+        int64_t pblocks = 256 / NS;                          // x NS slices = one block per CU
         if (pblocks > rounds) pblocks = rounds;
         pblocks = (pblocks + 7) / 8 * 8;
         hipLaunchKernelGGL(gru_bwd_dx_presplit_kernel<H>, dim3((unsigned)(NS * 4 * (H / 32))), dim3(512), 0, s, W_ih, W_hh, dxw);
-        if (DX_DEEP && in_norm_sums)
+        if (in_norm_sums)
             hipLaunchKernelGGL((gru_bwd_dx_deep_f16_kernel<H, true>), dim3((unsigned)(pblocks * NS)), dim3(512),
                                (size_t)3 * 4 * 128 * 64, s, pieces, inv_scale, dm, dh, V, (const char*)dxw, h, in_norm_sums);
-        else if (DX_DEEP)
+        else
             hipLaunchKernelGGL((gru_bwd_dx_deep_f16_kernel<H, false>), dim3((unsigned)(pblocks * NS)), dim3(512),
                                (size_t)3 * 4 * 128 * 64, s, pieces, inv_scale, dm, dh, V, (const char*)dxw,
-                               (const float*)nullptr, (double*)nullptr);
-        else if (in_norm_sums)
-            hipLaunchKernelGGL((gru_bwd_dx_wide_f16_kernel<H, true, true, DX_NW>), dim3((unsigned)(pblocks * NS)), dim3(64 * DX_NW),
-                               (size_t)2 * 4 * 128 * 64, s, pieces, inv_scale, W_ih, W_hh, dm, dh, V, (const char*)dxw, h,
-                               in_norm_sums);
-        else
-            hipLaunchKernelGGL((gru_bwd_dx_wide_f16_kernel<H, true, false, DX_NW>), dim3((unsigned)(pblocks * NS)), dim3(64 * DX_NW),
-                               (size_t)2 * 4 * 128 * 64, s, pieces, inv_scale, W_ih, W_hh, dm, dh, V, (const char*)dxw,
                                (const float*)nullptr, (double*)nullptr);
     }
     rc = launch_status("mpnn_gru_update_bwd_f32(dx, fp16 pieces)");

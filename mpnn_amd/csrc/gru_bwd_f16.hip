@@ -5,14 +5,16 @@
 // the dW_ih | dW_hh accumulators, waves 4-7 compute dm / dh with their weight slice resident in registers.  What
 // changes with fp16 pieces:
 //   * fp16 has 5 exponent bits, so every operand is range-guarded by an exact power-of-two scale: the gate gradients
-//     of a tile by sg (their largest magnitude lands in [2^14, 2^15)), a dx wave's weight slice by sw, the m | h rows
-//     by sx.  x*s = hi + lo, hi = fp16(x*s), lo = fp16(x*s - hi); entries more than 2^18 below their tile's largest
-//     lose relative (not absolute) accuracy.
-//   * the tile's scale is needed before the first split, i.e. a maximum over what four waves stage: one more block
-//     barrier per tile (the dx waves wait at that point anyway).
-//   * dm / dh are per tile: the epilogue multiplies by 1 / (sg * sw).  dW accumulates over all tiles of a block in
-//     registers; for that sum sg * sx must be the same for every tile.  The block keeps C = min over the tiles so far
-//     of sg * sx_opt and scales a tile's m | h rows by sx = C / sg <= sx_opt (never overflows; a tile whose gradients
+//     of a ROW (atom) by sg_row (the row's largest magnitude lands in [2^14, 2^15)), a dx wave's weight slice by sw, the
+//     row's m | h by sx_row.  x*s = hi + lo, hi = fp16(x*s), lo = fp16(x*s - hi); entries more than 2^16 below their
+//     ROW's largest lose relative (not absolute) accuracy.  (Round 2 had one sg per tile: an atom whose gradients lay
+//     1e6 below a tile-mate's kept ~15 bits in its dm / dh rows.)
+//   * C (below) needs the tile's largest gate gradient before the first split, i.e. a maximum over what four waves
+//     stage: one more block barrier per tile (the dx waves wait at that point anyway).
+//   * dm / dh rows are per atom: the epilogue multiplies row by row by 1 / (sg_row * sw).  dW accumulates over all tiles
+//     of a block in registers; for that sum sg_row * sx_row must be the same for every row of every tile.  The block
+//     keeps C = min over the tiles so far of sg_tile * sx_opt (sg_tile = the scale of the tile's largest row, its
+//     smallest) and scales a row's m | h by sx_row = C / sg_row <= sx_opt (never overflows; a tile whose gradients
 //     are small next to earlier ones gets m | h pieces below their best precision, by exactly the factor its
 //     contribution is small).  When C drops the accumulators are multiplied by the ratio (a power of two: exact).
 //   * m | h are parked as pieces too (same [32][128 x 16 bit] image format as the gate pairs, same LDS footprint as
@@ -38,8 +40,8 @@ constexpr int F_LDZ = 68;
 constexpr int F_GZ = 32 * F_LDZ * 4;
 constexpr int F_TILE = F_P + F_GZ;                     // 57,856 bytes; two of them per block
 constexpr int F_RED = 2 * F_TILE;                      // float red[8]: per staging wave max |gate gradient|, max |m|h|
-constexpr int F_SCL = F_RED + 32;                      // float inv_sg[2]: per tile buffer
-constexpr int F_LDS = F_SCL + 16;
+constexpr int F_SCL = F_RED + 32;                      // float inv_sg[2][32]: per tile buffer, per row
+constexpr int F_LDS = F_SCL + 256;
 
 // byte offset of 16-byte chunk `ch` (8 columns) of row `row` inside an image (the swizzle of gru_bwd_presplit.hip)
 __device__ __forceinline__ int f_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
@@ -137,8 +139,12 @@ __global__ void __launch_bounds__(512) gru_bwd_f16_kernel(
 #pragma unroll
         for (int k = 0; k < 16; ++k) cs[k] = 0.f;
         struct Grads { f32x4 s[6]; f32x4 gz; };           // dar, daz, dan, dnh, m, h of one row's four columns
-        auto grads_of = [&](const Staged& q, float count, float& gmx, float& xmx) {
+        // rmx: largest gate-gradient magnitude of THIS row (the row's 16 staging lanes are neighbours in the wave): the gate
+        // pieces carry one scale per row -- a row scale factors out of dm | dh, and in dW it is folded into the row's m | h
+        // scale (sx_row = C / sg_row) -- so an atom keeps its 22 bits whatever its tile-mates' magnitudes are
+        auto grads_of = [&](const Staged& q, float count, float& gmx, float& xmx, float& rmx) {
             Grads G;
+            rmx = 0.f;
             const float mk = q.ok ? q.mk : 0.0f;          // rows past V contribute exact zeros
             f_gate_grads4(q.v_do, q.vh, q.v_r, q.v_z, q.v_n, q.v_nh, mk, G.s[0], G.s[1], G.s[2], G.s[3]);
             G.gz = q.v_do * mk * q.v_z;
@@ -150,8 +156,11 @@ __global__ void __launch_bounds__(512) gru_bwd_f16_kernel(
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     cs[4 * s + j] = fmaf(G.s[s][j], count, cs[4 * s + j]);
-                    gmx = fmaxf(gmx, fabsf(G.s[s][j]));
+                    rmx = fmaxf(rmx, fabsf(G.s[s][j]));
                 }
+#pragma unroll
+            for (int o = 8; o >= 1; o >>= 1) rmx = fmaxf(rmx, __shfl_xor(rmx, o));
+            gmx = fmaxf(gmx, rmx);
 #pragma unroll
             for (int j = 0; j < 4; ++j) xmx = fmaxf(xmx, fmaxf(fabsf(G.s[4][j]), fabsf(G.s[5][j])));
             return G;
@@ -183,14 +192,18 @@ __global__ void __launch_bounds__(512) gru_bwd_f16_kernel(
             }
         };
         float C_run = 3.0e38f;                            // min over staged tiles of sg * (best m|h scale)
-        // after the barrier that follows publish(): the staged tile's scales; C_run is updated
-        auto tile_scales = [&](float& sg, float& sx, float& inv_sg) {
+        // after the barrier that follows publish(): C_run is updated from the tile's largest row (its scale is the smallest
+        // of the tile, so C <= sg_row * sx_opt holds for every row); then a row's scales from its own maximum
+        auto tile_scales = [&]() {
             const float gm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
             const float xm = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
-            float sxo, inv_sxo;
-            guard_scale<90>(gm, sg, inv_sg);
+            float sgt, inv_sgt, sxo, inv_sxo;
+            guard_scale<90>(gm, sgt, inv_sgt);
             guard_scale<30>(xm, sxo, inv_sxo);
-            C_run = fminf(C_run, sg * sxo);
+            C_run = fminf(C_run, sgt * sxo);
+        };
+        auto row_scales = [&](float rmx, float& sg, float& sx, float& inv_sg) {
+            guard_scale<90>(rmx, sg, inv_sg);
             sx = C_run * inv_sg;
         };
 
@@ -223,15 +236,18 @@ __global__ void __launch_bounds__(512) gru_bwd_f16_kernel(
             for (int q = 0; q < 16; ++q) R[j][q] = 0.f;
         {
             const Staged q0 = stage_load(t0, 0), q1 = stage_load(t0, 1);
-            float gmx = 0.f, xmx = 0.f;
-            const Grads G0 = grads_of(q0, 1.0f, gmx, xmx), G1 = grads_of(q1, 1.0f, gmx, xmx);
+            float gmx = 0.f, xmx = 0.f, r0, r1;
+            const Grads G0 = grads_of(q0, 1.0f, gmx, xmx, r0), G1 = grads_of(q1, 1.0f, gmx, xmx, r1);
             publish(gmx, xmx);
             __syncthreads();
+            tile_scales();
             float sg, sx, inv_sg;
-            tile_scales(sg, sx, inv_sg);
+            row_scales(r0, sg, sx, inv_sg);
             park(G0, 0, smem, sg, sx);
+            if ((tid & 15) == 0) scl[srow] = inv_sg;
+            row_scales(r1, sg, sx, inv_sg);
             park(G1, 1, smem, sg, sx);
-            if (tid == 0) scl[0] = inv_sg;
+            if ((tid & 15) == 0) scl[srow + 16] = inv_sg;
         }
         float C_acc = C_run;                              // sg * sx of everything summed into R so far
         float C_cur = C_run;                              // ... of the tile in buffer `cur`
@@ -269,17 +285,20 @@ __global__ void __launch_bounds__(512) gru_bwd_f16_kernel(
             }
             __builtin_amdgcn_sched_barrier(0);
             {
-                float gmx = 0.f, xmx = 0.f;
+                float gmx = 0.f, xmx = 0.f, r0, r1;
                 const float count = more ? 1.0f : 0.0f;   // the clamped re-stage counts nothing
-                const Grads G0 = grads_of(nx0, count, gmx, xmx), G1 = grads_of(nx1, count, gmx, xmx);
+                const Grads G0 = grads_of(nx0, count, gmx, xmx, r0), G1 = grads_of(nx1, count, gmx, xmx, r1);
                 publish(gmx, xmx);
                 __syncthreads();
-                float sg, sx, inv_sg;
-                tile_scales(sg, sx, inv_sg);
+                tile_scales();
                 char* Tn = smem + (cur ^ 1) * F_TILE;
+                float sg, sx, inv_sg;
+                row_scales(r0, sg, sx, inv_sg);
                 park(G0, 0, Tn, sg, sx);
+                if ((tid & 15) == 0) scl[(cur ^ 1) * 32 + srow] = inv_sg;
+                row_scales(r1, sg, sx, inv_sg);
                 park(G1, 1, Tn, sg, sx);
-                if (tid == 0) scl[cur ^ 1] = inv_sg;
+                if ((tid & 15) == 0) scl[(cur ^ 1) * 32 + srow + 16] = inv_sg;
                 C_cur = C_run;
             }
             cur ^= 1;
@@ -370,7 +389,7 @@ __global__ void __launch_bounds__(512) gru_bwd_f16_kernel(
     for (int64_t t = t0; t < tiles; t += tstep) {
         __syncthreads();
         const char* T = smem + cur * F_TILE;
-        const float un = scl[cur] * inv_sw;
+        const float* rs = scl + cur * 32;                  // 1 / (scale of the tile's row), per row
         // two accumulators (even / odd K steps) issued alternately
         f32x16 d, d1;
 #pragma unroll
@@ -394,7 +413,7 @@ __global__ void __launch_bounds__(512) gru_bwd_f16_kernel(
                 d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, Wh[p + 1], d1, 0, 0, 0);
             }
 #pragma unroll
-        for (int q = 0; q < 16; ++q) d[q] = (d[q] + d1[q]) * un;
+        for (int q = 0; q < 16; ++q) d[q] = (d[q] + d1[q]) * (rs[acc_row(q, lane)] * inv_sw);
         if (which == 1) {                                 // scalar branch; the 16 LDS reads go out together
             const float* GZ = reinterpret_cast<const float*>(T + F_P);
 #pragma unroll
