@@ -23,29 +23,46 @@ __global__ void __launch_bounds__(256) att_gate_fwd_kernel(const float* __restri
     const int sub = lane / LPR, c = 4 * (lane % LPR);
     const bool live = c < F;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
-    for (int64_t e0 = wave * RPW; e0 < E; e0 += nwaves * RPW) {
-        const int64_t e = e0 + sub;
-        const bool ok = e < E;
-        const int64_t ec = ok ? e : E - 1;
-        const int d = dst[ec], t = edge_type[ec];
-        f32x4 z = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
-        if (live) z = *reinterpret_cast<const f32x4*>(z_atom + (int64_t)d * F + c) +
-                      *reinterpret_cast<const f32x4*>(q + (int64_t)t * F + c);
-        float mx = fmaxf(fmaxf(z.x, z.y), fmaxf(z.z, z.w));
+    // UN edges per lane group and pass, every load of the pass requested before the first is used: with one edge per
+    // pass the kernel was a chain index -> logits -> store per wave (89 % of its wave cycles parked on loads)
+    constexpr int UN = 4;
+    for (int64_t e0 = wave * (RPW * UN); e0 < E; e0 += nwaves * (RPW * UN)) {
+        int64_t e[UN];
+        bool ok[UN];
+        int d[UN], t[UN];
 #pragma unroll
-        for (int o = 1; o < LPR; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        f32x4 p = {0.f, 0.f, 0.f, 0.f};
-        if (live) {
-            p.x = __expf(z.x - mx);
-            p.y = __expf(z.y - mx);
-            p.z = __expf(z.z - mx);
-            p.w = __expf(z.w - mx);
+        for (int u = 0; u < UN; ++u) {
+            e[u] = e0 + u * RPW + sub;
+            ok[u] = e[u] < E;
+            const int64_t ec = ok[u] ? e[u] : E - 1;
+            d[u] = dst[ec];
+            t[u] = edge_type[ec];
         }
-        float sm = p.x + p.y + p.z + p.w;
+        f32x4 z[UN];
 #pragma unroll
-        for (int o = 1; o < LPR; o <<= 1) sm += __shfl_xor(sm, o);
-        const float inv = 1.0f / sm;
-        if (ok && live) __builtin_nontemporal_store(p * inv, reinterpret_cast<f32x4*>(gate + e * F + c));
+        for (int u = 0; u < UN; ++u) {
+            z[u] = f32x4{-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+            if (live) z[u] = *reinterpret_cast<const f32x4*>(z_atom + (int64_t)d[u] * F + c) +
+                             *reinterpret_cast<const f32x4*>(q + (int64_t)t[u] * F + c);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            float mx = fmaxf(fmaxf(z[u].x, z[u].y), fmaxf(z[u].z, z[u].w));
+#pragma unroll
+            for (int o = 1; o < LPR; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            f32x4 p = {0.f, 0.f, 0.f, 0.f};
+            if (live) {
+                p.x = __expf(z[u].x - mx);
+                p.y = __expf(z[u].y - mx);
+                p.z = __expf(z[u].z - mx);
+                p.w = __expf(z[u].w - mx);
+            }
+            float sm = p.x + p.y + p.z + p.w;
+#pragma unroll
+            for (int o = 1; o < LPR; o <<= 1) sm += __shfl_xor(sm, o);
+            const float inv = 1.0f / sm;
+            if (ok[u] && live) __builtin_nontemporal_store(p * inv, reinterpret_cast<f32x4*>(gate + e[u] * F + c));
+        }
     }
 }
 
@@ -77,32 +94,43 @@ __global__ void __launch_bounds__(256) att_gate_bwd_kernel(const float* __restri
 #pragma unroll
         for (int o = LPR; o < 64; o <<= 1) n = max(n, __shfl_xor(n, o));   // longest row of the wave pass
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int j = 0; j < n; ++j) {
-            const bool has = beg + j < end;
-            const int64_t e = has ? beg + j : (beg < end ? beg : 0);
-            f32x4 g = {0.f, 0.f, 0.f, 0.f}, dg = {0.f, 0.f, 0.f, 0.f};
-            if (live && has) {
-                g = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gate + e * F + c));
-                dg = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dgate + e * F + c));
+        // two edges of the row per step, all four loads requested before the first is used (the adds stay in edge order)
+        for (int j = 0; j < n; j += 2) {
+            bool has[2];
+            int64_t e[2];
+            f32x4 g[2], dg[2];
+            int t[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                has[u] = beg + j + u < end;
+                e[u] = has[u] ? beg + j + u : (beg < end ? beg : 0);
+                g[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dg[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (live && has[u]) {
+                    g[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gate + e[u] * F + c));
+                    dg[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dgate + e[u] * F + c));
+                }
+                t[u] = (live && has[u]) ? edge_type[e[u]] : -1;
             }
-            float dot = g.x * dg.x + g.y * dg.y + g.z * dg.z + g.w * dg.w;
 #pragma unroll
-            for (int o = 1; o < LPR; o <<= 1) dot += __shfl_xor(dot, o);
-            const f32x4 dz = g * (dg - dot);
-            acc += dz;
-            if (KREG > 0) {
-                const int t = (live && has) ? edge_type[e] : -1;
+            for (int u = 0; u < 2; ++u) {
+                float dot = g[u].x * dg[u].x + g[u].y * dg[u].y + g[u].z * dg[u].z + g[u].w * dg[u].w;
 #pragma unroll
-                for (int k = 0; k < KREG; ++k)
-                    if (t == k) qacc[k] += dz;
-            } else if (live && has) {
-                const int t = edge_type[e];
-                if (t < k_lds) {                           // LDS float adds (ds_add_f32), flushed once per block
-                    float* p = part + t * F + c;
-                    atomicAdd(p, dz.x); atomicAdd(p + 1, dz.y); atomicAdd(p + 2, dz.z); atomicAdd(p + 3, dz.w);
-                } else {
-                    float* p = dq + (int64_t)t * F + c;
-                    atomicAdd(p, dz.x); atomicAdd(p + 1, dz.y); atomicAdd(p + 2, dz.z); atomicAdd(p + 3, dz.w);
+                for (int o = 1; o < LPR; o <<= 1) dot += __shfl_xor(dot, o);
+                const f32x4 dz = g[u] * (dg[u] - dot);
+                acc += dz;
+                if (KREG > 0) {
+#pragma unroll
+                    for (int k = 0; k < KREG; ++k)
+                        if (t[u] == k) qacc[k] += dz;
+                } else if (t[u] >= 0) {
+                    if (t[u] < k_lds) {                    // LDS float adds (ds_add_f32), flushed once per block
+                        float* p = part + t[u] * F + c;
+                        atomicAdd(p, dz.x); atomicAdd(p + 1, dz.y); atomicAdd(p + 2, dz.z); atomicAdd(p + 3, dz.w);
+                    } else {
+                        float* p = dq + (int64_t)t[u] * F + c;
+                        atomicAdd(p, dz.x); atomicAdd(p + 1, dz.y); atomicAdd(p + 2, dz.z); atomicAdd(p + 3, dz.w);
+                    }
                 }
             }
         }

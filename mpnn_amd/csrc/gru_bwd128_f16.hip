@@ -78,17 +78,6 @@ __device__ __forceinline__ void g_copy_to_lds(const char* src, const char* lds_d
                  : "memory");
 }
 
-// the same for one dword per lane: lane L's 4 bytes at `src` land at lds_dst + 4 L
-__device__ __forceinline__ void g_copy_dword_to_lds(const float* src, const float* lds_dst) {
-    typedef __attribute__((address_space(3))) const float lds_float;
-    const unsigned dst = (unsigned)(uintptr_t)(lds_float*)lds_dst;
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(src), "s"(dst)
-                 : "memory");
-}
-
 __device__ __forceinline__ h16x8 g_tr8(const char* a0, const char* a1) {
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
@@ -308,7 +297,6 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_deep_f16_kernel(const char* __
     constexpr int BUF = 4 * IMGC;              // 32 KB
     extern __shared__ __attribute__((aligned(16))) char smem[];          // three chunk images
     __shared__ double stat_s[NORM ? 8 : 1][2][128];            // NORM: per wave, column sums of dh | dh * hn
-    __shared__ float rs_s[8][64];                              // per wave: 1 / (gate-gradient scale) of its tile's rows
 
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
     const int slice = jb % NS;
@@ -378,11 +366,6 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_deep_f16_kernel(const char* __
     int64_t tile_next = nrounds > 1 ? (int64_t)(pblock + pblocks) * 8 + wv : tile;
     if (tile_next >= tiles) tile_next = tiles - 1;
     int ct = 0;
-    // the rows' inverse scales travel global -> LDS like every other load of the loop (no register across the K loop, no
-    // load the compiler would wait for): requested when a round begins, read in its epilogue sixteen or more chunks later
-#ifndef MPNN_ABL_DX_NOSCALE
-    g_copy_dword_to_lds(inv_scale + tile * 32 + r, rs_s[wv]);
-#endif
 
     auto epilogue = [&](auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
@@ -396,9 +379,11 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_deep_f16_kernel(const char* __
         float* dmb = dm + tile * 32 * H + lo;
         const float* hnb = NORM ? hn + tile * 32 * H + lo : nullptr;
         const int64_t row0 = tile * 32 + 4 * hi;
-        // rs_s[wv][row]: 1 / (scale of the tile's row).  Accumulator entry i of a lane is row 8 (i >> 2) + 4 hi + (i & 3):
-        // four consecutive rows per i >> 2, one 16-byte LDS read each (per pass: nothing is kept across passes)
-        const float* rsp = rs_s[wv] + ((ln >> 5) << 2);
+        // inv_scale[row]: 1 / (scale of the row's gate gradients).  Accumulator entry i of a lane is row
+        // 8 (i >> 2) + 4 hi + (i & 3): four consecutive rows per i >> 2, one 16-byte load each, requested with the pass's
+        // other loads (per pass: nothing is kept across passes, and nothing across the K loop -- a staging of these 128
+        // bytes in LDS at the start of a round put an s_waitcnt vmcnt(1) of the compiler's into the K loop, +15 %)
+        const float* rsp = inv_scale + tile * 32 + ((ln >> 5) << 2);
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
             const int nb0 = NBP == 2 ? 2 * ps : ps / PPB, i0 = NBP == 2 ? 0 : RPP * (ps % PPB);
@@ -422,6 +407,21 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_deep_f16_kernel(const char* __
                     if (NORM) hv[b][q] = hnb[ro];
                 }
             __builtin_amdgcn_sched_barrier(0);
+            if (!FULL) {
+                // Ragged tile: some of these values are used under `row < V` only.  A load that is not consumed on every
+                // path stays "pending" in the compiler's wait-count bookkeeping when the chunk loop is re-entered, and it
+                // then protects the register with an s_waitcnt vmcnt(1) INSIDE the K loop -- which also waits for the loop's
+                // own two-chunks-ahead requests (+15 % on the whole kernel).  Consume them all here.
+#pragma unroll
+                for (int g4 = 0; g4 < RPP / 4; ++g4) asm volatile("" ::"v"(un4[g4]));
+#pragma unroll
+                for (int b = 0; b < NBP; ++b)
+#pragma unroll
+                    for (int q = 0; q < RPP; ++q) {
+                        asm volatile("" ::"v"(prev[b][q]));
+                        if (NORM) asm volatile("" ::"v"(hv[b][q]));
+                    }
+            }
 #pragma unroll
             for (int b = 0; b < NBP; ++b) {
                 const int nb = nb0 + b;
@@ -455,11 +455,6 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_deep_f16_kernel(const char* __
 
     // One chunk.  X = row set of this chunk, Z = of the next one (in flight since the previous body), Y = the set that is
     // free (last chunk's) and receives chunk + 2; BI = ring buffer of this chunk's weight image.
-#ifdef MPNN_ABL_DX_NOSCALE
-#define DX_RS_COPY() ((void)0)
-#else
-#define DX_RS_COPY() g_copy_dword_to_lds(inv_scale + tile * 32 + r, rs_s[wv])
-#endif
 #define DX_BODY(X0, X1, X2, X3, Y0, Y1, Y2, Y3, Z0, Z1, Z2, Z3, BI)                                                       \
     {                                                                                                                     \
         if (ct == 0) {                                                                                                    \
@@ -495,7 +490,6 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_deep_f16_kernel(const char* __
             live_tile = (int64_t)(pblock + rd * pblocks) * 8 + wv < tiles;                                                \
             tile_next = rd + 1 < nrounds ? (int64_t)(pblock + (rd + 1) * pblocks) * 8 + wv : tile;                        \
             if (tile_next >= tiles) tile_next = tiles - 1;                                                                \
-            DX_RS_COPY();                                                                                                 \
             ct = 0;                                                                                                       \
         } else {                                                                                                          \
             ++ct;                                                                                                         \
@@ -525,7 +519,6 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_deep_f16_kernel(const char* __
         DX_BODY(c0, c1, c2, c3, b0, b1, b2, b3, a0, a1, a2, a3, 2)
     }
 #undef DX_BODY
-#undef DX_RS_COPY
 #undef DX_ROWS
 #undef DX_WAIT
 #undef DX_LANDED
