@@ -174,6 +174,8 @@ __global__ void __launch_bounds__(512) gru_gate_f16_kernel(const float* __restri
         float sg, inv_sg;
         g_guard_scale<90>(mx, sg, inv_sg);
         if (c16 == 0) inv_scale[t * 32 + srow] = inv_sg;
+        // (the row scale lives in a vector register where the tile scale was wave-uniform: 130-134 registers instead of 126
+        // at H = 128, three waves per SIMD instead of four, ~5 % on this HBM-bound kernel; forcing four spills 12-48 bytes)
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
             // kstep inside the segment = (c16 + 16 j) >> 1; inside its 1 KB block: row srow, 16-byte half c16 & 1
