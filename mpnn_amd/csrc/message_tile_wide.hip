@@ -224,10 +224,21 @@ __global__ void __launch_bounds__(512) message_sum_wide_kernel(
         mw_barrier();                                     // every wave is done with the previous tile's index data
         // ---- the tile's index data: slot rows (64 bytes each), sorted-atom list, (block, type) offsets
         {
+            // every load goes out before the first LDS store: as load -> store pairs (a loop over the slot rows, then the
+            // two lists) the compiler waited for each load in turn, four memory round trips per tile with all waves idle
             const int4* sp = reinterpret_cast<const int4*>(slots + (int64_t)row0 * 32);
-            for (int i = tid; i < nrows * 4; i += 512) reinterpret_cast<int4*>(SL)[i] = sp[i];
-            if (tid < MW_TV) AT[tid] = tile_atom[(int64_t)t * MW_TV + tid];
-            if (tid < MW_NB * K + 1) OFF[tid] = blk_off[(int64_t)t * (MW_NB * K + 1) + tid];
+            const int nq = nrows * 4;                      // 16-byte quads of slot words: at most 1024 (256 slot rows)
+            int4 q0 = {0, 0, 0, 0}, q1 = {0, 0, 0, 0};
+            int at_v = 0, off_v = 0;
+            if (tid < nq) q0 = sp[tid];
+            if (tid + 512 < nq) q1 = sp[tid + 512];
+            if (tid < MW_TV) at_v = tile_atom[(int64_t)t * MW_TV + tid];
+            if (tid < MW_NB * K + 1) off_v = blk_off[(int64_t)t * (MW_NB * K + 1) + tid];
+            __builtin_amdgcn_sched_barrier(0);
+            if (tid < nq) reinterpret_cast<int4*>(SL)[tid] = q0;
+            if (tid + 512 < nq) reinterpret_cast<int4*>(SL)[tid + 512] = q1;
+            if (tid < MW_TV) AT[tid] = at_v;
+            if (tid < MW_NB * K + 1) OFF[tid] = off_v;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         mw_barrier();
