@@ -26,7 +26,10 @@ const Switches& switches() {
 }
 }  // namespace mpnn
 
-extern "C" int mpnn_version(void) { return 300; /* 0.3.0: mpnn_gru_update_f32 takes a workspace, mpnn_message_aggregate_wide_f32 added, mpnn_message_aggregate_bwd_da_f32 removed */ }
+// 0.3.0: mpnn_gru_update_f32 takes a workspace, mpnn_message_aggregate_wide_f32 added, mpnn_message_aggregate_bwd_da_f32
+//        removed.  0.3.1: mpnn_gru_update_norm_f32 / _norm_bwd_f32 / _norm_supported, mpnn_norm_fold_f32,
+//        mpnn_norm_bwd_consts_f32, mpnn_norm_bwd_sums_f32 added; the H = 128 / 256 backward workspace holds one scale per atom.
+extern "C" int mpnn_version(void) { return 301; }
 
 extern "C" int mpnn_init(void) {
     (void)mpnn::switches();
