@@ -185,6 +185,19 @@ int mpnn_message_aggregate_wide_f32(const float* h, const float* A, const int32_
                                     const int32_t* blk_off, const int16_t* slots, float* out, void* workspace,
                                     size_t workspace_bytes, int64_t V, int64_t num_tiles, int K, int nf, int mf,
                                     void* stream);
+/*
+ * The same with the feature gate of AttEdgeNetwork applied inside the kernel (replaces: att_edge_network.py:18-31
+ * composed with adjacent_message_agg.py:18): out[i] = sum_e A[type e] . (gate[e] * h[src e]) with
+ * gate[e, :] = softmax_f(z_atom[dst e, :] + q[type e, :]).  The gate depends on the destination atom and the bond type
+ * only, so the kernel forms it per (atom, type) from two softmax statistics (a small pre-pass into the workspace) and
+ * multiplies the typed neighbour sums by it; no (E, nf) gate tensor exists.  z_atom [V,nf], q [K,nf].
+ * nf = mf = 128, K <= 4; workspace: mpnn_message_aggregate_wide_gated_workspace_bytes(K, nf, num_tiles).
+ */
+size_t mpnn_message_aggregate_wide_gated_workspace_bytes(int K, int nf, int64_t num_tiles);
+int mpnn_message_aggregate_wide_gated_f32(const float* h, const float* A, const float* z_atom, const float* q,
+                                          const int32_t* tile_rec, const int32_t* tile_atom, const int32_t* blk_off,
+                                          const int16_t* slots, float* out, void* workspace, size_t workspace_bytes,
+                                          int64_t V, int64_t num_tiles, int K, int nf, int mf, void* stream);
 
 /*
  * BiLiniearEdgeNetwork message on the dense padded batch: out[b,i,j,k] = sum_{a,c} afm[b,j,a] T[b,i,j][a,k,c] afm[b,i,c]

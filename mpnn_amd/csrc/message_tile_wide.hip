@@ -122,13 +122,89 @@ __global__ void __launch_bounds__(256) mw_split_kernel(const float* __restrict__
     *reinterpret_cast<h16x8*>(dst + F * 64) = pl;
 }
 
+// ---- the feature gate of AttEdgeNetwork inside the fused kernel (att_edge_network.py:18-21) ----
+// gate[e, :] = softmax_f(z_atom[dst e, :] + q[type e, :]) depends on the DESTINATION atom and the bond type only, so it
+// factorises like the message itself:  out[i] = sum_k A_k (g_ik * S_k[i]),  g_ik = softmax_f(z_atom[i] + q[k]).  The
+// kernel multiplies its S_k fragment by g_ik before the split; what it needs per (atom, type) are the two softmax
+// statistics, written here in the plan's sorted tile order: stats[(tile * 256 + position) * K + k] =
+// (log2(e) * max_f(z + q), 1 / sum_f exp(z + q - max)).  A tile per block pass, 32 lanes per atom (F = 128).
+constexpr float MW_LOG2E = 1.4426950408889634f;
+// Eight lanes per atom, sixteen logits per lane (a 64-byte piece of the row), the K <= 4 types reduced side by side (four
+// independent shuffle chains): 32 lanes x one type at a time was a chain of ten dependent cross-lane steps per (atom, type)
+// and took 0.85 ms at c3's size against 0.3 ms of bytes.
+__global__ void __launch_bounds__(512) mw_gate_stats_kernel(const float* __restrict__ z_atom, const float* __restrict__ q,
+                                                            const int32_t* __restrict__ tile_rec,
+                                                            const int32_t* __restrict__ tile_atom, float2* __restrict__ stats,
+                                                            int num_tiles, int K) {
+    constexpr int F = 128, KM = 4;
+    __shared__ float qs[KM * F];
+    for (int i = threadIdx.x; i < KM * F; i += 512) qs[i] = i < K * F ? q[i] : 0.f;
+    __syncthreads();
+    const int grp = threadIdx.x >> 3, l = threadIdx.x & 7;          // 64 atom groups of 8 lanes; lane l: columns 16 l ...
+    for (int t = blockIdx.x; t < num_tiles; t += gridDim.x) {
+        const int n = tile_rec[4 * t + 1];
+        for (int p0 = 0; p0 < n; p0 += 64) {
+            const int p = p0 + grp;
+            const bool ok = p < n;
+            const int atom = ok ? tile_atom[(int64_t)t * MW_TV + p] : 0;
+            const float* zr = z_atom + (int64_t)(atom < 0 ? 0 : atom) * F + 16 * l;
+            f32x4 zv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) zv[j] = *reinterpret_cast<const f32x4*>(zr + 4 * j);
+            float m[KM], e[KM];
+#pragma unroll
+            for (int k = 0; k < KM; ++k) {
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 v = zv[j] + *reinterpret_cast<const f32x4*>(qs + k * F + 16 * l + 4 * j);
+                    mx = fmaxf(mx, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+                }
+                m[k] = mx;
+            }
+#pragma unroll
+            for (int o = 4; o >= 1; o >>= 1)
+#pragma unroll
+                for (int k = 0; k < KM; ++k) m[k] = fmaxf(m[k], __shfl_xor(m[k], o));
+#pragma unroll
+            for (int k = 0; k < KM; ++k) {
+                float sm = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 v = zv[j] + *reinterpret_cast<const f32x4*>(qs + k * F + 16 * l + 4 * j);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) sm += __builtin_amdgcn_exp2f((v[u] - m[k]) * MW_LOG2E);
+                }
+                e[k] = sm;
+            }
+#pragma unroll
+            for (int o = 4; o >= 1; o >>= 1)
+#pragma unroll
+                for (int k = 0; k < KM; ++k) e[k] += __shfl_xor(e[k], o);
+            if (ok && l < K) {
+                const float mk = l == 0 ? m[0] : l == 1 ? m[1] : l == 2 ? m[2] : m[3];
+                const float ek = l == 0 ? e[0] : l == 1 ? e[1] : l == 2 ? e[2] : e[3];
+                stats[((int64_t)t * MW_TV + p) * K + l] = float2{mk * MW_LOG2E, 1.0f / ek};
+            }
+        }
+    }
+}
+
+struct MwGate {
+    const float* z_atom;   // (V, F) atom part of the gate logits
+    const float* q;        // (K, F) bond part
+    const float2* stats;   // from mw_gate_stats_kernel
+};
+
 // ------------------------------------------------------------------------------------------------------ the kernel
-template <int F>
+template <int F, bool GATED = false>
 __global__ void __launch_bounds__(512) message_sum_wide_kernel(
     const float* __restrict__ h, const char* __restrict__ ws, const int32_t* __restrict__ tile_rec,
     const int32_t* __restrict__ tile_atom, const int32_t* __restrict__ blk_off, const int16_t* __restrict__ slots,
-    float* __restrict__ out, int num_tiles, int K, int dbg) {
+    float* __restrict__ out, int num_tiles, int K, int dbg, MwGate gt) {
+    static_assert(!GATED || F == 128, "the gated form exists at width 128");
     constexpr int NKC = F / 32, CT = F / 32, ABUF = F * 128;
+    __shared__ float qs_s[GATED ? 4 * F : 1];              // GATED: log2(e) * q, at most four bond types
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const HB = smem;                               // two h chunk images
     char* const AB = smem + 2 * MW_HB;                   // two matrix chunk images
@@ -142,6 +218,8 @@ __global__ void __launch_bounds__(512) message_sum_wide_kernel(
     const float a_inv = reinterpret_cast<const float*>(ws)[1];
     const char* const wsA = ws + 64;
     const int nphase = NKC * K;
+    if (GATED)
+        for (int i = tid; i < K * F; i += 512) qs_s[i] = gt.q[i] * MW_LOG2E;   // (published by the first tile's barriers)
 
     // the zero rows of the two h images: slot word MW_TV reads them
     if (tid < 16) {
@@ -251,6 +329,41 @@ __global__ void __launch_bounds__(512) message_sum_wide_kernel(
         const unsigned long long pairs = __builtin_amdgcn_ballot_w64(lane < MW_NB * K && OFF[lane < MW_NB * K ? lane + 1 : 1] >
                                                                                        OFF[lane < MW_NB * K ? lane : 0]);
 
+        // GATED: this lane's atom (block wv, row r): its logits row, its softmax statistics per bond type, and the chunk of
+        // logits the current phases multiply with (`zc`) plus the next chunk's (`zn`, requested a chunk ahead)
+        const float* zp = nullptr;
+        float sm0 = 0.f, sm1 = 0.f, sm2 = 0.f, sm3 = 0.f, si0 = 0.f, si1 = 0.f, si2 = 0.f, si3 = 0.f;
+        // (named registers: as arrays handed to lambdas they lived in scratch)
+        f32x4 zc00, zc01, zc10, zc11, zn00, zn01, zn10, zn11;
+#define MW_ZLOAD(KC)                                                                  \
+    zn00 = *reinterpret_cast<const f32x4*>(zp + 32 * (KC));                           \
+    zn01 = *reinterpret_cast<const f32x4*>(zp + 32 * (KC) + 4);                       \
+    zn10 = *reinterpret_cast<const f32x4*>(zp + 32 * (KC) + 16);                      \
+    zn11 = *reinterpret_cast<const f32x4*>(zp + 32 * (KC) + 20)
+        if (GATED) {
+            const int at = AT[32 * wv + r];
+            zp = gt.z_atom + (int64_t)(at < 0 ? 0 : at) * F + 8 * hi;
+            const float2* sp2 = gt.stats + ((int64_t)t * MW_TV + 32 * wv + r) * K;
+            const float2 a = sp2[0], b = sp2[K > 1 ? 1 : 0], c2 = sp2[K > 2 ? 2 : 0], d = sp2[K > 3 ? 3 : 0];
+            sm0 = a.x; si0 = a.y; sm1 = b.x; si1 = b.y; sm2 = c2.x; si2 = c2.y; sm3 = d.x; si3 = d.y;
+            MW_ZLOAD(0);
+        }
+        // s *= softmax_f(z + q_k) on the chunk's columns of this lane: exp2(z L + (q_k L - max L)) / sum
+        auto apply_gate = [&](int kc, int k, f32x4 (&s)[2][2]) {
+            const float m = k == 0 ? sm0 : k == 1 ? sm1 : k == 2 ? sm2 : sm3;
+            const float iv = k == 0 ? si0 : k == 1 ? si1 : k == 2 ? si2 : si3;
+            const float* qp = qs_s + k * F + 32 * kc + 8 * hi;
+            auto one = [&](f32x4& sv, const f32x4& zv, const float* qq) {
+                const f32x4 qv = *reinterpret_cast<const f32x4*>(qq);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sv[j] *= __builtin_amdgcn_exp2f(fmaf(zv[j], MW_LOG2E, qv[j] - m)) * iv;
+            };
+            one(s[0][0], zc00, qp);
+            one(s[0][1], zc01, qp + 4);
+            one(s[1][0], zc10, qp + 16);
+            one(s[1][1], zc11, qp + 20);
+        };
+
         f32x16 acc[CT];
 #pragma unroll
         for (int c = 0; c < CT; ++c)
@@ -320,12 +433,17 @@ __global__ void __launch_bounds__(512) message_sum_wide_kernel(
                     else if (more) copy_h(a0n, nn, 0, 0, rank, share);
                 }
             }
+            if (GATED && k == 0 && amask != 0) {          // a new chunk: its logits arrived during the last one
+                zc00 = zn00; zc01 = zn01; zc10 = zn10; zc11 = zn11;
+                if (kc + 1 < NKC) { MW_ZLOAD(kc + 1); }
+            }
             if ((amask >> k) & 1) {
                 const char* hb = HB + (kc & 1) * MW_HB;
                 const char* ab = AB + (ph & 1) * ABUF;
                 if (!have) {
                     const int b0 = __builtin_amdgcn_readfirstlane(OFF[wv * K + k]);
                     gather(hb, b0, __builtin_amdgcn_readfirstlane(OFF[wv * K + k + 1]) - b0, s);
+                    if (GATED) apply_gate(kc, k, s);
                 }
                 MW_T(s2);
                 h16x8 ah[2], al[2];
@@ -338,6 +456,7 @@ __global__ void __launch_bounds__(512) message_sum_wide_kernel(
                     const int kn = k + 1 + __builtin_ctz(rest);
                     const int bn = __builtin_amdgcn_readfirstlane(OFF[wv * K + kn]);
                     gather(hb, bn, __builtin_amdgcn_readfirstlane(OFF[wv * K + kn + 1]) - bn, s);
+                    if (GATED) apply_gate(kc, kn, s);
                 }
                 if (!(dbg & 2)) {
 #pragma unroll
@@ -398,6 +517,8 @@ __global__ void __launch_bounds__(512) message_sum_wide_kernel(
         n = nn;
     }
 }
+
+#undef MW_ZLOAD
 
 // ------------------------------------------------------------------------------------------ width 64: resident matrices
 // At nf = mf = 64 the K <= 4 matrices fit in LDS as fp16 piece pairs (16 KB per type) next to a whole 256-atom tile of h
@@ -634,14 +755,20 @@ static int launch_message_res64(const float* h, const float* A, const int32_t* t
 }
 
 size_t message_wide_workspace_bytes(int K, int F) { return 64 + (size_t)K * F * F * 4; }
+size_t message_wide_gated_workspace_bytes(int K, int F, int64_t num_tiles) {
+    return message_wide_workspace_bytes(K, F) + (size_t)num_tiles * MW_TV * K * sizeof(float2);
+}
 
 template <int F>
 static int launch_message_wide_t(const float* h, const float* A, const int32_t* tile_rec, const int32_t* tile_atom,
                                  const int32_t* blk_off, const int16_t* slots, float* out, void* workspace,
-                                 int64_t num_tiles, int K, hipStream_t s) {
+                                 int64_t num_tiles, int K, hipStream_t s, const float* z_atom = nullptr,
+                                 const float* q = nullptr) {
     static const hipError_t attr = [] {
         LdsOptIn opt_in_;
         opt_in_((const void*)message_sum_wide_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize, mw_lds_bytes<F>());
+        if (F == 128)
+            opt_in_((const void*)message_sum_wide_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mw_lds_bytes<128>());
         return opt_in_.err;
     }();
     if (attr != hipSuccess) return lds_opt_in_failed(attr);
@@ -652,8 +779,19 @@ static int launch_message_wide_t(const float* h, const float* A, const int32_t* 
     int64_t blocks = 256;                                 // one block per CU
     if (blocks > num_tiles) blocks = num_tiles;
     const int dbg = 0;                                    // (bits 2 / 4 / 8 switch off the products / the copies / all work: timing ablations)
+    if (z_atom) {
+        if constexpr (F == 128) {
+            float2* stats = reinterpret_cast<float2*>(ws + message_wide_workspace_bytes(K, F));
+            hipLaunchKernelGGL(mw_gate_stats_kernel, dim3((unsigned)(num_tiles < 2048 ? num_tiles : 2048)), dim3(512), 0, s,
+                               z_atom, q, tile_rec, tile_atom, stats, (int)num_tiles, K);
+            hipLaunchKernelGGL((message_sum_wide_kernel<128, true>), dim3((unsigned)blocks), dim3(512), mw_lds_bytes<128>(), s, h,
+                               ws, tile_rec, tile_atom, blk_off, slots, out, (int)num_tiles, K, dbg, MwGate{z_atom, q, stats});
+            return launch_status("mpnn_message_aggregate_wide_gated_f32");
+        }
+        return 1;
+    }
     hipLaunchKernelGGL(message_sum_wide_kernel<F>, dim3((unsigned)blocks), dim3(512), mw_lds_bytes<F>(), s, h, ws, tile_rec,
-                       tile_atom, blk_off, slots, out, (int)num_tiles, K, dbg);
+                       tile_atom, blk_off, slots, out, (int)num_tiles, K, dbg, MwGate{nullptr, nullptr, nullptr});
     return launch_status("mpnn_message_aggregate_wide_f32");
 }
 
@@ -697,4 +835,26 @@ extern "C" int mpnn_message_aggregate_wide_f32(const float* h, const float* A, c
     if (nf == 64) return launch_message_res64(h, A, tile_rec, tile_atom, blk_off, slots, out, workspace, num_tiles, K, s);
     if (nf == 128) return launch_message_wide_t<128>(h, A, tile_rec, tile_atom, blk_off, slots, out, workspace, num_tiles, K, s);
     return launch_message_wide_t<256>(h, A, tile_rec, tile_atom, blk_off, slots, out, workspace, num_tiles, K, s);
+}
+
+extern "C" size_t mpnn_message_aggregate_wide_gated_workspace_bytes(int K, int nf, int64_t num_tiles) {
+    return message_wide_gated_workspace_bytes(K, nf, num_tiles);
+}
+
+extern "C" int mpnn_message_aggregate_wide_gated_f32(const float* h, const float* A, const float* z_atom, const float* q,
+                                                     const int32_t* tile_rec, const int32_t* tile_atom,
+                                                     const int32_t* blk_off, const int16_t* slots, float* out,
+                                                     void* workspace, size_t workspace_bytes, int64_t V, int64_t num_tiles,
+                                                     int K, int nf, int mf, void* stream) {
+    MPNN_REQUIRE(nf == mf && nf == 128, "mpnn_message_aggregate_wide_gated_f32: nf = mf = 128 only (got %d, %d)", nf, mf);
+    MPNN_REQUIRE(K >= 1 && K <= 4, "mpnn_message_aggregate_wide_gated_f32: 1 <= K <= 4 bond types (got %d)", K);
+    MPNN_REQUIRE(V >= 0 && num_tiles >= 0 && num_tiles < (1ll << 24), "mpnn_message_aggregate_wide_gated_f32: bad sizes");
+    if (V == 0 || num_tiles == 0) return MPNN_OK;
+    MPNN_REQUIRE(h && A && z_atom && q && tile_rec && tile_atom && blk_off && slots && out && workspace,
+                 "mpnn_message_aggregate_wide_gated_f32: NULL buffer");
+    MPNN_REQUIRE(workspace_bytes >= message_wide_gated_workspace_bytes(K, nf, num_tiles),
+                 "mpnn_message_aggregate_wide_gated_f32: workspace of %zu bytes, need %zu", workspace_bytes,
+                 message_wide_gated_workspace_bytes(K, nf, num_tiles));
+    return launch_message_wide_t<128>(h, A, tile_rec, tile_atom, blk_off, slots, out, workspace, num_tiles, K,
+                                      (hipStream_t)stream, z_atom, q);
 }

@@ -32,6 +32,8 @@ class EdgeMessages:
     def values(self):
         if self._values is None:
             A, gate = self.recipe
+            if isinstance(gate, ops.LazyAttGate):
+                gate = gate.materialise()
             self._values = ops.edge_message(self.h, A, self.graph, gate=gate)
         return self._values
 

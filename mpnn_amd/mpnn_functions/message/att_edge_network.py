@@ -34,7 +34,8 @@ class AttEdgeNetwork(EdgeNetwork):
             # default activation: one streaming kernel gathers both parts of the logits and applies the softmax
             # over the feature axis (mpnn_att_gate_f32); the bond part is a (K, nf) table, one row per distinct
             # bond-feature row
-            gate = ops.att_gate(z_atom, g.type_feat @ W_e.t(), g)
+            # -- lazily: followed by the sum aggregator at hidden 128 the gate is never written out (ops.LazyAttGate)
+            gate = ops.LazyAttGate(z_atom, g.type_feat @ W_e.t(), g)
         else:
             # any other activation: the atom part is broadcast along CSR rows (backward = the aggregator kernel),
             # the bond part is a thin GEMM on the edge features (backward = a GEMM) -- no index_put backward

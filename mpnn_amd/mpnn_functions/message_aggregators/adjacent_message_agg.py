@@ -21,6 +21,8 @@ class AdjMsgAgg(nn.Module):
             w = adjacency_multiplier(messages, adj)
             if messages._values is None:          # lazy messages: message + sum as one autograd node
                 A, gate = messages.recipe
+                if isinstance(gate, ops.LazyAttGate):     # AttEdgeNetwork: the gate is formed inside the fused kernel where it can
+                    return g.node_unview(ops.gated_message_aggregate(messages.h, A, gate, g, w))
                 return g.node_unview(ops.message_aggregate(messages.h, A, g, w, gate))
             return g.node_unview(ops.segsum(messages.values, g.row_ptr, w))
         rows, row_ptr, (B, N) = dense_rows(messages, adj)

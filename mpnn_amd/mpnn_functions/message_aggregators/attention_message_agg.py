@@ -30,6 +30,8 @@ class AttMsgAgg(nn.Module):
                 # Linear is identically 0), so the member pairs are a plain sum -- message + sum as ONE autograd node,
                 # exactly as AdjMsgAgg does -- and every non-member pair of the padded row joins with weight 1
                 A, gate = messages.recipe
+                if isinstance(gate, ops.LazyAttGate):
+                    gate = gate.materialise()
                 out = ops.message_aggregate(messages.h, A, g, None, gate) + messages.nonedge_sum()
                 return g.node_unview(out)
             w = self.att(edge_adjacency(messages, adj).unsqueeze(-1)).squeeze(-1).contiguous()

@@ -194,6 +194,30 @@ def message_aggregate_wide_raw(h, A, graph):
     return out
 
 
+def wide_gated_applies(A, w, graph):
+    """The fused message+sum kernel with AttEdgeNetwork's feature gate formed inside it (mpnn_message_aggregate_wide_gated_f32):
+    nf = mf = 128, at most four bond types, otherwise as wide_kernel_applies."""
+    K, mf, nf = (int(s) for s in A.shape)
+    return nf == 128 and K <= 4 and wide_kernel_applies(A, None, w, graph)
+
+
+def message_aggregate_wide_gated_raw(h, A, z_atom, q, graph):
+    lib = _lib.load()
+    K, mf, nf = (int(s) for s in A.shape)
+    V = graph.num_nodes
+    plan = graph.wide_plan
+    if V == 0 or graph.num_edges == 0:
+        return torch.zeros(V, mf, dtype=torch.float32, device=h.device)
+    out = _empty((V, mf), h)
+    ws_bytes = lib.mpnn_message_aggregate_wide_gated_workspace_bytes(K, nf, plan.num_tiles)
+    ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=h.device)
+    _lib.check(_timed("message_aggregate", lambda: lib.mpnn_message_aggregate_wide_gated_f32(
+        _lib.fptr(h), _lib.fptr(A), _lib.fptr(z_atom), _lib.fptr(q), _lib.iptr(plan.tile_rec), _lib.iptr(plan.tile_atom),
+        _lib.iptr(plan.blk_off), _lib.ptr(plan.slots, torch.int16), _lib.fptr(out), _lib.ptr(ws), ws_bytes, V,
+        plan.num_tiles, K, nf, mf, _lib.stream())), "mpnn_message_aggregate_wide_gated_f32")
+    return out
+
+
 def edge_message_bwd_raw(h, A, graph, gate, dmsg, need_dx=True, need_dA=True):
     lib = _lib.load()
     K, mf, nf = (int(s) for s in A.shape)
@@ -915,6 +939,83 @@ class AttGate(torch.autograd.Function):
 
 def att_gate(z_atom, q, graph):
     return AttGate.apply(z_atom, q, graph)
+
+
+class LazyAttGate:
+    """AttEdgeNetwork's feature gate, softmax_f(z_atom[dst e] + q[type e]), not yet evaluated: the sum aggregator forms it
+    inside the fused message + sum kernel where that kernel applies (ops.gated_message_aggregate); every other consumer
+    calls materialise() and gets the (E, F) tensor of ops.att_gate."""
+
+    def __init__(self, z_atom, q, graph):
+        self.z_atom, self.q, self.graph = z_atom, q, graph
+        self._gate = None
+
+    def materialise(self):
+        if self._gate is None:
+            self._gate = att_gate(self.z_atom, self.q, self.graph)
+        return self._gate
+
+
+class GatedMessageAggregate(torch.autograd.Function):
+    """out[i] = sum_{e in row i} A[type e] . (softmax_f(z_atom[i] + q[type e]) * h[src e]): AttEdgeNetwork followed by
+    AdjMsgAgg (att_edge_network.py:18-31, adjacent_message_agg.py:18) as ONE kernel without an (E, F) gate tensor
+    (mpnn_message_aggregate_wide_gated_f32).  Backward: the gate is re-evaluated (mpnn_att_gate_f32), then the kernels of
+    the unfused path -- weight gradient and gate gradient straight from dout[dst e], softmax backward -- run on it."""
+
+    @staticmethod
+    def forward(ctx, h, A, z_atom, q, graph):
+        h, A, z_atom, q = h.contiguous(), A.contiguous(), z_atom.contiguous(), q.contiguous()
+        ctx.graph = graph
+        ctx.save_for_backward(h, A, z_atom, q)
+        return message_aggregate_wide_gated_raw(h, A, z_atom, q, graph)
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        h, A, z_atom, q = ctx.saved_tensors
+        g = ctx.graph
+        K, mf, nf = (int(s) for s in A.shape)
+        V, E = g.num_nodes, g.num_edges
+        dout = dout.contiguous()
+        if ctx.needs_input_grad[0] or E == 0:
+            # gradient for the node features as well (not what the attention models ask for: their message input is the
+            # constant afm): differentiate the unfused composition
+            with torch.enable_grad():
+                leaves = [t.detach().requires_grad_(need) for t, need in zip((h, A, z_atom, q), ctx.needs_input_grad[:4])]
+                out = MessageAggregate.apply(leaves[0], leaves[1], att_gate(leaves[2], leaves[3], g), None, g)
+            want = [t for t in leaves if t.requires_grad]
+            got = iter(torch.autograd.grad(out, want, dout, allow_unused=True)) if want else iter(())
+            return tuple(next(got) if t.requires_grad else None for t in leaves) + (None,)
+        gate = _empty((E, nf), h)
+        _lib.check(lib.mpnn_att_gate_f32(_lib.fptr(z_atom), _lib.fptr(q), _lib.iptr(g.edge_dst), _lib.iptr(g.edge_type),
+                                         _lib.fptr(gate), V, E, K, nf, _lib.stream()), "mpnn_att_gate_f32")
+        dA = None
+        if ctx.needs_input_grad[1]:
+            dA = torch.zeros_like(A)
+            _lib.check(_timed("message_aggregate_bwd", lambda: lib.mpnn_edge_message_agg_bwd_da_f32(
+                _lib.fptr(dout), _lib.fptr(h), _lib.iptr(g.col_idx), _lib.iptr(g.edge_dst), None, _lib.iptr(g.order),
+                _lib.iptr(g.type_ptr), _lib.fptr(gate), _lib.fptr(dA), V, E, K, nf, mf, _lib.stream())),
+                "mpnn_edge_message_agg_bwd_da_f32")
+        dz_atom = dq = None
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            dgate = _empty((E, nf), h)
+            _lib.check(lib.mpnn_edge_message_agg_bwd_dgate_f32(
+                _lib.fptr(dout), _lib.fptr(A), _lib.fptr(h), _lib.iptr(g.col_idx), _lib.iptr(g.edge_dst), None,
+                _lib.iptr(g.order), _lib.iptr(g.type_ptr), _lib.fptr(dgate), V, E, K, nf, mf, _lib.stream()),
+                "mpnn_edge_message_agg_bwd_dgate_f32")
+            dz_atom = _empty((V, nf), h)
+            dq = torch.zeros((K, nf), dtype=torch.float32, device=h.device)
+            _lib.check(lib.mpnn_att_gate_bwd_f32(_lib.fptr(gate), _lib.fptr(dgate), _lib.iptr(g.row_ptr),
+                                                 _lib.iptr(g.edge_type), _lib.fptr(dz_atom), _lib.fptr(dq), V, E, K, nf,
+                                                 _lib.stream()), "mpnn_att_gate_bwd_f32")
+        return None, dA, dz_atom, dq, None
+
+
+def gated_message_aggregate(h, A, lazy_gate, graph, w=None):
+    """AttEdgeNetwork messages summed over neighbours: the fused gated kernel where it applies, else gate + message_aggregate."""
+    if w is None and wide_gated_applies(A, w, graph) and h.is_cuda:
+        return GatedMessageAggregate.apply(h, A, lazy_gate.z_atom, lazy_gate.q, graph)
+    return message_aggregate(h, A, graph, w, lazy_gate.materialise())
 
 
 class TowerChain(torch.autograd.Function):
