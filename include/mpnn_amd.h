@@ -268,8 +268,10 @@ int mpnn_gru_update_f32(const float* m, const float* h, const float* mask,
  * the same affine map into the hidden weights: W_hh_folded[k, :] = h_scale[k] * W_hh[k, :], b_hh_folded = b_hh +
  * h_shift W_hh.  out_moments [2H] doubles, ACCUMULATED (caller zeroes): column sums of `out` and of out^2 over all
  * atoms -- the moments the norm that follows this update needs, so it runs no reduction pass.  With saved != NULL the
- * kernel also writes h_norm [V,H] (= hn, the `h` operand of mpnn_gru_update_bwd_f32).  Widths: those for which
- * mpnn_gru_update_norm_supported(H) returns 1 (128, 256; 0 under MPNN_GRU_MATH=fp32); the workspace is required.
+ * kernel also writes h_norm [V,H] (= hn, the `h` operand of mpnn_gru_update_bwd_f32).  mpnn_gru_update_norm_supported(H):
+ * 2 = the wide split-precision kernels (H = 128 / 256; workspace of mpnn_gru_fwd_workspace_bytes required), 1 = the generic
+ * fp32 kernel (every other H <= 256, and every H under MPNN_GRU_MATH=fp32: the kernel the plain update runs on at those
+ * widths, 32 / 64 / 128 excepted, which have faster un-normed forms; no workspace), 0 = none.
  */
 int mpnn_gru_update_norm_supported(int H);
 int mpnn_gru_update_norm_f32(const float* m, const float* h_raw, const float* mask, const float* W_ih,
@@ -307,8 +309,9 @@ int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const float* h, c
  *   in_norm_sums [2H] doubles, ACCUMULATED (caller zeroes), or NULL.  Non-NULL: h_norm = norm(y_prev); the dm | dh
  *     kernel adds the column sums of dh_norm and of dh_norm * h_norm -- S_b and S_h of THAT norm -- so the update before
  *     this one can be called with their out_norm_k and no norm-backward pass runs at all.
- * Widths and workspace as mpnn_gru_update_norm_f32 / mpnn_gru_bwd_workspace_bytes.
+ * Widths as mpnn_gru_update_norm_f32; workspace: mpnn_gru_norm_bwd_workspace_bytes(V, H).
  */
+size_t mpnn_gru_norm_bwd_workspace_bytes(int64_t V, int H);
 int mpnn_gru_update_norm_bwd_f32(const float* dout, const float* m, const float* h_norm, const float* mask,
                                  const float* W_ih, const float* W_hh, const float* saved, const float* out_norm_k,
                                  float* dm, float* dh_norm, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh,

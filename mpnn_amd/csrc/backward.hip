@@ -515,11 +515,14 @@ __global__ void __launch_bounds__(512) tn_direct_kernel(const float* __restrict_
 // mask is 0/1 (as the reference's create_mask makes it): d sigma / d tanh use the masked gate values.
 // COMPACT: ws[row] = [ dar daz dan dnh ] (4H floats; dgi = first 3 blocks, dgh = blocks 0, 1, 3) for the H = 128
 // kernels of gru_bwd128.hip, which index the blocks themselves.
-template <bool COMPACT>
+// NORM: dout is the gradient of norm(out); the gradient of out = this update's raw output y is formed here as
+// dout * k1[col] + y * k2[col] + k4[col] with y = (1-z) n + z h of the saved gates (gru_bwd128_f16.hip has the algebra).
+template <bool COMPACT, bool NORM = false>
 __global__ void __launch_bounds__(256) gru_gate_grad_kernel(const float* __restrict__ dout, const float* __restrict__ h,
                                                             const float* __restrict__ mask,
                                                             const float* __restrict__ saved, float* __restrict__ ws,
-                                                            float* __restrict__ dh, int64_t V, int H) {
+                                                            float* __restrict__ dh, int64_t V, int H,
+                                                            const float* __restrict__ kn = nullptr) {
     const int64_t total = V * H;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
@@ -528,7 +531,11 @@ __global__ void __launch_bounds__(256) gru_gate_grad_kernel(const float* __restr
         const float mk = mask ? mask[row] : 1.0f;
         const float* sv = saved + row * 4 * H + col;
         const float r = sv[0], z = sv[H], n = sv[2 * H], nh = sv[3 * H];
-        const float g = dout[idx] * mk;                 // through the final "* mask"
+        float g = dout[idx] * mk;                       // through the final "* mask"
+        if (NORM) {
+            const float y = ((1.0f - z) * n + z * h[idx]) * mk;
+            g = (dout[idx] * kn[col] + y * kn[H + col] + kn[2 * H + col]) * mk;
+        }
         const float dn = g * (1.0f - z);
         const float dz = g * (h[idx] - n);
         const float dan = dn * mk * (1.0f - n * n);     // n = tanh(.)*mask
@@ -651,6 +658,44 @@ int launch_gru_bwd_f16_wide(const float* dout, const float* m, const float* h, c
                             double* in_norm_sums, hipStream_t s);
 }  // namespace mpnn
 
+// the generic-width backward after the gate-gradient pass (ws = (V, 6H) pre-activation gradients, dh holds g * z):
+// dm, dh as row GEMMs, dW / db as accumulating contractions over the atoms
+static int gru_bwd_generic_tail(const float* m, const float* h, const float* W_ih, const float* W_hh, float* ws, float* dm,
+                                float* dh, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, int64_t V, int H,
+                                hipStream_t s) {
+    int rc;
+    // dm = dgi . W_ih^T : B given as [n = input feature][k = gate column], ld 3H
+    rc = launch_rows_gemm<true, false>(ws, 6 * H, nullptr, nullptr, 0, W_ih, 0, 3 * H, nullptr, dm, H, V, 3 * H, H, s,
+                                       "mpnn_gru_update_bwd_f32(dm)");
+    if (rc) return rc;
+    // dh = dgh . W_hh^T + dout*mask*z   (the direct term already sits in dh)
+    rc = launch_rows_gemm<true, false>(ws + 3 * H, 6 * H, nullptr, nullptr, 0, W_hh, 0, 3 * H, dh, dh, H, V, 3 * H, H, s,
+                                       "mpnn_gru_update_bwd_f32(dh)");
+    if (rc) return rc;
+    if (H == 128) {
+        // dW (128 x 384) and db on the register-direct wide kernel: 8 waves = 4 a-blocks x 2 groups of 6 b-blocks
+        int64_t gxd = 512;
+        if (gxd > ceil_div(V, 32)) gxd = ceil_div(V, 32);
+        hipLaunchKernelGGL((tn_direct_kernel<4, 6, false>), dim3((unsigned)gxd), dim3(512), 0, s, m, H, ws, 6 * H,
+                           (const int32_t*)nullptr, (const int32_t*)nullptr, 1, (const int32_t*)nullptr,
+                           (const int32_t*)nullptr, (const float*)nullptr, (const float*)nullptr, dW_ih, db_ih, V);
+        hipLaunchKernelGGL((tn_direct_kernel<4, 6, false>), dim3((unsigned)gxd), dim3(512), 0, s, h, H, ws + 3 * H, 6 * H,
+                           (const int32_t*)nullptr, (const int32_t*)nullptr, 1, (const int32_t*)nullptr,
+                           (const int32_t*)nullptr, (const float*)nullptr, (const float*)nullptr, dW_hh, db_hh, V);
+        return launch_status("mpnn_gru_update_bwd_f32(dW direct 128)");
+    }
+    const int pairs = (int)(ceil_div(H, 64) * ceil_div(3 * H, 64));
+    int64_t gx = ceil_div(V, kBT);
+    if (gx > 512) gx = 512;
+    hipLaunchKernelGGL((tn_accumulate_kernel<false>), dim3((unsigned)gx, pairs), dim3(256), 0, s, m, H, H, ws, 6 * H,
+                       3 * H, (const int32_t*)nullptr, (const int32_t*)nullptr, (const float*)nullptr,
+                       (const int32_t*)nullptr, 1, dW_ih, db_ih, V);
+    hipLaunchKernelGGL((tn_accumulate_kernel<false>), dim3((unsigned)gx, pairs), dim3(256), 0, s, h, H, H, ws + 3 * H,
+                       6 * H, 3 * H, (const int32_t*)nullptr, (const int32_t*)nullptr, (const float*)nullptr,
+                       (const int32_t*)nullptr, 1, dW_hh, db_hh, V);
+    return launch_status("mpnn_gru_update_bwd_f32(dW)");
+}
+
 extern "C" size_t mpnn_gru_bwd_workspace_bytes(int64_t V, int H) {
     if (V < 0 || H <= 0) return 0;
     if (H == 64) return 16;                                               // one kernel, gate gradients stay in LDS
@@ -690,36 +735,7 @@ extern "C" int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const 
                        H);
     rc = launch_status("mpnn_gru_update_bwd_f32(gates)");
     if (rc) return rc;
-    // dm = dgi . W_ih^T : B given as [n = input feature][k = gate column], ld 3H
-    rc = launch_rows_gemm<true, false>(ws, 6 * H, nullptr, nullptr, 0, W_ih, 0, 3 * H, nullptr, dm, H, V, 3 * H, H, s,
-                                       "mpnn_gru_update_bwd_f32(dm)");
-    if (rc) return rc;
-    // dh = dgh . W_hh^T + dout*mask*z   (the direct term already sits in dh)
-    rc = launch_rows_gemm<true, false>(ws + 3 * H, 6 * H, nullptr, nullptr, 0, W_hh, 0, 3 * H, dh, dh, H, V, 3 * H, H, s,
-                                       "mpnn_gru_update_bwd_f32(dh)");
-    if (rc) return rc;
-    if (H == 128) {
-        // dW (128 x 384) and db on the register-direct wide kernel: 8 waves = 4 a-blocks x 2 groups of 6 b-blocks
-        int64_t gxd = 512;
-        if (gxd > ceil_div(V, 32)) gxd = ceil_div(V, 32);
-        hipLaunchKernelGGL((tn_direct_kernel<4, 6, false>), dim3((unsigned)gxd), dim3(512), 0, s, m, H, ws, 6 * H,
-                           (const int32_t*)nullptr, (const int32_t*)nullptr, 1, (const int32_t*)nullptr,
-                           (const int32_t*)nullptr, (const float*)nullptr, (const float*)nullptr, dW_ih, db_ih, V);
-        hipLaunchKernelGGL((tn_direct_kernel<4, 6, false>), dim3((unsigned)gxd), dim3(512), 0, s, h, H, ws + 3 * H, 6 * H,
-                           (const int32_t*)nullptr, (const int32_t*)nullptr, 1, (const int32_t*)nullptr,
-                           (const int32_t*)nullptr, (const float*)nullptr, (const float*)nullptr, dW_hh, db_hh, V);
-        return launch_status("mpnn_gru_update_bwd_f32(dW direct 128)");
-    }
-    const int pairs = (int)(ceil_div(H, 64) * ceil_div(3 * H, 64));
-    int64_t gx = ceil_div(V, kBT);
-    if (gx > 512) gx = 512;
-    hipLaunchKernelGGL((tn_accumulate_kernel<false>), dim3((unsigned)gx, pairs), dim3(256), 0, s, m, H, H, ws, 6 * H,
-                       3 * H, (const int32_t*)nullptr, (const int32_t*)nullptr, (const float*)nullptr,
-                       (const int32_t*)nullptr, 1, dW_ih, db_ih, V);
-    hipLaunchKernelGGL((tn_accumulate_kernel<false>), dim3((unsigned)gx, pairs), dim3(256), 0, s, h, H, H, ws + 3 * H,
-                       6 * H, 3 * H, (const int32_t*)nullptr, (const int32_t*)nullptr, (const float*)nullptr,
-                       (const int32_t*)nullptr, 1, dW_hh, db_hh, V);
-    return launch_status("mpnn_gru_update_bwd_f32(dW)");
+    return gru_bwd_generic_tail(m, h, W_ih, W_hh, ws, dm, dh, dW_ih, dW_hh, db_ih, db_hh, V, H, s);
 }
 
 extern "C" int mpnn_edge_message_agg_bwd_dgate_f32(const float* dagg, const float* A, const float* h, const int32_t* src,
@@ -775,22 +791,50 @@ extern "C" int mpnn_edge_message_agg_bwd_da_f32(const float* dagg, const float* 
 
 int mpnn_gru_update_norm_supported(int H);
 
+// the generic form keeps the (V, 6H) pre-activation gradients whatever the width (mpnn_gru_bwd_workspace_bytes is 16 bytes
+// at H = 64, whose plain backward is one fused kernel)
+extern "C" size_t mpnn_gru_norm_bwd_workspace_bytes(int64_t V, int H) {
+    if (V < 0 || H <= 0) return 0;
+    if (mpnn_gru_update_norm_supported(H) == 2) return gru_bwd_f16_workspace_bytes(V, H);
+    return (size_t)V * 6 * H * sizeof(float);
+}
+
 extern "C" int mpnn_gru_update_norm_bwd_f32(const float* dout, const float* m, const float* h_norm, const float* mask,
                                             const float* W_ih, const float* W_hh, const float* saved,
                                             const float* out_norm_k, float* dm, float* dh_norm, float* dW_ih,
                                             float* dW_hh, float* db_ih, float* db_hh, double* in_norm_sums,
                                             void* workspace, size_t workspace_bytes, int64_t V, int H, void* stream) {
-    MPNN_REQUIRE(mpnn_gru_update_norm_supported(H), "mpnn_gru_update_norm_bwd_f32: no fused-norm kernels at H=%d%s", H,
-                 switches().math_fp32 ? " under MPNN_GRU_MATH=fp32" : "");
+    const int kind = mpnn_gru_update_norm_supported(H);
+    MPNN_REQUIRE(kind, "mpnn_gru_update_norm_bwd_f32: no fused-norm kernels at H=%d (1 <= H <= 256)", H);
     MPNN_REQUIRE(V >= 0, "mpnn_gru_update_norm_bwd_f32: V=%lld out of range", (long long)V);
     if (V == 0) return MPNN_OK;
     MPNN_REQUIRE(dout && m && h_norm && W_ih && W_hh && saved && dm && dh_norm && dW_ih && dW_hh && db_ih && db_hh,
                  "mpnn_gru_update_norm_bwd_f32: NULL buffer");
-    if (!workspace || workspace_bytes < mpnn_gru_bwd_workspace_bytes(V, H)) {
-        set_error("mpnn_gru_update_norm_bwd_f32: workspace %zu < %zu", workspace_bytes, mpnn_gru_bwd_workspace_bytes(V, H));
+    if (!workspace || workspace_bytes < mpnn_gru_norm_bwd_workspace_bytes(V, H)) {
+        set_error("mpnn_gru_update_norm_bwd_f32: workspace %zu < %zu", workspace_bytes, mpnn_gru_norm_bwd_workspace_bytes(V, H));
         return MPNN_EWORKSPACE;
     }
     MPNN_REQUIRE(V * 6 * (int64_t)H < (1ll << 40), "mpnn_gru_update_norm_bwd_f32: V too large");
+    if (kind == 1) {
+        // generic widths: the plain backward with the gate-gradient pass in its NORM form, then the two column sums of
+        // dh_norm in a pass of their own (the generic dm / dh are library-style GEMM launches without an epilogue hook)
+        hipStream_t s = (hipStream_t)stream;
+        float* ws = (float*)workspace;
+        int64_t g = ceil_div(V * H, 256);
+        if (g > 256 * 16) g = 256 * 16;
+        if (out_norm_k)
+            hipLaunchKernelGGL((gru_gate_grad_kernel<false, true>), dim3((unsigned)g), dim3(256), 0, s, dout, h_norm, mask, saved,
+                               ws, dh_norm, V, H, out_norm_k);
+        else
+            hipLaunchKernelGGL((gru_gate_grad_kernel<false, false>), dim3((unsigned)g), dim3(256), 0, s, dout, h_norm, mask,
+                               saved, ws, dh_norm, V, H, (const float*)nullptr);
+        int rc = launch_status("mpnn_gru_update_norm_bwd_f32(gates)");
+        if (rc) return rc;
+        rc = gru_bwd_generic_tail(m, h_norm, W_ih, W_hh, ws, dm, dh_norm, dW_ih, dW_hh, db_ih, db_hh, V, H, s);
+        if (rc) return rc;
+        if (in_norm_sums) return mpnn_norm_bwd_sums_f32(dh_norm, h_norm, nullptr, in_norm_sums, V, H, stream);
+        return MPNN_OK;
+    }
     return launch_gru_bwd_f16_wide(dout, m, h_norm, mask, W_ih, W_hh, saved, dm, dh_norm, dW_ih, dW_hh, db_ih, db_hh, workspace,
                                    V, H, out_norm_k, in_norm_sums, (hipStream_t)stream);
 }

@@ -102,12 +102,18 @@ __device__ __forceinline__ void gru_gemm_pass(const float* __restrict__ X, const
     }
 }
 
+// NORM: the masked batch norm in front of the `h` input fused in, as in gru_split.hip's wide kernel (same contract: `h` is
+// the previous update's raw output, hn = (h * hs[col] + ht[col]) * mask is formed where h is read, W_hh / b_hh arrive with
+// the map folded in; the column sums of out and out^2 go to `stats` (2H doubles), hn is written when `saved` is).
+template <bool NORM>
 __global__ void __launch_bounds__(256) gru_update_kernel(const float* __restrict__ m, const float* __restrict__ h,
                                                          const float* __restrict__ mask,
                                                          const float* __restrict__ W_ih, const float* __restrict__ W_hh,
                                                          const float* __restrict__ b_ih, const float* __restrict__ b_hh,
                                                          float* __restrict__ out, float* __restrict__ saved, int64_t V,
-                                                         int H, int row_tiles, int col_slices) {
+                                                         int H, int row_tiles, int col_slices, const float* __restrict__ hs,
+                                                         const float* __restrict__ ht, float* __restrict__ hnorm,
+                                                         double* stats) {
     __shared__ __attribute__((aligned(16))) float Xs[kRows * kLDX];
     __shared__ __attribute__((aligned(16))) float Bs[kKC * kLDB];
 
@@ -133,23 +139,40 @@ __global__ void __launch_bounds__(256) gru_update_kernel(const float* __restrict
     const float br = b_ih[col] + b_hh[col];
     const float bz = b_ih[H + col] + b_hh[H + col];
     const float bni = b_ih[2 * H + col], bnh = b_hh[2 * H + col];
+    const float hsc = NORM ? hs[col] : 1.0f, hsh = NORM ? ht[col] : 0.0f;
+    double sum1 = 0.0, sum2 = 0.0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int64_t row = i0 + 32 * wv + acc_row(i, lane);
         if (row >= V) continue;
         const float mk = mask ? mask[row] : 1.0f;
-        const float hv = h[row * H + col];
+        float hv = h[row * H + col];
+        if (NORM) hv = fmaf(hv, hsc, hsh) * mk;
         const float r = sigmoidf_(acc_r[i] + br) * mk;
         const float z = sigmoidf_(acc_z[i] + bz) * mk;
         const float nh = acc_nh[i] + bnh;
         const float n = tanhf_(acc_ni[i] + bni + r * nh) * mk;
-        out[row * H + col] = ((1.0f - z) * n + z * hv) * mk;
+        const float o = ((1.0f - z) * n + z * hv) * mk;
+        out[row * H + col] = o;
+        if (NORM) {
+            sum1 += (double)o;
+            sum2 += (double)o * (double)o;
+        }
         if (saved) {
             float* sv = saved + row * 4 * H + col;
             sv[0] = r;
             sv[H] = z;
             sv[2 * H] = n;
             sv[3 * H] = nh;
+            if (NORM) hnorm[row * H + col] = hv;
+        }
+    }
+    if (NORM) {                                            // the two lane halves hold the same column
+        sum1 += __shfl_xor(sum1, 32);
+        sum2 += __shfl_xor(sum2, 32);
+        if (lane < 32) {
+            atomicAdd(stats + col, sum1);
+            atomicAdd(stats + H + col, sum2);
         }
     }
 }
@@ -373,13 +396,18 @@ extern "C" int mpnn_gru_update_f32(const float* m, const float* h, const float* 
     MPNN_REQUIRE(row_tiles < (1 << 24), "mpnn_gru_update_f32: V too large for one launch");
     const int col_slices = (H + 31) / 32;
     const int64_t blocks = ceil_div(row_tiles, kNumXcd) * kNumXcd * col_slices;
-    hipLaunchKernelGGL(gru_update_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, m, h, mask, W_ih,
-                       W_hh, b_ih, b_hh, out, saved, V, H, (int)row_tiles, col_slices);
+    hipLaunchKernelGGL(gru_update_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, m, h, mask, W_ih,
+                       W_hh, b_ih, b_hh, out, saved, V, H, (int)row_tiles, col_slices, (const float*)nullptr,
+                       (const float*)nullptr, (float*)nullptr, (double*)nullptr);
     return launch_status("mpnn_gru_update_f32");
 }
 
+// 2: the wide split-precision kernels (H = 128 / 256); 1: the generic fp32 kernel (every other width, and every width
+// under MPNN_GRU_MATH=fp32) -- the kernel that runs the plain update at those widths anyway, except H = 32 / 64 / 128,
+// which have faster forms without the norm; 0: none
 extern "C" int mpnn_gru_update_norm_supported(int H) {
-    return (H == 128 || H == 256) && !switches().math_fp32 ? 1 : 0;
+    if (H <= 0 || H > 256) return 0;
+    return (H == 128 || H == 256) && !switches().math_fp32 ? 2 : 1;
 }
 
 extern "C" int mpnn_gru_update_norm_f32(const float* m, const float* h_raw, const float* mask, const float* W_ih,
@@ -387,13 +415,23 @@ extern "C" int mpnn_gru_update_norm_f32(const float* m, const float* h_raw, cons
                                         const float* h_scale, const float* h_shift, float* out, float* saved,
                                         float* h_norm, double* out_moments, void* workspace, size_t workspace_bytes,
                                         int64_t V, int H, void* stream) {
-    MPNN_REQUIRE(mpnn_gru_update_norm_supported(H), "mpnn_gru_update_norm_f32: no fused-norm kernel at H=%d%s", H,
-                 switches().math_fp32 ? " under MPNN_GRU_MATH=fp32" : "");
+    const int kind = mpnn_gru_update_norm_supported(H);
+    MPNN_REQUIRE(kind, "mpnn_gru_update_norm_f32: no fused-norm kernel at H=%d (1 <= H <= 256)", H);
     MPNN_REQUIRE(V >= 0, "mpnn_gru_update_norm_f32: V=%lld out of range", (long long)V);
     if (V == 0) return MPNN_OK;
     MPNN_REQUIRE(m && h_raw && W_ih && W_hh_folded && b_ih && b_hh_folded && h_scale && h_shift && out && out_moments,
                  "mpnn_gru_update_norm_f32: NULL buffer");
     MPNN_REQUIRE(!saved || h_norm, "mpnn_gru_update_norm_f32: a training pass (saved != NULL) also needs h_norm");
+    if (kind == 1) {                                       // generic fp32 kernel: no workspace
+        const int64_t row_tiles = ceil_div(V, kRows);
+        MPNN_REQUIRE(row_tiles < (1 << 24), "mpnn_gru_update_norm_f32: V too large for one launch");
+        const int col_slices = (H + 31) / 32;
+        const int64_t blocks = ceil_div(row_tiles, kNumXcd) * kNumXcd * col_slices;
+        hipLaunchKernelGGL(gru_update_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, m, h_raw, mask,
+                           W_ih, W_hh_folded, b_ih, b_hh_folded, out, saved, V, H, (int)row_tiles, col_slices, h_scale,
+                           h_shift, h_norm, out_moments);
+        return launch_status("mpnn_gru_update_norm_f32(generic)");
+    }
     MPNN_REQUIRE(workspace && workspace_bytes >= gru_fwd_workspace_bytes(H),
                  "mpnn_gru_update_norm_f32: workspace of mpnn_gru_fwd_workspace_bytes(V, H) bytes required");
     const uintptr_t al = reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(h_raw) |

@@ -284,18 +284,21 @@ __global__ void __launch_bounds__(256) bn_fold_kernel(const double* __restrict__
                                                       int flags) {
     __shared__ float s_hs[256], s_ht[256];
     const double n = (double)*count;
+    const bool given = flags & kBnUseStats;                // eval mode: `mean` / `var` are inputs (running statistics)
     for (int c = threadIdx.x; c < F; c += 256) {
         const double mu = moments[c] / n;
         double v = moments[F + c] / n - mu * mu;
         v = v > 0.0 ? v : 0.0;
-        const float vf = (float)v, mf = (float)mu;
+        const float vf = given ? var[c] : (float)v, mf = given ? mean[c] : (float)mu;
         const float g = weight ? weight[c] : 1.0f, b = weight ? bias[c] : 0.0f;
         const float sc = g / bn_scale(vf, eps, flags);
         s_hs[c] = sc;
         s_ht[c] = b - mf * sc;
         if (blockIdx.x == 0) {
-            mean[c] = mf;
-            var[c] = vf;
+            if (!given) {
+                mean[c] = mf;
+                var[c] = vf;
+            }
             hs[c] = sc;
             ht[c] = b - mf * sc;
         }
@@ -355,6 +358,31 @@ __global__ void __launch_bounds__(256) bn_bwd_sums_kernel(const float* __restric
     }
 }
 
+// any width: a block takes a strip of rows, thread = (row lane, column), float64 partials through LDS
+__global__ void __launch_bounds__(256) bn_bwd_sums_any_kernel(const float* __restrict__ d, const float* __restrict__ hn,
+                                                              const float* __restrict__ mask, double* __restrict__ sums,
+                                                              int64_t V, int F) {
+    __shared__ double red[2][256];
+    const int tpr = F < 256 ? F : 256, rl = 256 / tpr;     // threads per row, row lanes (F <= 256: one pass over the columns)
+    const int c = threadIdx.x % tpr, lr = threadIdx.x / tpr;
+    double a = 0.0, b = 0.0;
+    if (lr < rl)
+        for (int64_t row = (int64_t)blockIdx.x * rl + lr; row < V; row += (int64_t)gridDim.x * rl) {
+            const float mk = mask ? mask[row] : 1.0f;
+            const float dv = d[row * F + c] * mk;
+            a += (double)dv;
+            b += (double)dv * (double)hn[row * F + c];
+        }
+    red[0][threadIdx.x] = a;
+    red[1][threadIdx.x] = b;
+    __syncthreads();
+    if (lr == 0 && threadIdx.x < tpr) {
+        for (int q = 1; q < rl; ++q) { a += red[0][q * tpr + c]; b += red[1][q * tpr + c]; }
+        atomicAdd(sums + c, a);
+        atomicAdd(sums + F + c, b);
+    }
+}
+
 // column sums of d hn and d hn * hn (2F doubles, from the dm | dh kernel's epilogue) + the norm's statistics -> the three
 // constants of  dy = d hn * k1 + y * k2 + k4  (include/mpnn_amd.h has the derivation), and the norm's own parameter
 // gradients, accumulated
@@ -371,11 +399,12 @@ __global__ void __launch_bounds__(256) bn_bwd_consts_kernel(const double* __rest
     const double Sb = sums[c], Sh = sums[F + c];
     const double Sg = g != 0.0 ? (Sh - b * Sb) * s / g : 0.0;          // sum d hn * mask * (y - mean)
     const double root = (flags & kBnEpsInside) ? s : sqrt((double)var[c]);
-    const double dvar = root > 0.0 ? (-g * Sg * rs * rs) / (2.0 * root) : 0.0;
+    const bool given = flags & kBnUseStats;               // eval mode: mean / var are constants, the norm is a plain affine map
+    const double dvar = (root > 0.0 && !given) ? (-g * Sg * rs * rs) / (2.0 * root) : 0.0;
     const double k2 = 2.0 * dvar / n;
     kn[c] = (float)(g * rs);
     kn[F + c] = (float)k2;
-    kn[2 * F + c] = (float)(-g * Sb * rs / n - (double)mean[c] * k2);
+    kn[2 * F + c] = given ? 0.0f : (float)(-g * Sb * rs / n - (double)mean[c] * k2);
     if (dweight) {
         dweight[c] += (float)(Sg * rs);
         dbias[c] += (float)Sb;
@@ -483,12 +512,20 @@ extern "C" int mpnn_norm_bwd_consts_f32(const double* sums, const float* mean, c
 
 extern "C" int mpnn_norm_bwd_sums_f32(const float* dout, const float* h_norm, const float* mask, double* sums, int64_t V,
                                       int F, void* stream) {
-    MPNN_REQUIRE(V >= 0 && bn_vectorisable(F), "mpnn_norm_bwd_sums_f32: V=%lld F=%d (F must be 4 * 2^k <= 1024)",
-                 (long long)V, F);
+    MPNN_REQUIRE(V >= 0 && F > 0 && (bn_vectorisable(F) || F <= 256),
+                 "mpnn_norm_bwd_sums_f32: V=%lld F=%d (F <= 256, or 4 * 2^k <= 1024)", (long long)V, F);
     if (V == 0) return MPNN_OK;
     MPNN_REQUIRE(dout && h_norm && sums, "mpnn_norm_bwd_sums_f32: NULL buffer");
-    MPNN_REQUIRE((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(h_norm)) % 16 == 0,
-                 "mpnn_norm_bwd_sums_f32: buffers must be 16-byte aligned");
+    if (!bn_vectorisable(F) || (reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(h_norm)) % 16 != 0) {
+        MPNN_REQUIRE(F <= 256, "mpnn_norm_bwd_sums_f32: unaligned buffers need F <= 256");
+        const int rl = 256 / (F < 256 ? F : 256);
+        int64_t g = ceil_div(V, (int64_t)rl * 16);
+        if (g > 1024) g = 1024;
+        if (g < 1) g = 1;
+        hipLaunchKernelGGL(bn_bwd_sums_any_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, dout, h_norm, mask,
+                           sums, V, F);
+        return launch_status("mpnn_norm_bwd_sums_f32");
+    }
     int64_t vg = ceil_div(V, (int64_t)(256 / (F / 4)) * 16);
     if (vg > 2048) vg = 2048;
     if (vg < 1) vg = 1;

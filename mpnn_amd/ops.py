@@ -496,9 +496,24 @@ class GRUUpdateFn(torch.autograd.Function):
 
 
 # ---- masked batch norm fused into the update (models/att_model.py:58, lipo_basic_model.py:85) ----
+def gru_norm_kind(H, tensor):
+    """0: no fused update + norm kernel for width H on this tensor's device; 2: the wide split-precision kernels
+    (H = 128 / 256); 1: the generic fp32 kernel (what runs the plain update at the remaining widths anyway)."""
+    if not (tensor.is_cuda and tensor.dtype == torch.float32):
+        return 0
+    return int(_lib.load().mpnn_gru_update_norm_supported(int(H)))
+
+
 def gru_norm_applies(H, tensor):
-    """True when mpnn_gru_update_norm_f32 covers hidden width H on this tensor's device."""
-    return bool(tensor.is_cuda and tensor.dtype == torch.float32 and _lib.load().mpnn_gru_update_norm_supported(int(H)))
+    """True when the fast fused update + norm kernels (hidden 128 / 256) cover width H on this tensor's device."""
+    return gru_norm_kind(H, tensor) == 2
+
+
+def gru_norm_costs_nothing(H, tensor):
+    """True when fusing the norm into the update cannot slow the update down: the wide kernels, or a width whose plain
+    update runs on the generic kernel as well (not 32 / 64 / 128, which have faster un-normed forms)."""
+    k = gru_norm_kind(H, tensor)
+    return k == 2 or (k == 1 and int(H) not in (32, 64, 128, 256))
 
 
 class OutputMoments:
@@ -597,12 +612,15 @@ def gru_update_norm_in(m, y_prev, mask, W_ih, W_hh, b_ih, b_hh, moments=None, we
     return y, OutputMoments(sums, count)
 
 
-def _norm_fold(sums, count, weight, bias, W_hh, b_hh, eps, flags):
-    """moments of an update's output -> (mean, var, hs, ht, W_hh with the norm folded in, b_hh likewise): one launch."""
+def _norm_fold(sums, count, weight, bias, W_hh, b_hh, eps, flags, given=None):
+    """moments of an update's output (or, with BN_USE_STATS, the `given` (mean, var)) -> (mean, var, hs, ht, W_hh with the
+    norm folded in, b_hh likewise): one launch."""
     lib = _lib.load()
     H = int(W_hh.shape[0])
     dev = W_hh.device
     mean, var, hs, ht = (torch.empty(H, dtype=torch.float32, device=dev) for _ in range(4))
+    if given is not None:
+        mean, var = given[0].contiguous().float(), given[1].contiguous().float()
     Wf, bf = torch.empty_like(W_hh), torch.empty_like(b_hh)
     _lib.check(lib.mpnn_norm_fold_f32(_lib.ptr(sums), _lib.fptr(count), _lib.fptr(weight), _lib.fptr(bias), _lib.fptr(W_hh),
                                       _lib.fptr(b_hh), _lib.fptr(mean), _lib.fptr(var), _lib.fptr(hs), _lib.fptr(ht),
@@ -624,7 +642,8 @@ class GRUNormChain(torch.autograd.Function):
     2H moments, the count and the 2H backward sums are all-reduced -- five tiny collectives per step, no extra pass."""
 
     @staticmethod
-    def forward(ctx, h0, mask, W_ih, W_hh, b_ih, b_hh, weight, bias, eps, flags, sync, grad_mode, *msgs):
+    def forward(ctx, h0, mask, W_ih, W_hh, b_ih, b_hh, weight, bias, eps, flags, sync, grad_mode, given_mean, given_var,
+                *msgs):
         lib = _lib.load()
         y = h0.contiguous()
         V, H = int(y.shape[0]), int(y.shape[1])
@@ -657,13 +676,14 @@ class GRUNormChain(torch.autograd.Function):
                 _lib.ptr(ws), ws_bytes, V, H, _lib.stream())), "mpnn_gru_update_norm_f32")
             if sync:
                 _all_reduce(sums)
-            mean, var, hs, ht, Wf, bf = _norm_fold(sums, count, weight, bias, W_hh, b_hh, eps, flags)
+            mean, var, hs, ht, Wf, bf = _norm_fold(sums, count, weight, bias, W_hh, b_hh, eps, flags,
+                                                   None if given_mean is None else (given_mean, given_var))
             hns.append(hn)
             saveds.append(saved)
             stats.append((mean, var))
             y = out
         if not msgs:
-            return y
+            return (y,)
         final = _empty((V, H), y)
         bws_bytes = lib.mpnn_masked_bn_workspace_bytes(H)
         bws = torch.empty(bws_bytes // 4, dtype=torch.float32, device=dev)
@@ -674,10 +694,13 @@ class GRUNormChain(torch.autograd.Function):
         if need:
             ctx.save_for_backward(final, mask, W_ih, W_hh, weight, bias, count, *msgs, *hns, *saveds, *[t for mv in stats for t in mv])
         ctx.T, ctx.eps, ctx.flags, ctx.sync = len(msgs), float(eps), int(flags), sync
-        return final
+        # the per-step batch statistics ride along as non-differentiable outputs (running estimates of MaskBatchNorm1d)
+        flat = [t.clone() for mv in stats for t in mv]
+        ctx.mark_non_differentiable(*flat)
+        return (final,) + tuple(flat)
 
     @staticmethod
-    def backward(ctx, dfinal):
+    def backward(ctx, dfinal, *_dstats):
         lib = _lib.load()
         T = ctx.T
         sv = ctx.saved_tensors
@@ -721,7 +744,7 @@ class GRUNormChain(torch.autograd.Function):
         dW_ih, dW_hh = torch.zeros_like(W_ih), torch.zeros_like(W_hh)
         db_ih = torch.zeros(3 * H, dtype=torch.float32, device=dev)
         db_hh = torch.zeros(3 * H, dtype=torch.float32, device=dev)
-        ws_bytes = lib.mpnn_gru_bwd_workspace_bytes(V, H)
+        ws_bytes = lib.mpnn_gru_norm_bwd_workspace_bytes(V, H)
         ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=dev)
         dms = [None] * T
         dout = dfinal
@@ -737,7 +760,7 @@ class GRUNormChain(torch.autograd.Function):
             if t > 0:                                   # constants of the norm between update t-1 and update t
                 kn = consts(sums, t - 1)
             dout = dhn
-        return (dout, None, dW_ih, dW_hh, db_ih, db_hh, dweight, dbias, None, None, None, None) + tuple(dms)
+        return (dout, None, dW_ih, dW_hh, db_ih, db_hh, dweight, dbias, None, None, None, None, None, None) + tuple(dms)
 
 
 def _dist_world():
@@ -756,9 +779,17 @@ def _all_reduce(t):
 
 
 def gru_norm_chain(h0, msgs, mask, W_ih, W_hh, b_ih, b_hh, weight=None, bias=None, eps=1e-6, flags=BN_EPS_INSIDE,
-                   sync=False):
-    return GRUNormChain.apply(h0, mask, W_ih, W_hh, b_ih, b_hh, weight, bias, eps, flags, sync, torch.is_grad_enabled(),
-                              *msgs)
+                   sync=False, given=None, return_stats=False):
+    """`given` = (mean, var): every norm of the chain uses these statistics instead of the batch's (flags gets
+    BN_USE_STATS: MaskBatchNorm1d in eval mode).  return_stats: also the list of per-step (mean, var)."""
+    if given is not None:
+        flags = int(flags) | BN_USE_STATS
+    res = GRUNormChain.apply(h0, mask, W_ih, W_hh, b_ih, b_hh, weight, bias, eps, flags, sync, torch.is_grad_enabled(),
+                             None if given is None else given[0], None if given is None else given[1], *msgs)
+    out, flat = res[0], res[1:]
+    if return_stats:
+        return out, [(flat[2 * i], flat[2 * i + 1]) for i in range(len(flat) // 2)]
+    return out
 
 
 class MaskedBatchNormGiven(torch.autograd.Function):

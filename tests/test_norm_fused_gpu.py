@@ -217,14 +217,60 @@ def test_norm_constant_kernels_against_torch(dev):
         assert _rel(d * k1 + y * k2 + k4, yl.grad) < 2e-5
 
 
+@pytest.mark.parametrize("H,V", [(22, 777), (38, 1200), (64, 500)])
+@pytest.mark.parametrize("eval_mode", [False, True])
+def test_generic_width_chain_like_the_lipo_model(dev, H, V, eval_mode):
+    """Widths without a wide kernel run the fused update + norm on the generic fp32 kernel (what the lipo model's 22-38
+    features use): affine norm with eps outside the root and masked mean (MaskBatchNorm1d, mask_batch_norm.py:20-38), batch
+    statistics or given (running) ones, three updates, against float64."""
+    from mpnn_amd import ops
+    T = 3
+    g = torch.Generator().manual_seed(V + H)
+    mk = (torch.rand(V, generator=g) > 0.15).float()
+    leaves = dict(h0=torch.randn(V, H, generator=g) * mk.unsqueeze(1), W_ih=torch.randn(H, 3 * H, generator=g) / H ** 0.5,
+                  W_hh=torch.randn(H, 3 * H, generator=g) / H ** 0.5, b_ih=torch.randn(3 * H, generator=g) * 0.1,
+                  b_hh=torch.randn(3 * H, generator=g) * 0.1, gamma=torch.rand(H, generator=g) + 0.5,
+                  beta=torch.randn(H, generator=g) * 0.2)
+    for t in range(T):
+        leaves["m%d" % t] = torch.randn(V, H, generator=g)
+    rmean, rvar = torch.randn(H, generator=g) * 0.1, torch.rand(H, generator=g) + 0.5
+    cot = torch.randn(V, H, generator=g)
+    eps = 1e-5
+    ref = {k: v.double().requires_grad_(True) for k, v in leaves.items()}
+    st = ref["h0"]
+    want_stats = []
+    for t in range(T):
+        y = _gru64(ref["m%d" % t], st, mk.double(), ref["W_ih"], ref["W_hh"], ref["b_ih"], ref["b_hh"])
+        if eval_mode:
+            st = ((y - rmean.double()) / (rvar.double().sqrt() + eps) * ref["gamma"] + ref["beta"]) * mk.double().unsqueeze(1)
+        else:
+            mean = (y * mk.double().unsqueeze(1)).sum(0) / mk.sum()
+            want_stats.append((mean.detach(), ((((y - mean) * mk.double().unsqueeze(1)) ** 2).sum(0) / mk.sum()).detach()))
+            st = _norm64(y, mk.double(), ref["gamma"], ref["beta"], eps, True, False)
+    (st * cot.double()).sum().backward()
+    c = {k: v.to(dev).requires_grad_(True) for k, v in leaves.items()}
+    out, stats = ops.gru_norm_chain(c["h0"], [c["m%d" % t] for t in range(T)], mk.to(dev), c["W_ih"], c["W_hh"], c["b_ih"],
+                                    c["b_hh"], weight=c["gamma"], bias=c["beta"], eps=eps, flags=ops.BN_MASKED_MEAN,
+                                    given=(rmean.to(dev), rvar.to(dev)) if eval_mode else None, return_stats=True)
+    (out * cot.to(dev)).sum().backward()
+    assert _rel(out, st.detach()) < 3e-5
+    if not eval_mode:
+        for (m_got, v_got), (m_want, v_want) in zip(stats, want_stats):
+            assert _rel(m_got, m_want) < 1e-5 and _rel(v_got, v_want) < 1e-5
+    for k in leaves:
+        assert _rel(c[k].grad, ref[k].grad) < 2e-4, (k, _rel(c[k].grad, ref[k].grad))
+
+
 def test_unsupported_width_is_refused():
     from mpnn_amd import _lib, ops
     if not torch.cuda.is_available():
         pytest.skip("needs the GPU")
     dev = torch.device("cuda:0")
-    assert not ops.gru_norm_applies(64, torch.zeros(1, device=dev))
-    assert not ops.gru_norm_applies(128, torch.zeros(1))
-    x = torch.zeros(8, 64, device=dev)
+    assert not ops.gru_norm_applies(64, torch.zeros(1, device=dev))       # no FAST fused kernel at 64 ...
+    assert ops.gru_norm_kind(64, torch.zeros(1, device=dev)) == 1         # ... the generic one serves it
+    assert not ops.gru_norm_costs_nothing(64, torch.zeros(1, device=dev)) and ops.gru_norm_costs_nothing(22, torch.zeros(1, device=dev))
+    assert ops.gru_norm_kind(128, torch.zeros(1)) == 0                    # host tensors: none
+    x = torch.zeros(8, 300, device=dev)
     with pytest.raises(_lib.MpnnError):
-        ops.gru_update_norm_in(x, x, None, torch.zeros(64, 192, device=dev), torch.zeros(64, 192, device=dev),
-                               torch.zeros(192, device=dev), torch.zeros(192, device=dev))
+        ops.gru_update_norm_in(x, x, None, torch.zeros(300, 900, device=dev), torch.zeros(300, 900, device=dev),
+                               torch.zeros(900, device=dev), torch.zeros(900, device=dev))
