@@ -105,3 +105,37 @@ def test_attention_model_takes_the_gated_kernel(dev):
     for k, gr in res[0][1].items():
         ref = res[1][1][k]
         assert float((gr - ref).abs().max() / ref.abs().max().clamp_min(1e-30)) < 5e-4, k
+
+
+def test_attention_model_without_bonds_and_on_a_dense_batch(dev):
+    """Edge cases of the lazy gate: molecules of one atom (no edge at all: the fused kernel has nothing to launch, the
+    backward takes the generic route) and a dense padded batch (no tile plan: the gate is materialised as before)."""
+    from mpnn_amd import synth
+    from mpnn_amd.graph import MolGraph
+    from mpnn_amd.models.att_model import BasicModel as AttModel
+    from mpnn_amd.mpnn_functions import GraphLevelOutput
+    import numpy as np
+    H = 128
+    torch.manual_seed(3)
+    model = AttModel(H, 4, H, 6, 8, message_opts={}, agg_opts={}, update_opts={}, readout_opts={}, message_steps=2,
+                     readout_func=GraphLevelOutput).to(dev)
+    # (a) 40 single-atom molecules, compact batch
+    mb = synth.make_molecules(40, H, seed=2)
+    singles = synth.select(mb, np.arange(40))
+    one = synth.MolBatch(n_atoms=np.ones(40, np.int32), atom_ptr=np.arange(41, dtype=np.int32),
+                         row_ptr=np.zeros(41, np.int32), col_idx=np.zeros(0, np.int32),
+                         bond_type=np.zeros(0, singles.bond_type.dtype), type_feat=singles.type_feat,
+                         edge_feat=None if singles.edge_feat is None else singles.edge_feat[:0],
+                         atom_feat=singles.atom_feat[:40].copy())
+    g = MolGraph.from_molbatch(one, dev)
+    afm = torch.from_numpy(one.atom_feat).to(dev)
+    out = model(afm, g, g, torch.ones(40, 1, device=dev))
+    out.sum().backward()
+    assert torch.isfinite(out).all() and all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    # (b) dense padded batch of the same width
+    d = synth.to_dense(synth.select(mb, np.arange(6)))
+    dense = {k: torch.from_numpy(v).to(dev) for k, v in d.items() if k in ("afm", "bfm", "adj", "mask")}
+    model.zero_grad()
+    out = model(dense["afm"], dense["bfm"], dense["adj"], dense["mask"])
+    out.sum().backward()
+    assert torch.isfinite(out).all()
