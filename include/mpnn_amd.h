@@ -303,20 +303,22 @@ int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const float* h, c
  *   out_norm_k [3H] = k1 | k2 | k4, or NULL.  Non-NULL: `dout` is the gradient of norm(out) (out = this update's raw
  *     output y), and the gate-gradient kernel forms  dy = dout * k1 + y * k2 + k4  on rows with mask 1 from the saved
  *     gates (y is not read).  For a norm with scale s (sqrt(var + eps), or sqrt(var) + eps), weight g, bias b, batch
- *     mean, count n and the column sums S_b = sum dout, S_h = sum dout * norm(out):
- *       S_g = (S_h - b S_b) s / g;  dvar = -g S_g / (2 s^2 root)  (root = s, or sqrt(var) with eps outside);
- *       k1 = g / s;  k2 = 2 dvar / n;  k4 = -g S_b / (s n) - mean k2          (ops.GRUNormChain has it in torch ops).
- *   in_norm_sums [2H] doubles, ACCUMULATED (caller zeroes), or NULL.  Non-NULL: h_norm = norm(y_prev); the dm | dh
- *     kernel adds the column sums of dh_norm and of dh_norm * h_norm -- S_b and S_h of THAT norm -- so the update before
- *     this one can be called with their out_norm_k and no norm-backward pass runs at all.
+ *     mean, count n and the column sums S_b = sum dout, S_y = sum dout * out (against the norm's RAW input, so that a
+ *     weight entry of 0 keeps its gradient and nothing is divided by g):
+ *       S_g = S_y - mean S_b;  dvar = -g S_g / (2 s^2 root)  (root = s, or sqrt(var) with eps outside);
+ *       k1 = g / s;  k2 = 2 dvar / n;  k4 = -g S_b / (s n) - mean k2;  dweight = S_g / s;  dbias = S_b.
+ *   in_norm_sums [2H] doubles, ACCUMULATED (caller zeroes), or NULL.  Non-NULL: h_norm = norm(h_raw), h_raw [V,H] = the
+ *     `h_raw` mpnn_gru_update_norm_f32 was called with; the dm | dh kernel adds the column sums of dh_norm and of
+ *     dh_norm * h_raw -- S_b and S_y of THAT norm -- so the update before this one can be called with their out_norm_k
+ *     and no norm-backward pass runs at all.  h_raw may be NULL when in_norm_sums is.
  * Widths as mpnn_gru_update_norm_f32; workspace: mpnn_gru_norm_bwd_workspace_bytes(V, H).
  */
 size_t mpnn_gru_norm_bwd_workspace_bytes(int64_t V, int H);
 int mpnn_gru_update_norm_bwd_f32(const float* dout, const float* m, const float* h_norm, const float* mask,
                                  const float* W_ih, const float* W_hh, const float* saved, const float* out_norm_k,
                                  float* dm, float* dh_norm, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh,
-                                 double* in_norm_sums, void* workspace, size_t workspace_bytes, int64_t V, int H,
-                                 void* stream);
+                                 double* in_norm_sums, const float* h_raw, void* workspace, size_t workspace_bytes,
+                                 int64_t V, int H, void* stream);
 
 /* ------------------------------------------------------------------ masked batch norm */
 /*
@@ -348,17 +350,17 @@ int mpnn_masked_bn_bwd_f32(const float* dout, const float* x, const float* mask,
  * mpnn_norm_bwd_consts_f32: sums [2F] doubles (in_norm_sums of mpnn_gru_update_norm_bwd_f32) + the norm's statistics
  *   -> out_norm_k [3F] for the update in front of that norm; dweight / dbias [F] (affine norms) are ACCUMULATED.
  * mpnn_norm_bwd_sums_f32: the same two sums for a norm whose output left the chain (no dm | dh kernel behind it):
- *   sums [2F] doubles += (sum dout * mask | sum dout * mask * h_norm), one read of dout and of the norm's output.
+ *   sums [2F] doubles += (sum dout * mask | sum dout * mask * y_raw), one read of dout and of the norm's raw INPUT.
  *   F = 4 * 2^k <= 1024.
  */
-int mpnn_norm_bwd_sums_f32(const float* dout, const float* h_norm, const float* mask, double* sums, int64_t V, int F,
+int mpnn_norm_bwd_sums_f32(const float* dout, const float* y_raw, const float* mask, double* sums, int64_t V, int F,
                            void* stream);
 int mpnn_norm_fold_f32(const double* moments, const float* count, const float* weight, const float* bias,
                        const float* W_hh, const float* b_hh, float* mean, float* var, float* h_scale, float* h_shift,
                        float* W_hh_folded, float* b_hh_folded, int F, float eps, int flags, void* stream);
 int mpnn_norm_bwd_consts_f32(const double* sums, const float* mean, const float* var, const float* count,
-                             const float* weight, const float* bias, float* out_norm_k, float* dweight, float* dbias,
-                             int F, float eps, int flags, void* stream);
+                             const float* weight, float* out_norm_k, float* dweight, float* dbias, int F, float eps,
+                             int flags, void* stream);
 
 #ifdef __cplusplus
 }

@@ -66,13 +66,19 @@ def library_path():
 
 
 def load():
-    """Load (building first if stale/missing) the C-ABI library; raises if that is impossible."""
+    """Load the C-ABI library, building it first when it is missing or STALE (its manifest differs from the hash of the
+    sources, headers and flags now in the tree: build._stale()); raises if that is impossible -- a library that was not
+    built from this tree is never loaded silently."""
     global _lib
     if _lib is not None:
         return _lib
     path = _build.LIB
-    if not os.path.exists(path):
-        path = _build.build()          # raises when hipcc is absent
+    if _build._stale():
+        try:
+            path = _build.build()      # raises when hipcc is absent or a source does not compile
+        except Exception as e:
+            raise MpnnError("libmpnn_amd.so is missing or was not built from the sources in this tree, and rebuilding "
+                            "it failed (%s); run `python -m mpnn_amd.build`" % e)
     lib = ctypes.CDLL(path)
     for name, (res, args) in header_signatures().items():
         fn = getattr(lib, name)        # AttributeError => the .so is out of date: fail loudly

@@ -5,10 +5,15 @@
 hipcc cross-compiles without a GPU, so this runs in the build container; the resulting
 .so travels to the GPU box with the source snapshot.
 
-An object is rebuilt when its source or any header is newer, or when it was compiled with other flags
-(MPNN_EXTRA_HIPCC_FLAGS: the hash of the flag list sits next to every object).  Objects and the library are written
-to a per-process temporary name and renamed into place, and the whole build holds a file lock, so several ranks
-that find the library missing at start-up build it once instead of over each other.
+The library is STALE when the manifest written next to it at link time (a hash over every source, every header and the
+flag list) differs from the hash of the files now in the tree -- content, not mtimes: a snapshot copied to the GPU box
+keeps its library, an edited .hip does not.  _lib.load() checks this on every first load and rebuilds, or raises when
+hipcc is absent.  An object is recompiled when its source or any header is newer, or when it was compiled with other
+flags.  Objects and the library are written to a per-process temporary name and renamed into place, and the whole build
+holds a file lock, so several ranks that find the library stale at start-up build it once instead of over each other.
+
+Builds with extra flags (MPNN_EXTRA_HIPCC_FLAGS: timing experiments, some with wrong results by design) go to a
+directory of their own, lib/variant_<hash of the flags>/, and never replace the product library.
 """
 import fcntl
 import glob
@@ -20,12 +25,14 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIBDIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIBDIR, "libmpnn_amd.so")
 ARCH = "gfx950"
+EXTRA = os.environ.get("MPNN_EXTRA_HIPCC_FLAGS", "").split()
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
-         "-fno-fast-math"] + os.environ.get("MPNN_EXTRA_HIPCC_FLAGS", "").split()
+         "-fno-fast-math"] + EXTRA
 FLAGS_HASH = hashlib.sha256(" ".join(FLAGS).encode()).hexdigest()[:16]
+LIBDIR = os.path.join(HERE, "lib", "variant_" + FLAGS_HASH) if EXTRA else os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libmpnn_amd.so")
+MANIFEST = LIB + ".manifest"
 
 
 def sources():
@@ -51,18 +58,25 @@ def _obj_stale(src, t_hdr):
         return True
 
 
+def source_hash():
+    """Hash over the flag list and the contents of every source and header: what a library must have been built from."""
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for p in sorted(sources() + _headers(), key=os.path.basename):
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(hashlib.sha256(f.read()).digest())
+    return h.hexdigest()
+
+
 def _stale():
+    """True when the library is missing or was not built from the sources, headers and flags now in the tree."""
     if not os.path.exists(LIB):
         return True
-    t = os.path.getmtime(LIB)
-    if any(os.path.getmtime(p) > t for p in sources() + _headers()):
+    try:
+        with open(MANIFEST) as f:
+            return f.read().strip() != source_hash()
+    except OSError:
         return True
-    # a library without objects (a snapshot on the GPU box carries only the .so) is taken as it is
-    objs = [_obj_of(s) for s in sources()]
-    if not any(os.path.exists(o) for o in objs):
-        return False
-    t_hdr = max(os.path.getmtime(p) for p in _headers())
-    return any(_obj_stale(s, t_hdr) for s in sources())
 
 
 def _compile_one(job):
@@ -117,6 +131,9 @@ def build(force=False, verbose=False):
             sys.stderr.write(r.stdout + r.stderr)
             raise RuntimeError("hipcc failed linking libmpnn_amd.so")
         os.replace(tmp, LIB)
+        with open(MANIFEST + ".tmp%d" % os.getpid(), "w") as f:
+            f.write(source_hash() + "\n")
+        os.replace(MANIFEST + ".tmp%d" % os.getpid(), MANIFEST)
     return LIB
 
 

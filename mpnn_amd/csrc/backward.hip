@@ -655,7 +655,7 @@ size_t gru_bwd_f16_workspace_bytes(int64_t V, int H);                      // gr
 int launch_gru_bwd_f16_wide(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
                             const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
                             float* db_ih, float* db_hh, void* workspace, int64_t V, int H, const float* out_norm_k,
-                            double* in_norm_sums, hipStream_t s);
+                            double* in_norm_sums, const float* in_norm_raw, hipStream_t s);
 }  // namespace mpnn
 
 // the generic-width backward after the gate-gradient pass (ws = (V, 6H) pre-activation gradients, dh holds g * z):
@@ -730,7 +730,7 @@ extern "C" int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const 
     // widths: elementwise gate gradients into a (V, 6H) workspace + generic fp32 contractions below
     if ((H == 128 || H == 256) && !fp32_only)
         return launch_gru_bwd_f16_wide(dout, m, h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, workspace, V, H,
-                                       nullptr, nullptr, s);
+                                       nullptr, nullptr, nullptr, s);
     hipLaunchKernelGGL(gru_gate_grad_kernel<false>, dim3((unsigned)g), dim3(256), 0, s, dout, h, mask, saved, ws, dh, V,
                        H);
     rc = launch_status("mpnn_gru_update_bwd_f32(gates)");
@@ -803,13 +803,15 @@ extern "C" int mpnn_gru_update_norm_bwd_f32(const float* dout, const float* m, c
                                             const float* W_ih, const float* W_hh, const float* saved,
                                             const float* out_norm_k, float* dm, float* dh_norm, float* dW_ih,
                                             float* dW_hh, float* db_ih, float* db_hh, double* in_norm_sums,
-                                            void* workspace, size_t workspace_bytes, int64_t V, int H, void* stream) {
+                                            const float* h_raw, void* workspace, size_t workspace_bytes, int64_t V, int H,
+                                            void* stream) {
     const int kind = mpnn_gru_update_norm_supported(H);
     MPNN_REQUIRE(kind, "mpnn_gru_update_norm_bwd_f32: no fused-norm kernels at H=%d (1 <= H <= 256)", H);
     MPNN_REQUIRE(V >= 0, "mpnn_gru_update_norm_bwd_f32: V=%lld out of range", (long long)V);
     if (V == 0) return MPNN_OK;
     MPNN_REQUIRE(dout && m && h_norm && W_ih && W_hh && saved && dm && dh_norm && dW_ih && dW_hh && db_ih && db_hh,
                  "mpnn_gru_update_norm_bwd_f32: NULL buffer");
+    MPNN_REQUIRE(!in_norm_sums || h_raw, "mpnn_gru_update_norm_bwd_f32: in_norm_sums needs h_raw (the norm's raw input)");
     if (!workspace || workspace_bytes < mpnn_gru_norm_bwd_workspace_bytes(V, H)) {
         set_error("mpnn_gru_update_norm_bwd_f32: workspace %zu < %zu", workspace_bytes, mpnn_gru_norm_bwd_workspace_bytes(V, H));
         return MPNN_EWORKSPACE;
@@ -832,9 +834,9 @@ extern "C" int mpnn_gru_update_norm_bwd_f32(const float* dout, const float* m, c
         if (rc) return rc;
         rc = gru_bwd_generic_tail(m, h_norm, W_ih, W_hh, ws, dm, dh_norm, dW_ih, dW_hh, db_ih, db_hh, V, H, s);
         if (rc) return rc;
-        if (in_norm_sums) return mpnn_norm_bwd_sums_f32(dh_norm, h_norm, nullptr, in_norm_sums, V, H, stream);
+        if (in_norm_sums) return mpnn_norm_bwd_sums_f32(dh_norm, h_raw, nullptr, in_norm_sums, V, H, stream);
         return MPNN_OK;
     }
     return launch_gru_bwd_f16_wide(dout, m, h_norm, mask, W_ih, W_hh, saved, dm, dh_norm, dW_ih, dW_hh, db_ih, db_hh, workspace,
-                                   V, H, out_norm_k, in_norm_sums, (hipStream_t)stream);
+                                   V, H, out_norm_k, in_norm_sums, h_raw, (hipStream_t)stream);
 }

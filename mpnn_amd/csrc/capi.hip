@@ -29,7 +29,9 @@ const Switches& switches() {
 // 0.3.0: mpnn_gru_update_f32 takes a workspace, mpnn_message_aggregate_wide_f32 added, mpnn_message_aggregate_bwd_da_f32
 //        removed.  0.3.1: mpnn_gru_update_norm_f32 / _norm_bwd_f32 / _norm_supported, mpnn_norm_fold_f32,
 //        mpnn_norm_bwd_consts_f32, mpnn_norm_bwd_sums_f32 added; the H = 128 / 256 backward workspace holds one scale per atom.
-extern "C" int mpnn_version(void) { return 301; }
+// 0.4.0: the fused norm's backward sums run against the norm's raw input: mpnn_gru_update_norm_bwd_f32 takes h_raw,
+//        mpnn_norm_bwd_sums_f32 takes y_raw, mpnn_norm_bwd_consts_f32 lost its bias argument.
+extern "C" int mpnn_version(void) { return 400; }
 
 extern "C" int mpnn_init(void) {
     (void)mpnn::switches();

@@ -275,8 +275,9 @@ __global__ void __launch_bounds__(512) gru_bwd_dx_presplit_kernel(const float* _
 
 // ------------------------------------------------ dm | dh, loads two chunks ahead
 // NORM: `h` entered the update as hn = norm(y_prev); the backward of that norm needs the column sums of dh and of
-// dh * hn over all atoms.  They are taken here, where dh is final: `hn` is read in the accumulator layout, the sums go
-// to `sums` (2 H doubles, accumulated; per wave in LDS across its tiles, one atomic per column and block at the end).
+// dh * y_prev over all atoms (against the norm's RAW input: sum dh (y_prev - mean) then needs no division by the norm's
+// weight).  They are taken here, where dh is final: `hn` = y_prev is read in the accumulator layout, the sums go to
+// `sums` (2 H doubles, accumulated; per wave in LDS across its tiles, one atomic per column and block at the end).
 // Rounds 2-3 had a form of this kernel that requested chunk c + 1's operands -- the block's weight image (global -> LDS
 // copy) and the wave's row fragments -- at the start of chunk c and waited for them at its end.  Measured on it
 // (DESIGN 3c): with BOTH served from nowhere / from L2 it took 2.08 instead of 3.0 ms at c4's size, with either one alone
@@ -757,12 +758,13 @@ size_t gru_bwd_f16_workspace_bytes(int64_t V, int H) {
 }
 
 // out_norm_k != NULL: dout is the gradient of norm(out), the gate kernel turns it into the gradient of out (NORM there);
-// in_norm_sums != NULL: h = hn = norm(y_prev), the dm | dh kernel also takes the column sums the backward of THAT norm needs
+// in_norm_sums != NULL: h = hn = norm(y_prev), y_prev = in_norm_raw: the dm | dh kernel also takes the column sums the
+// backward of THAT norm needs
 template <int H>
 static int launch_gru_bwd_f16_t(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
                                 const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
                                 float* db_ih, float* db_hh, void* workspace, int64_t V, const float* out_norm_k,
-                                double* in_norm_sums, hipStream_t s) {
+                                double* in_norm_sums, const float* in_norm_raw, hipStream_t s) {
     const int64_t tiles = (V + 31) / 32;
     char* pieces = (char*)workspace;
     float* inv_scale = (float*)(pieces + (size_t)tiles * (32 * 4 * H * 4));
@@ -803,7 +805,7 @@ static int launch_gru_bwd_f16_t(const float* dout, const float* m, const float* 
         hipLaunchKernelGGL(gru_bwd_dx_presplit_kernel<H>, dim3((unsigned)(NS * 4 * (H / 32))), dim3(512), 0, s, W_ih, W_hh, dxw);
         if (in_norm_sums)
             hipLaunchKernelGGL((gru_bwd_dx_deep_f16_kernel<H, true>), dim3((unsigned)(pblocks * NS)), dim3(512),
-                               (size_t)3 * 4 * 128 * 64, s, pieces, inv_scale, dm, dh, V, (const char*)dxw, h, in_norm_sums);
+                               (size_t)3 * 4 * 128 * 64, s, pieces, inv_scale, dm, dh, V, (const char*)dxw, in_norm_raw, in_norm_sums);
         else
             hipLaunchKernelGGL((gru_bwd_dx_deep_f16_kernel<H, false>), dim3((unsigned)(pblocks * NS)), dim3(512),
                                (size_t)3 * 4 * 128 * 64, s, pieces, inv_scale, dm, dh, V, (const char*)dxw,
@@ -823,12 +825,12 @@ static int launch_gru_bwd_f16_t(const float* dout, const float* m, const float* 
 int launch_gru_bwd_f16_wide(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
                             const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
                             float* db_ih, float* db_hh, void* workspace, int64_t V, int H, const float* out_norm_k,
-                            double* in_norm_sums, hipStream_t s) {
+                            double* in_norm_sums, const float* in_norm_raw, hipStream_t s) {
     if (H == 128)
         return launch_gru_bwd_f16_t<128>(dout, m, h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, workspace, V,
-                                         out_norm_k, in_norm_sums, s);
+                                         out_norm_k, in_norm_sums, in_norm_raw, s);
     return launch_gru_bwd_f16_t<256>(dout, m, h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, workspace, V,
-                                     out_norm_k, in_norm_sums, s);
+                                     out_norm_k, in_norm_sums, in_norm_raw, s);
 }
 
 }  // namespace mpnn

@@ -315,8 +315,10 @@ __global__ void __launch_bounds__(256) bn_fold_kernel(const double* __restrict__
     bf[j] = acc;
 }
 
-// S_b = sum d * mask and S_h = sum d * mask * hn over all rows (2F doubles, accumulated): the sums of the norm backward
-// for a norm whose output hn left the chain (the last one), where no dm | dh epilogue produces them.  One read of d and hn.
+// S_b = sum d * mask and S_y = sum d * mask * y over all rows (2F doubles, accumulated), y = the RAW input of the norm: the
+// sums of the norm backward for a norm whose output left the chain (the last one), where no dm | dh epilogue produces them.
+// One read of d and y.  (Round 3 summed against the norm's OUTPUT g xhat + b and divided by g afterwards: a weight entry
+// of exactly 0 then lost its gradient for good, a tiny one amplified rounding -- ADVICE r3.)
 __global__ void __launch_bounds__(256) bn_bwd_sums_kernel(const float* __restrict__ d, const float* __restrict__ hn,
                                                           const float* __restrict__ mask, double* __restrict__ sums,
                                                           int64_t V, int F) {
@@ -383,21 +385,21 @@ __global__ void __launch_bounds__(256) bn_bwd_sums_any_kernel(const float* __res
     }
 }
 
-// column sums of d hn and d hn * hn (2F doubles, from the dm | dh kernel's epilogue) + the norm's statistics -> the three
-// constants of  dy = d hn * k1 + y * k2 + k4  (include/mpnn_amd.h has the derivation), and the norm's own parameter
-// gradients, accumulated
+// column sums of d hn and d hn * y (2F doubles, from the dm | dh kernel's epilogue; y = the norm's raw input) + the norm's
+// statistics -> the three constants of  dy = d hn * k1 + y * k2 + k4  (include/mpnn_amd.h has the derivation), and the
+// norm's own parameter gradients, accumulated
 __global__ void __launch_bounds__(256) bn_bwd_consts_kernel(const double* __restrict__ sums, const float* __restrict__ mean,
                                                             const float* __restrict__ var, const float* __restrict__ count,
-                                                            const float* __restrict__ weight, const float* __restrict__ bias,
+                                                            const float* __restrict__ weight,
                                                             float* __restrict__ kn, float* __restrict__ dweight,
                                                             float* __restrict__ dbias, int F, float eps, int flags) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= F) return;
     const double n = (double)*count;
-    const double g = weight ? (double)weight[c] : 1.0, b = weight ? (double)bias[c] : 0.0;
+    const double g = weight ? (double)weight[c] : 1.0;
     const double s = (double)bn_scale(var[c], eps, flags), rs = 1.0 / s;
-    const double Sb = sums[c], Sh = sums[F + c];
-    const double Sg = g != 0.0 ? (Sh - b * Sb) * s / g : 0.0;          // sum d hn * mask * (y - mean)
+    const double Sb = sums[c], Sy = sums[F + c];
+    const double Sg = Sy - (double)mean[c] * Sb;                       // sum d hn * mask * (y - mean): no division by g
     const double root = (flags & kBnEpsInside) ? s : sqrt((double)var[c]);
     const bool given = flags & kBnUseStats;               // eval mode: mean / var are constants, the norm is a plain affine map
     const double dvar = (root > 0.0 && !given) ? (-g * Sg * rs * rs) / (2.0 * root) : 0.0;
@@ -499,36 +501,36 @@ extern "C" int mpnn_norm_fold_f32(const double* moments, const float* count, con
 }
 
 extern "C" int mpnn_norm_bwd_consts_f32(const double* sums, const float* mean, const float* var, const float* count,
-                                        const float* weight, const float* bias, float* out_norm_k, float* dweight,
-                                        float* dbias, int F, float eps, int flags, void* stream) {
+                                        const float* weight, float* out_norm_k, float* dweight, float* dbias, int F,
+                                        float eps, int flags, void* stream) {
     MPNN_REQUIRE(F > 0 && F <= 1024, "mpnn_norm_bwd_consts_f32: F=%d out of range", F);
     MPNN_REQUIRE(sums && mean && var && count && out_norm_k, "mpnn_norm_bwd_consts_f32: NULL buffer");
-    MPNN_REQUIRE((weight == nullptr) == (bias == nullptr) && (weight == nullptr) == (dweight == nullptr) &&
-                 (dweight == nullptr) == (dbias == nullptr), "mpnn_norm_bwd_consts_f32: weight, bias and their gradients go together");
+    MPNN_REQUIRE((weight == nullptr) == (dweight == nullptr) && (dweight == nullptr) == (dbias == nullptr),
+                 "mpnn_norm_bwd_consts_f32: the weight and the parameter gradients go together");
     hipLaunchKernelGGL(bn_bwd_consts_kernel, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sums, mean,
-                       var, count, weight, bias, out_norm_k, dweight, dbias, F, eps, flags);
+                       var, count, weight, out_norm_k, dweight, dbias, F, eps, flags);
     return launch_status("mpnn_norm_bwd_consts_f32");
 }
 
-extern "C" int mpnn_norm_bwd_sums_f32(const float* dout, const float* h_norm, const float* mask, double* sums, int64_t V,
+extern "C" int mpnn_norm_bwd_sums_f32(const float* dout, const float* y_raw, const float* mask, double* sums, int64_t V,
                                       int F, void* stream) {
     MPNN_REQUIRE(V >= 0 && F > 0 && (bn_vectorisable(F) || F <= 256),
                  "mpnn_norm_bwd_sums_f32: V=%lld F=%d (F <= 256, or 4 * 2^k <= 1024)", (long long)V, F);
     if (V == 0) return MPNN_OK;
-    MPNN_REQUIRE(dout && h_norm && sums, "mpnn_norm_bwd_sums_f32: NULL buffer");
-    if (!bn_vectorisable(F) || (reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(h_norm)) % 16 != 0) {
+    MPNN_REQUIRE(dout && y_raw && sums, "mpnn_norm_bwd_sums_f32: NULL buffer");
+    if (!bn_vectorisable(F) || (reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(y_raw)) % 16 != 0) {
         MPNN_REQUIRE(F <= 256, "mpnn_norm_bwd_sums_f32: unaligned buffers need F <= 256");
         const int rl = 256 / (F < 256 ? F : 256);
         int64_t g = ceil_div(V, (int64_t)rl * 16);
         if (g > 1024) g = 1024;
         if (g < 1) g = 1;
-        hipLaunchKernelGGL(bn_bwd_sums_any_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, dout, h_norm, mask,
+        hipLaunchKernelGGL(bn_bwd_sums_any_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, dout, y_raw, mask,
                            sums, V, F);
         return launch_status("mpnn_norm_bwd_sums_f32");
     }
     int64_t vg = ceil_div(V, (int64_t)(256 / (F / 4)) * 16);
     if (vg > 2048) vg = 2048;
     if (vg < 1) vg = 1;
-    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((unsigned)vg), dim3(256), 0, (hipStream_t)stream, dout, h_norm, mask, sums, V, F);
+    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((unsigned)vg), dim3(256), 0, (hipStream_t)stream, dout, y_raw, mask, sums, V, F);
     return launch_status("mpnn_norm_bwd_sums_f32");
 }

@@ -24,6 +24,54 @@ from . import _lib
 def _i32(t):
     return t.to(torch.int32).contiguous()
 
+def _tile_layout(g, tv, lib):
+    """What both tile plans start from: the batch's atoms cut into molecule-aligned tiles of at most `tv` atoms (greedy,
+    whole molecules) and, inside every tile, sorted by their per-type in-degree pattern (rare types lead the key, high
+    counts first).  None when the batch does not fit (no atoms, a molecule larger than a tile, an edge that leaves its
+    tile).  -> (nt, tile_ptr, tp64, n_t, tile_of_atom, dst, src, et, cnt, pos_in_tile)"""
+    import ctypes
+    K, E, V = g.num_types, g.num_edges, g.num_nodes
+    if V == 0 or g.num_graphs == 0:
+        return None
+    gp = g.graph_ptr.to("cpu", torch.int32).contiguous()
+    tp = torch.empty(g.num_graphs + 2, dtype=torch.int32)
+    nt = lib.mpnn_plan_tiles_host(ctypes.c_void_p(gp.data_ptr()), g.num_graphs, tv, ctypes.c_void_p(tp.data_ptr()))
+    if nt <= 0:
+        return None                                       # a molecule larger than a tile
+    dev = g.device
+    tile_ptr = tp[:nt + 1].to(dev)
+    tp64 = tile_ptr.to(torch.int64)
+    n_t = tp64[1:] - tp64[:-1]
+    tile_of_atom = torch.repeat_interleave(torch.arange(nt, device=dev), n_t, output_size=V)
+    dst, src, et = g.edge_dst.to(torch.int64), g.col_idx.to(torch.int64), g.edge_type.to(torch.int64)
+    if E and bool((tile_of_atom[src] != tile_of_atom[dst]).any().item()):
+        return None                                       # an edge leaves its tile: not a batch of separate molecules
+    # per-atom in-degree by type; the pattern key packs one field per type into an int64: 8 bits each up to seven types,
+    # 7 bits at eight (56 bits either way -- 256 ** 8 does not fit).  The tile is NOT packed into the same word (tile *
+    # 256 ** K wraps from K = 7 on): two stable sorts, pattern first, tile second.
+    cnt = torch.bincount(dst * K + et, minlength=V * K).view(V, K)
+    bits = 8 if K <= 7 else 7
+    top = (1 << bits) - 1
+    code = torch.zeros(V, dtype=torch.int64, device=dev)
+    for k in reversed(range(K)):                          # rare types (high ids) first: measured best fill on c2
+        code = (code << bits) + (top - cnt[:, k].clamp(max=top))
+    by_code = torch.sort(code, stable=True).indices
+    perm = by_code[torch.sort(tile_of_atom[by_code], stable=True).indices]            # sorted position -> atom
+    pos_in_tile = torch.empty(V, dtype=torch.int64, device=dev)
+    pos_in_tile[perm] = torch.arange(V, device=dev) - tp64[tile_of_atom[perm]]
+    return nt, tile_ptr, tp64, n_t, tile_of_atom, dst, src, et, cnt, pos_in_tile
+
+
+def _edge_rank(dst, et, cnt, K, V, E, dev):
+    """rank of an edge among the edges of its (destination, type), in edge order"""
+    key = dst * K + et
+    order = torch.sort(key, stable=True).indices
+    first = torch.zeros(V * K + 1, dtype=torch.int64, device=dev)
+    first[1:] = torch.cumsum(cnt.reshape(-1), 0)
+    rank = torch.empty(E, dtype=torch.int64, device=dev)
+    rank[order] = torch.arange(E, device=dev) - first[key[order]]
+    return rank
+
 
 class TilePlan:
     """Work list of the fused message+sum kernel (csrc/message_tile.hip).
@@ -65,33 +113,14 @@ class TilePlan:
         tv, kmax = lib.mpnn_message_aggregate_tile_atoms(), lib.mpnn_message_aggregate_max_types()
         rtmax = lib.mpnn_message_aggregate_max_row_tiles()
         K, E, V = g.num_types, g.num_edges, g.num_nodes
-        if K > kmax or V == 0 or g.num_graphs == 0:
+        if K > kmax:
             return None
-        import ctypes
-        gp = g.graph_ptr.to("cpu", torch.int32).contiguous()
-        tp = torch.empty(g.num_graphs + 2, dtype=torch.int32)
-        nt = lib.mpnn_plan_tiles_host(ctypes.c_void_p(gp.data_ptr()), g.num_graphs, tv, ctypes.c_void_p(tp.data_ptr()))
-        if nt <= 0:
-            return None                                   # a molecule larger than a tile
+        lay = _tile_layout(g, tv, lib)
+        if lay is None:
+            return None
+        nt, tile_ptr, tp64, n_t, tile_of_atom, dst, src, et, cnt, pos_in_tile = lay
         dev = g.device
-        tile_ptr = tp[:nt + 1].to(dev)
-        tp64 = tile_ptr.to(torch.int64)
-        n_t = tp64[1:] - tp64[:-1]
-        tile_of_atom = torch.repeat_interleave(torch.arange(nt, device=dev), n_t, output_size=V)
-        dst = g.edge_dst.to(torch.int64)
-        src = g.col_idx.to(torch.int64)
-        et = g.edge_type.to(torch.int64)
         src_local = src - tp64[tile_of_atom[dst]]
-        if E and bool((tile_of_atom[src] != tile_of_atom[dst]).any().item()):
-            return None                                   # an edge leaves its tile: not a batch of separate molecules
-        # ---- per-atom in-degree by type, and the sort of every tile's atoms by that pattern (high counts first)
-        cnt = torch.bincount(dst * K + et, minlength=V * K).view(V, K)
-        code = torch.zeros(V, dtype=torch.int64, device=dev)
-        for k in reversed(range(K)):                     # rare types (high ids) first: measured best fill on c2
-            code = code * 256 + (255 - cnt[:, k].clamp(max=255))
-        perm = torch.sort(tile_of_atom * (256 ** K) + code, stable=True).indices     # sorted position -> atom
-        pos_in_tile = torch.empty(V, dtype=torch.int64, device=dev)
-        pos_in_tile[perm] = torch.arange(V, device=dev) - tp64[tile_of_atom[perm]]
         nblk = tv // 16
         sblk_of_atom = tile_of_atom * nblk + pos_in_tile // 16                        # block in sorted order
         row_of_atom = pos_in_tile % 16
@@ -125,13 +154,7 @@ class TilePlan:
         slots = (tv | ((rt_grp % K) << 16)).repeat_interleave(16)                      # empty: the zero row
         slot_eid = torch.full((16 * R,), -1, dtype=torch.int64, device=dev)
         if E:
-            # rank of an edge among the edges of its (destination, type), in edge order
-            key = dst * K + et
-            order = torch.sort(key, stable=True).indices
-            first = torch.zeros(V * K + 1, dtype=torch.int64, device=dev)
-            first[1:] = torch.cumsum(cnt.reshape(-1), 0)
-            rank = torch.empty(E, dtype=torch.int64, device=dev)
-            rank[order] = torch.arange(E, device=dev) - first[key[order]]
+            rank = _edge_rank(dst, et, cnt, K, V, E, dev)
             pos = (rt_start[blk_of_atom[dst] * K + et] + rank) * 16 + row_of_atom[dst]
             slots[pos] = src_local | (1 << 14) | (et << 16)
             slot_eid[pos] = torch.arange(E, device=dev)
@@ -174,30 +197,14 @@ class WidePlan:
         lib = _lib.load()
         tv, nb32 = cls.TILE_ATOMS, cls.BLOCK
         K, E, V = g.num_types, g.num_edges, g.num_nodes
-        if K > cls.MAX_TYPES or V == 0 or g.num_graphs == 0:
+        if K > cls.MAX_TYPES:
             return None
-        import ctypes
-        gp = g.graph_ptr.to("cpu", torch.int32).contiguous()
-        tp = torch.empty(g.num_graphs + 2, dtype=torch.int32)
-        nt = lib.mpnn_plan_tiles_host(ctypes.c_void_p(gp.data_ptr()), g.num_graphs, tv, ctypes.c_void_p(tp.data_ptr()))
-        if nt <= 0:
-            return None                                   # a molecule larger than a tile
+        lay = _tile_layout(g, tv, lib)
+        if lay is None:
+            return None
+        nt, tile_ptr, tp64, n_t, tile_of_atom, dst, src, et, cnt, pos_in_tile = lay
         dev = g.device
-        tile_ptr = tp[:nt + 1].to(dev)
-        tp64 = tile_ptr.to(torch.int64)
-        n_t = tp64[1:] - tp64[:-1]
-        tile_of_atom = torch.repeat_interleave(torch.arange(nt, device=dev), n_t, output_size=V)
-        dst, src, et = g.edge_dst.to(torch.int64), g.col_idx.to(torch.int64), g.edge_type.to(torch.int64)
-        if E and bool((tile_of_atom[src] != tile_of_atom[dst]).any().item()):
-            return None                                   # an edge leaves its tile: not a batch of separate molecules
         nblk = tv // nb32
-        cnt = torch.bincount(dst * K + et, minlength=V * K).view(V, K)
-        code = torch.zeros(V, dtype=torch.int64, device=dev)
-        for k in reversed(range(K)):                      # rare types (high ids) lead the key, high counts first
-            code = code * 256 + (255 - cnt[:, k].clamp(max=255))
-        perm = torch.sort(tile_of_atom * (256 ** K) + code, stable=True).indices      # sorted position -> atom
-        pos_in_tile = torch.empty(V, dtype=torch.int64, device=dev)
-        pos_in_tile[perm] = torch.arange(V, device=dev) - tp64[tile_of_atom[perm]]
         blk_of_atom = tile_of_atom * nblk + pos_in_tile // nb32
         row_of_atom = pos_in_tile % nb32
         need = torch.zeros(nt * nblk * K, dtype=torch.int64, device=dev)
@@ -219,12 +226,7 @@ class WidePlan:
         slots = torch.full((nb32 * R,), tv, dtype=torch.int16, device=dev)
         slot_eid = torch.full((nb32 * R,), -1, dtype=torch.int64, device=dev)
         if E:
-            key = dst * K + et
-            order = torch.sort(key, stable=True).indices
-            first = torch.zeros(V * K + 1, dtype=torch.int64, device=dev)
-            first[1:] = torch.cumsum(cnt.reshape(-1), 0)
-            rank = torch.empty(E, dtype=torch.int64, device=dev)
-            rank[order] = torch.arange(E, device=dev) - first[key[order]]
+            rank = _edge_rank(dst, et, cnt, K, V, E, dev)
             pos = (start[blk_of_atom[dst] * K + et] + rank) * nb32 + row_of_atom[dst]
             slots[pos] = (src - tp64[tile_of_atom[dst]]).to(torch.int16)
             slot_eid[pos] = torch.arange(E, device=dev)

@@ -663,9 +663,10 @@ class GRUNormChain(torch.autograd.Function):
         ws_bytes = lib.mpnn_gru_fwd_workspace_bytes(V, H)
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
         msgs = [m.contiguous() for m in msgs]
-        hns, saveds, stats = [], [], []
+        hns, saveds, stats, raws = [], [], [], []
         mean = var = None
         for m in msgs:
+            raws.append(y)                                # the raw state this update's norm took (h0 for the first)
             out = _empty((V, H), y)
             saved = _empty((V, 4 * H), y) if need else None
             hn = _empty((V, H), y) if need else None
@@ -692,7 +693,10 @@ class GRUNormChain(torch.autograd.Function):
                                               int(flags) | BN_USE_STATS, _lib.ptr(bws), bws_bytes, _lib.stream()),
                    "mpnn_masked_bn_fwd_f32")
         if need:
-            ctx.save_for_backward(final, mask, W_ih, W_hh, weight, bias, count, *msgs, *hns, *saveds, *[t for mv in stats for t in mv])
+            # y = the last update's raw output: the last norm's backward sums run against it (not against `final`, the
+            # norm's affine output, from which a zero weight entry could not be undone)
+            ctx.save_for_backward(y, mask, W_ih, W_hh, weight, bias, count, *msgs, *hns, *saveds, *raws[1:],
+                                  *[t for mv in stats for t in mv])
         ctx.T, ctx.eps, ctx.flags, ctx.sync = len(msgs), float(eps), int(flags), sync
         # the per-step batch statistics ride along as non-differentiable outputs (running estimates of MaskBatchNorm1d)
         flat = [t.clone() for mv in stats for t in mv]
@@ -704,11 +708,12 @@ class GRUNormChain(torch.autograd.Function):
         lib = _lib.load()
         T = ctx.T
         sv = ctx.saved_tensors
-        final, mask, W_ih, W_hh, weight, bias, count = sv[:7]
+        y_last, mask, W_ih, W_hh, weight, bias, count = sv[:7]
         msgs, hns, saveds = sv[7:7 + T], sv[7 + T:7 + 2 * T], sv[7 + 2 * T:7 + 3 * T]
-        stats = sv[7 + 3 * T:]
-        V, H = int(final.shape[0]), int(final.shape[1])
-        dev = final.device
+        raws = (None,) + tuple(sv[7 + 3 * T:7 + 4 * T - 1])   # raws[t] = raw input state of update t (t >= 1)
+        stats = sv[7 + 4 * T - 1:]
+        V, H = int(y_last.shape[0]), int(y_last.shape[1])
+        dev = y_last.device
         affine = weight is not None
         dweight = torch.zeros(H, dtype=torch.float32, device=dev) if affine else None
         dbias = torch.zeros(H, dtype=torch.float32, device=dev) if affine else None
@@ -721,7 +726,7 @@ class GRUNormChain(torch.autograd.Function):
 
             def run(sm, dw, db, out):
                 _lib.check(lib.mpnn_norm_bwd_consts_f32(_lib.ptr(sm), _lib.fptr(mean), _lib.fptr(var), _lib.fptr(count),
-                                                        _lib.fptr(weight), _lib.fptr(bias), _lib.fptr(out), _lib.fptr(dw),
+                                                        _lib.fptr(weight), _lib.fptr(out), _lib.fptr(dw),
                                                         _lib.fptr(db), H, ctx.eps, ctx.flags, _lib.stream()),
                            "mpnn_norm_bwd_consts_f32")
             if not ctx.sync:
@@ -734,11 +739,11 @@ class GRUNormChain(torch.autograd.Function):
             run(sums, scratch[0], scratch[1], kn)
             return kn
 
-        # the last norm's output left this function: its two sums take one pass over (dfinal, final); its apply happens in
-        # the gate-gradient kernel of the last update like every other norm's
+        # the last norm's output left this function: its two sums take one pass over (dfinal, the norm's raw input); its
+        # apply happens in the gate-gradient kernel of the last update like every other norm's
         dfinal = dfinal.contiguous()
         lsums = torch.zeros(2 * H, dtype=torch.float64, device=dev)
-        _lib.check(lib.mpnn_norm_bwd_sums_f32(_lib.fptr(dfinal), _lib.fptr(final), _lib.fptr(mask), _lib.ptr(lsums), V, H,
+        _lib.check(lib.mpnn_norm_bwd_sums_f32(_lib.fptr(dfinal), _lib.fptr(y_last), _lib.fptr(mask), _lib.ptr(lsums), V, H,
                                               _lib.stream()), "mpnn_norm_bwd_sums_f32")
         kn = consts(lsums, T - 1)
         dW_ih, dW_hh = torch.zeros_like(W_ih), torch.zeros_like(W_hh)
@@ -749,12 +754,13 @@ class GRUNormChain(torch.autograd.Function):
         dms = [None] * T
         dout = dfinal
         for t in range(T - 1, -1, -1):
-            dm, dhn = _empty((V, H), final), _empty((V, H), final)
+            dm, dhn = _empty((V, H), y_last), _empty((V, H), y_last)
             sums = torch.zeros(2 * H, dtype=torch.float64, device=dev) if t > 0 else None
             _lib.check(_timed("gru_update_bwd", lambda: lib.mpnn_gru_update_norm_bwd_f32(
                 _lib.fptr(dout), _lib.fptr(msgs[t]), _lib.fptr(hns[t]), _lib.fptr(mask), _lib.fptr(W_ih), _lib.fptr(W_hh),
                 _lib.fptr(saveds[t]), _lib.fptr(kn), _lib.fptr(dm), _lib.fptr(dhn), _lib.fptr(dW_ih), _lib.fptr(dW_hh),
-                _lib.fptr(db_ih), _lib.fptr(db_hh), _lib.ptr(sums), _lib.ptr(ws), ws_bytes, V, H, _lib.stream())),
+                _lib.fptr(db_ih), _lib.fptr(db_hh), _lib.ptr(sums), _lib.fptr(raws[t]), _lib.ptr(ws), ws_bytes, V, H,
+                _lib.stream())),
                 "mpnn_gru_update_norm_bwd_f32")
             dms[t] = dm
             if t > 0:                                   # constants of the norm between update t-1 and update t

@@ -118,13 +118,48 @@ def test_wide_kernel_is_bit_reproducible_and_equals_the_two_kernel_path(dev, F):
     assert max_err(a, two) < 2e-5 * max(1.0, float(two.abs().max()))
 
 
-def test_other_type_counts_and_the_autograd_node(dev, monkeypatch):
+@pytest.mark.parametrize("K", [1, 2, 4, 5, 7, 8])
+@pytest.mark.parametrize("F,n_mols", [(128, 500), (128, 60000), (256, 12000)])
+def test_bond_type_counts_small_and_large_batches(dev, K, F, n_mols):
+    """Every type count the ops accept (graph.WidePlan.MAX_TYPES = 8), on a batch of a few tiles and on batches of more
+    than 128 tiles (60k molecules = ~7.5k tiles, c4 / c5 sized): the plan's sort key used to wrap there at K = 7 and to
+    overflow at K = 8."""
     from mpnn_amd import ops
-    for K in (1, 2, 7):
-        mb, g, h = _graph(dev, 500, 128, 20 + K, K=K)
-        gen = torch.Generator(device=dev).manual_seed(K)
-        A = torch.randn(g.num_types, 128, 128, device=dev, generator=gen) / 11.0
-        assert max_err(ops.message_aggregate_wide_raw(h, A, g), _ref(g, h, A)) < 2e-5
+    mb, g, h = _graph(dev, n_mols, F, 20 + K, K=K)
+    assert g.num_types == K
+    gen = torch.Generator(device=dev).manual_seed(K)
+    A = torch.randn(K, F, F, device=dev, generator=gen) / F ** 0.5
+    assert ops.wide_kernel_applies(A, None, None, g) and (n_mols < 10000 or g.wide_plan.num_tiles > 128)
+    out = ops.message_aggregate_wide_raw(h, A, g)
+    ref = _ref(g, h, A)
+    assert max_err(out, ref) < 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("K", [4, 5, 8])
+def test_gated_aggregate_falls_back_beyond_four_types(dev, K):
+    """AttEdgeNetwork + AdjMsgAgg: the fused gated kernel covers K <= 4; beyond that ops.gated_message_aggregate takes the
+    materialised gate + message_aggregate path (unit weights) and must still match float64."""
+    from mpnn_amd import ops
+    F = 128
+    mb, g, h = _graph(dev, 400, F, 40 + K, K=K)
+    gen = torch.Generator(device=dev).manual_seed(K)
+    A = torch.randn(K, F, F, device=dev, generator=gen) / F ** 0.5
+    z = torch.randn(g.num_nodes, F, device=dev, generator=gen)
+    q = torch.randn(K, F, device=dev, generator=gen)
+    assert ops.wide_gated_applies(A, None, g) == (K <= 4)
+    out = ops.gated_message_aggregate(h, A, ops.LazyAttGate(z, q, g), g)
+    src, dst, typ = g.col_idx.long(), g.edge_dst.long(), g.edge_type.long()
+    gate = torch.softmax(z.double()[dst] + q.double()[typ], dim=-1)
+    x = gate * h.double()[src]
+    ref = torch.zeros(g.num_nodes, F, dtype=torch.float64, device=dev)
+    for k in range(K):
+        idx = (typ == k).nonzero().squeeze(1)
+        ref.index_add_(0, dst[idx], x[idx] @ A.double()[k].t())
+    assert max_err(out, ref) < 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_the_autograd_node(dev, monkeypatch):
+    from mpnn_amd import ops
     mb, g, h = _graph(dev, 2000, 128, 14)
     gen = torch.Generator(device=dev).manual_seed(14)
     A = (torch.randn(g.num_types, 128, 128, device=dev, generator=gen) / 11.0).requires_grad_(True)

@@ -66,6 +66,7 @@ def test_two_updates_with_the_norm_between_them(dev, H, V, affine, partial_mask)
                   b_ih=torch.randn(3 * H, generator=g) * 0.1, b_hh=torch.randn(3 * H, generator=g) * 0.1)
     if affine:
         leaves.update(gamma=torch.rand(H, generator=g) + 0.5, beta=torch.randn(H, generator=g) * 0.2)
+        leaves["gamma"][:3] = torch.tensor([0.0, 1e-6, -1e-6])   # weight entries at / near zero keep exact gradients
     cot = torch.randn(V, H, generator=g)
     eps, masked_mean, eps_inside = (1e-5, True, False) if affine else (1e-6, False, True)
     flags = ops.BN_MASKED_MEAN if affine else ops.BN_EPS_INSIDE
@@ -187,6 +188,7 @@ def test_norm_constant_kernels_against_torch(dev):
     sums = torch.cat([y.sum(0), (y * y).sum(0)]).to(dev)
     count = torch.tensor([n], device=dev)
     gamma, beta = (torch.rand(H, generator=g) + 0.5).to(dev), (torch.randn(H, generator=g) * 0.2).to(dev)
+    gamma[:4] = torch.tensor([0.0, 1e-6, -1e-6, 1e-12], device=dev)    # a zero weight keeps its gradient
     W, b = torch.randn(H, 3 * H, generator=g).to(dev), torch.randn(3 * H, generator=g).to(dev)
     for weight, bias, eps, flags in ((None, None, 1e-6, ops.BN_EPS_INSIDE), (gamma, beta, 1e-5, ops.BN_MASKED_MEAN)):
         mean, var, hs, ht, Wf, bf = ops._norm_fold(sums, count, weight, bias, W, b, eps, flags)
@@ -200,21 +202,24 @@ def test_norm_constant_kernels_against_torch(dev):
         assert _rel(Wf, W.double().cpu() * (g64 / s).unsqueeze(1)) < 1e-6
         assert _rel(bf, b.double().cpu() + (b64 - mu * g64 / s) @ W.double().cpu()) < 1e-5
         d = torch.randn(int(n), H, generator=g).double()
-        hn = (y - mu) / s * g64 + b64
-        bs = torch.cat([d.sum(0), (d * hn).sum(0)]).to(dev)
+        bs = torch.cat([d.sum(0), (d * y).sum(0)]).to(dev)           # the sums run against the norm's RAW input
         kn = torch.empty(3 * H, device=dev)
         dw = torch.zeros(H, device=dev) if weight is not None else None
         db = torch.zeros(H, device=dev) if weight is not None else None
         _lib.check(lib.mpnn_norm_bwd_consts_f32(_lib.ptr(bs), _lib.fptr(mean), _lib.fptr(var), _lib.fptr(count),
-                                                _lib.fptr(weight), _lib.fptr(bias), _lib.fptr(kn), _lib.fptr(dw),
+                                                _lib.fptr(weight), _lib.fptr(kn), _lib.fptr(dw),
                                                 _lib.fptr(db), H, eps, flags, _lib.stream()), "consts")
         yl = y.clone().requires_grad_(True)
+        gl = g64.clone().requires_grad_(True)
         m2 = yl.mean(0)
         v2 = ((yl - m2) ** 2).mean(0)
         s2 = torch.sqrt(v2 + eps) if flags & ops.BN_EPS_INSIDE else torch.sqrt(v2) + eps
-        (((yl - m2) / s2 * g64 + b64) * d).sum().backward()
+        (((yl - m2) / s2 * gl + b64) * d).sum().backward()
         k1, k2, k4 = kn[:H].double().cpu(), kn[H:2 * H].double().cpu(), kn[2 * H:].double().cpu()
         assert _rel(d * k1 + y * k2 + k4, yl.grad) < 2e-5
+        if weight is not None:
+            assert _rel(dw, gl.grad) < 1e-5 and float(dw[0].abs()) > 1e-3      # (the zero entry's gradient is not zero)
+            assert _rel(db, d.sum(0)) < 1e-5
 
 
 @pytest.mark.parametrize("H,V", [(22, 777), (38, 1200), (64, 500)])
@@ -231,6 +236,7 @@ def test_generic_width_chain_like_the_lipo_model(dev, H, V, eval_mode):
                   W_hh=torch.randn(H, 3 * H, generator=g) / H ** 0.5, b_ih=torch.randn(3 * H, generator=g) * 0.1,
                   b_hh=torch.randn(3 * H, generator=g) * 0.1, gamma=torch.rand(H, generator=g) + 0.5,
                   beta=torch.randn(H, generator=g) * 0.2)
+    leaves["gamma"][:3] = torch.tensor([0.0, 1e-6, -1e-6])       # weight entries at / near zero keep exact gradients
     for t in range(T):
         leaves["m%d" % t] = torch.randn(V, H, generator=g)
     rmean, rvar = torch.randn(H, generator=g) * 0.1, torch.rand(H, generator=g) + 0.5

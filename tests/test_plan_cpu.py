@@ -174,3 +174,47 @@ def test_wide_plan_rank_order_is_edge_order_and_limits():
                 last[key] = e
     many = synth.make_molecules(20, 4, seed=6, edge_features=9)      # 9 bond types: more than the kernel's phases take
     assert MolGraph.from_molbatch(many, torch.device("cpu")).wide_plan is None
+
+
+def _check_wide_fast(g):
+    """Vectorised form of _walk_wide's structural assertions (every tile's atom list a permutation of the tile, every edge
+    in exactly one slot, of its own destination row, source and type) for batches too large for the Python walk."""
+    p = g.wide_plan
+    assert p is not None
+    K = g.num_types
+    rec, ta, bo = p.tile_rec.numpy().astype(np.int64), p.tile_atom.numpy().astype(np.int64), p.blk_off.numpy().astype(np.int64)
+    sl, se = p.slots.numpy().astype(np.int64).reshape(-1, 32), p.slot_eid.numpy().astype(np.int64).reshape(-1, 32)
+    for t in range(p.num_tiles):
+        a = np.sort(ta[t][ta[t] >= 0])
+        assert np.array_equal(a, np.arange(rec[t, 0], rec[t, 0] + rec[t, 1]))
+    placed = se[se >= 0]
+    assert len(placed) == g.num_edges and np.array_equal(np.sort(placed), np.arange(g.num_edges))
+    # slot row rr belongs to (tile, block, type): recover them from blk_off
+    row_tile = np.repeat(np.arange(p.num_tiles), rec[:, 3])
+    assert len(row_tile) == sl.shape[0]
+    local = np.arange(sl.shape[0]) - rec[row_tile, 2]
+    grp = np.array([np.searchsorted(bo[t, 1:], l, side="right") for t, l in zip(row_tile, local)])
+    blk, typ = grp // K, grp % K
+    rr, m = np.nonzero(se >= 0)
+    e = se[rr, m]
+    dst, src, et = g.edge_dst.numpy(), g.col_idx.numpy(), g.edge_type.numpy()
+    assert np.array_equal(ta[row_tile[rr], 32 * blk[rr] + m], dst[e])
+    assert np.array_equal(rec[row_tile[rr], 0] + sl[rr, m], src[e]) and np.array_equal(typ[rr], et[e])
+    assert (sl[se < 0] == p.TILE_ATOMS).all()
+
+
+@pytest.mark.parametrize("ef,n_mols", [(7, 5000), (8, 5000), (8, 60)])
+def test_wide_plan_at_seven_and_eight_bond_types(ef, n_mols):
+    """the sort key used to pack (tile, per-type counts) into one int64 -- tile * 256 ** 7 wraps beyond
+    128 tiles and 256 ** 8 does not fit at all.  5000 molecules = ~147 tiles."""
+    mb = synth.make_molecules(n_mols, 8, seed=11, edge_features=ef)
+    g = MolGraph.from_molbatch(mb, torch.device("cpu"))
+    assert g.num_types == ef
+    assert g.wide_plan is not None and (n_mols < 5000 or g.wide_plan.num_tiles > 128)
+    _check_wide_fast(g)
+    if n_mols <= 60:
+        h = torch.randn(g.num_nodes, 8, dtype=torch.float64)
+        A = torch.randn(g.num_types, 8, 8, dtype=torch.float64)
+        ref = torch.zeros(g.num_nodes, 8, dtype=torch.float64)
+        ref.index_add_(0, g.edge_dst.long(), torch.einsum("emn,en->em", A[g.edge_type.long()], h[g.col_idx.long()]))
+        assert float((_walk_wide(g, h, A) - ref).abs().max()) < 1e-12

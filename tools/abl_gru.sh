@@ -7,6 +7,8 @@
 # left out.  dm | dh kernel (gru_bwd128_f16.hip): MPNN_ABL_DX_NOSCALE = the rows' scales neither fetched nor undone.  (The
 # HOT_ROWS / NO_WCOPY pair was first used on the one-chunk-ahead dm | dh kernel that round 3 replaced: DESIGN 3c.)
 # Kernel times vary by up to 15 % between boxes: compare runs of ONE call only.
+# A build with MPNN_EXTRA_HIPCC_FLAGS set lands in mpnn_amd/lib/variant_<hash of the flags>/ and is loaded from there by
+# processes that carry the same variable (mpnn_amd/build.py): the product library is never replaced by an experiment.
 cd "$GRAFT_REPO_ROOT" || exit 1
 H=$1; shift
 bash tools/prof_kernels.sh abl_base_$H "gru_(update|bwd_d|gate)" -- python3 tools/bench_gru_bwd.py $H time
