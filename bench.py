@@ -71,6 +71,10 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-side", action="store_true",
                     help="skip the side measurements that start child processes (the fp32-pipe step time)")
+    ap.add_argument("--side-workloads", default="auto", choices=["auto", "on", "off"],
+                    help="the \"workloads\" side field (c1, c3, c4, c5 stepped in the same process after the headline): "
+                         "auto = with the default headline (c2, train, weak, one GPU)")
+    ap.add_argument("--side-scale", type=float, default=1.0, help="fraction of each side workload's molecules (tests)")
     return ap.parse_args()
 
 
@@ -109,7 +113,7 @@ def pmc_traffic(workload, kernel_substr):
     tools/pmc_summary.py are the only writers).  PMC collection needs the profiler, so it cannot happen inside this
     process; the figure is a property of (kernel, workload) and is reported with its source file, that file's hash and
     the commit it was measured at, so a stale figure is visible.  (None, None) when no pass exists."""
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         path = os.path.join(REPO, "profiles", "%s_pmc_%s.json" % (rnd, workload))
         try:
             with open(path, "rb") as f:
@@ -266,6 +270,121 @@ def segsum_calibration(ops, graph, F, dev):
             "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "timed": "10 launches after 3 warm-ups, outside the timed steps"}
 
 
+def make_model(workload, hidden, T, dev):
+    """The model of a workload: models.basic_model.BasicModel, or (c3 / c3a) models.att_model.BasicModel with the cheap
+    readout (the metric times message + aggregate + update; the default Set2Vec readout -- 100 LSTM steps over every
+    atom -- is outside it)."""
+    from mpnn_amd.models.basic_model import BasicModel
+    if workload in ("c3", "c3a"):
+        from mpnn_amd.models.att_model import BasicModel as AttModel
+        from mpnn_amd.mpnn_functions import AdjMsgAgg, AttMsgAgg, GraphLevelOutput
+        return AttModel(hidden, 4, hidden, 1 if workload == "c3a" else 50, 8, message_opts={}, agg_opts={},
+                        update_opts={}, readout_opts={}, message_steps=T, readout_func=GraphLevelOutput,
+                        message_agg_func=AttMsgAgg if workload == "c3a" else AdjMsgAgg).to(dev)
+    return BasicModel(hidden, 4, hidden, 50, 8, message_opts={}, agg_opts={}, update_opts={}, readout_opts={},
+                      message_steps=T).to(dev)
+
+
+SIDE_KERNELS = ["message_aggregate", "segsum", "edge_message", "gru_update", "gru_update_bwd", "message_aggregate_bwd"]
+
+
+def side_workload(name, dev, steps=3, warmup=1, scale=1.0):
+    """One of the other BASELINE configs in the same process, outside the headline's clock: `warmup` + `steps` forward
+    passes, the same of training steps, then one pass with HIP events around the hot-path launches.  The molecules are
+    the workload's own synthetic set (seed 317); the atom features are made on the device (synth.hashed_features: same
+    distribution, no 5 GB host array at hidden 256) -- step times do not depend on their values."""
+    from mpnn_amd import ops, parallel, synth
+    from mpnn_amd.graph import MolGraph
+    mols, hidden, T, dist_name, desc = WORKLOADS[name]
+    mols = max(32, int(mols * scale))
+    t_start = time.perf_counter()
+    mb = synth.make_molecules(mols, hidden, seed=317, dist=dist_name, edge_features=4, atom_features=False)
+    g = MolGraph.from_molbatch(mb, dev)
+    g.prepare(tile_plan=(hidden == 64), wide_plan=(hidden in (128, 256)))
+    V, E = g.num_nodes, g.num_edges
+    afm = synth.hashed_features(torch.arange(V, device=dev), hidden)
+    mask = torch.ones(V, 1, device=dev)
+    torch.manual_seed(317)
+    model = make_model(name, hidden, T, dev)
+    bucket = parallel.GradientBucket([p for n, p in model.named_parameters() if not n.startswith("of.")])
+    seed = torch.full((V, hidden), 1.0 / float(mols), device=dev)
+
+    def fwd():
+        with torch.no_grad():
+            model.message_passing(afm, g, g, mask)
+
+    def train():
+        bucket.zero()
+        state, _ = model.message_passing(afm, g, g, mask)
+        state.backward(gradient=seed.view_as(state))
+
+    def clock(step, n_warm, n):
+        for _ in range(n_warm):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    fwd_ms = clock(fwd, warmup, steps)
+    train_ms = clock(train, warmup, steps)
+    timer = ops.KernelTimer(SIDE_KERNELS)
+    ops.set_kernel_timer(timer)
+    for _ in range(steps):
+        train()
+    torch.cuda.synchronize()
+    ops.set_kernel_timer(None)
+    per_launch = {k: timer.mean_ms(k) for k in sorted(timer.names) if timer.events[k]}
+    per_step = {k: per_launch[k] * len(timer.events[k]) / steps for k in per_launch}
+    dom = max(per_step, key=per_step.get) if per_step else None
+    out = {"workload": "%s: %s" % (name, desc), "mols": mols, "atoms": V, "edges": E, "hidden": hidden, "mp_steps": T,
+           "steps": steps, "warmup": warmup, "train_ms": train_ms, "fwd_ms": fwd_ms,
+           "edges_per_s": E * T / (train_ms * 1e-3), "forward_edges_per_s": E * T / (fwd_ms * 1e-3),
+           "kernels_ms_per_launch": per_launch, "kernels_ms_per_step": per_step,
+           "dominant_kernel": ({"kernel": dom, "ms_per_launch": per_launch[dom], "ms_per_step": per_step[dom]} if dom else None)}
+    if name == "c1":
+        # the reference driver's own batching (test_lipo.py:150): batches of 16 molecules, each its own CSR
+        parts = []
+        for b0 in range(0, mols, 16):
+            sub = synth.select(mb, np.arange(b0, min(b0 + 16, mols)))
+            gs = MolGraph.from_molbatch(sub, dev)
+            gs.prepare()
+            a0, a1 = int(mb.atom_ptr[b0]), int(mb.atom_ptr[min(b0 + 16, mols)])
+            parts.append((afm[a0:a1].contiguous(), gs, torch.ones(a1 - a0, 1, device=dev)))
+
+        def epoch_fwd():
+            with torch.no_grad():
+                for a, gs, mk in parts:
+                    model.message_passing(a, gs, gs, mk)
+
+        def epoch_train():
+            for a, gs, mk in parts:
+                bucket.zero()
+                state, _ = model.message_passing(a, gs, gs, mk)
+                (state.sum() / 16).backward()
+
+        f16, t16 = clock(epoch_fwd, warmup, steps), clock(epoch_train, warmup, steps)
+        out["batches_of_16"] = {"batches": len(parts), "train_ms_per_epoch": t16, "fwd_ms_per_epoch": f16,
+                                "train_edges_per_s": E * T / (t16 * 1e-3), "forward_edges_per_s": E * T / (f16 * 1e-3),
+                                "note": "the same molecules as %d batches of 16 (the reference driver's batch size, "
+                                        "test_lipo.py:150), one optimizer-sized step per batch" % len(parts)}
+        # ... and the same epoch with every batch's step recorded into a HIP graph once and replayed (mpnn_amd/capture.py).
+        # A child process: an illegal call inside a capture aborts the process, and a side figure must not take the headline down.
+        try:
+            r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "capture_step.py"), "--mols", str(mols), "--hidden",
+                                str(hidden), "--steps", str(T), "--epochs", str(max(steps, 3))], stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE, text=True, timeout=300)
+            out["batches_of_16"]["recorded_graphs"] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        except Exception as e:
+            out["batches_of_16"]["recorded_graphs"] = {"error": repr(e)[:200]}
+    out["wall_s"] = time.perf_counter() - t_start
+    del model, bucket, afm, g, seed, mask
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -295,7 +414,6 @@ def main():
 
     from mpnn_amd import ops, parallel, synth
     from mpnn_amd.graph import MolGraph
-    from mpnn_amd.models.basic_model import BasicModel
 
     mols, hidden, T, dist_name, desc = WORKLOADS[args.workload]
     # ---- resident inputs: a list of micro-batches (afm, graph, mask); weak scaling has exactly one
@@ -321,17 +439,7 @@ def main():
     V = sum(g.num_nodes for _, g, _ in batches)
     E = sum(g.num_edges for _, g, _ in batches)
     torch.manual_seed(317)                               # same weights on every rank
-    if args.workload in ("c3", "c3a"):
-        from mpnn_amd.models.att_model import BasicModel as AttModel
-        from mpnn_amd.mpnn_functions import AdjMsgAgg, AttMsgAgg, GraphLevelOutput
-        # the metric times message + aggregate + update; the model's default Set2Vec readout (100 LSTM steps over
-        # every atom) is outside it, so the cheap readout closes the loss here as in the other workloads
-        model = AttModel(hidden, 4, hidden, 1 if args.workload == "c3a" else 50, 8, message_opts={}, agg_opts={},
-                         update_opts={}, readout_opts={}, message_steps=T, readout_func=GraphLevelOutput,
-                         message_agg_func=AttMsgAgg if args.workload == "c3a" else AdjMsgAgg).to(dev)
-    else:
-        model = BasicModel(hidden, 4, hidden, 50, 8, message_opts={}, agg_opts={}, update_opts={}, readout_opts={},
-                           message_steps=T).to(dev)
+    model = make_model(args.workload, hidden, T, dev)
     hot = [p for n, p in model.named_parameters() if not n.startswith("of.")]   # readout is off the hot path
     bucket = parallel.GradientBucket(hot)
     total_mols = parallel.global_count(local_mols, dev)
@@ -411,8 +519,7 @@ def main():
     edges_per_rank = gather_stat(E)
     mols_per_rank = gather_stat(local_mols)
     total_edges = float(sum(edges_per_rank))
-    timer = ops.KernelTimer(["message_aggregate", "segsum", "edge_message", "gru_update", "gru_update_bwd",
-                             "message_aggregate_bwd"])
+    timer = ops.KernelTimer(SIDE_KERNELS)
     if args.mode == "train":
         dt_fwd = timed(step_fwd)
         dt = timed(step_train)
@@ -643,6 +750,17 @@ def main():
                 cmb = synth.make_molecules(min(mols, 4096), hidden, seed=317, dist=dist_name, edge_features=4)
             out["cpu_baseline"] = cpu_baseline(cmb, hidden, T, args.mode, args.cpu_seconds)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        side = args.side_workloads == "on" or (args.side_workloads == "auto" and args.workload == "c2" and args.mode == "train"
+                                               and args.scaling == "weak" and not args.no_side)
+        if world == 1 and side:
+            # the other BASELINE configs, so that every config has a driver-run number: same process, after the headline's
+            # timed region (the headline's batch stays resident: 288 GB hold all of them)
+            out["workloads"] = {}
+            for wl in ("c1", "c3", "c4", "c5"):
+                try:
+                    out["workloads"][wl] = side_workload(wl, dev, scale=args.side_scale)
+                except Exception as e:                    # a side figure must not take the headline down
+                    out["workloads"][wl] = {"error": repr(e)[:300]}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

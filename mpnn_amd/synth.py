@@ -129,8 +129,10 @@ def _ring_closures(rng, n, parent, want):
 
 
 def make_molecules(num_mols, node_features, seed=317, dist="drug", edge_features=4,
-                   continuous=False, preferential=None, lipo_features=False):
-    """Build a :class:`MolBatch` of `num_mols` synthetic molecules."""
+                   continuous=False, preferential=None, lipo_features=False, atom_features=True):
+    """Build a :class:`MolBatch` of `num_mols` synthetic molecules.  atom_features=False: graph structure only (`atom_feat`
+    is a (V, 0) array; the caller makes the features on the device, `hashed_features`) -- at hidden 256 the host-side
+    random features are 5 GB and most of the generation time."""
     rng = np.random.default_rng(seed)
     G = int(num_mols)
     n = _atom_counts(rng, G, dist).astype(np.int64)
@@ -190,7 +192,9 @@ def make_molecules(num_mols, node_features, seed=317, dist="drug", edge_features
         type_feat = np.eye(K, dtype=np.float32)
 
     nf = int(node_features)
-    if lipo_features:
+    if not atom_features:
+        atom_feat = np.zeros((V, 0), dtype=np.float32)
+    elif lipo_features:
         # C1 shape: 19 one-hot columns + 3 numeric columns in [0,1)
         onehot = max(nf - 3, 1)
         atom_feat = np.zeros((V, nf), dtype=np.float32)

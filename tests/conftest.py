@@ -16,6 +16,36 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+_PARITY = {}
+
+
+def record_parity(case, **measured):
+    """Keep the MEASURED errors of a parity test (not just pass / fail): printed, and written at the end of the session to
+    gpurun_out/r04_parity.json (MPNN_PARITY_OUT overrides), which is committed as profiles/r04_parity.json."""
+    _PARITY.setdefault(case, {}).update({k: (float(v) if isinstance(v, (int, float)) else v) for k, v in measured.items()})
+    print("parity[%s] %s" % (case, " ".join("%s=%.3g" % (k, v) if isinstance(v, float) else "%s=%s" % (k, v)
+                                              for k, v in _PARITY[case].items())))
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _PARITY:
+        return
+    import json
+    path = os.environ.get("MPNN_PARITY_OUT", os.path.join(REPO, "gpurun_out", "r04_parity.json"))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        old = {}
+        if os.path.exists(path):
+            with open(path) as f:
+                old = json.load(f)
+        old.update(_PARITY)
+        old["_math"] = os.environ.get("MPNN_GRU_MATH", "split (default)")
+        with open(path, "w") as f:
+            json.dump(old, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
 class Fixture:
     """One golden .npz split into inputs / params / outputs / grads (see make_golden.py)."""
 

@@ -18,7 +18,8 @@ def test_bench_contract_tiny_workload():
     env = dict(os.environ)
     env["MPNN_CPU_THREADS"] = "4"
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--workload", "tiny", "--steps", "2", "--warmup",
-                        "1", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600, env=env)
+                        "1", "--cpu-seconds", "1", "--side-workloads", "on", "--side-scale", "0.02"], capture_output=True,
+                       text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -39,3 +40,13 @@ def test_bench_contract_tiny_workload():
         assert d["fp32_pipe"]["ms_per_step"] > 0                    # strict fp32 MFMA step (child process)
     assert cb["host_cpu_count"] >= cb["cores"] and cb["extrapolated_seconds_for_2k_molecules"] > 0
     assert all(v is None or v > 0 for v in d["kernels_ms"].values())
+    # every other BASELINE config stepped in the same run (here at 2 % of its molecules): c1 with the reference's batches of
+    # 16 beside the whole-set batch, c3 (attention model), c4, c5
+    wl = d["workloads"]
+    assert set(wl) == {"c1", "c3", "c4", "c5"}
+    for name, w in wl.items():
+        assert "error" not in w, (name, w)
+        assert w["train_ms"] > w["fwd_ms"] > 0 and w["edges_per_s"] > 0 and w["edges"] > 0
+        assert w["dominant_kernel"]["ms_per_step"] > 0 and w["dominant_kernel"]["kernel"] in w["kernels_ms_per_launch"]
+    assert (wl["c3"]["hidden"], wl["c4"]["hidden"], wl["c5"]["hidden"]) == (128, 128, 256) and wl["c3"]["mp_steps"] == 5
+    assert wl["c1"]["batches_of_16"]["train_edges_per_s"] > 0 and wl["c1"]["batches_of_16"]["batches"] >= 2
