@@ -656,6 +656,28 @@ int launch_gru_bwd_f16_wide(const float* dout, const float* m, const float* h, c
                             const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
                             float* db_ih, float* db_hh, void* workspace, int64_t V, int H, const float* out_norm_k,
                             double* in_norm_sums, const float* in_norm_raw, hipStream_t s);
+size_t gru_bwd_rc_workspace_bytes(int H);                                  // gru_bwd_rc.hip: no per-atom workspace
+bool gru_bwd_rc_covers(int H);
+int launch_gru_bwd_rc(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
+                      const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh, float* db_ih,
+                      float* db_hh, void* workspace, int64_t V, int H, const float* out_norm_k, double* in_norm_sums,
+                      const float* in_norm_raw, hipStream_t s);
+// the wide backward of this width and process: gate gradients formed inside the two contractions (gru_bwd_rc.hip) unless
+// the width has no such kernels yet or MPNN_GRU_BWD=pieces asks for round 3's three-kernel form
+static inline bool gru_bwd_use_rc(int H) { return gru_bwd_rc_covers(H) && !switches().gru_bwd_pieces; }
+static inline size_t gru_bwd_wide_workspace(int64_t V, int H) {
+    return gru_bwd_use_rc(H) ? gru_bwd_rc_workspace_bytes(H) : gru_bwd_f16_workspace_bytes(V, H);
+}
+static inline int launch_gru_bwd_wide(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
+                                      const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
+                                      float* db_ih, float* db_hh, void* workspace, int64_t V, int H, const float* out_norm_k,
+                                      double* in_norm_sums, const float* in_norm_raw, hipStream_t s) {
+    if (gru_bwd_use_rc(H))
+        return launch_gru_bwd_rc(dout, m, h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, workspace, V, H,
+                                 out_norm_k, in_norm_sums, in_norm_raw, s);
+    return launch_gru_bwd_f16_wide(dout, m, h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, workspace, V, H,
+                                   out_norm_k, in_norm_sums, in_norm_raw, s);
+}
 }  // namespace mpnn
 
 // the generic-width backward after the gate-gradient pass (ws = (V, 6H) pre-activation gradients, dh holds g * z):
@@ -700,7 +722,7 @@ extern "C" size_t mpnn_gru_bwd_workspace_bytes(int64_t V, int H) {
     if (V < 0 || H <= 0) return 0;
     if (H == 64) return 16;                                               // one kernel, gate gradients stay in LDS
     if ((H == 128 || H == 256) && !switches().math_fp32)                  // fp16 pieces per 32-atom tile, tile scales,
-        return gru_bwd_f16_workspace_bytes(V, H);                         // pre-split weights of the dm | dh kernel
+        return gru_bwd_wide_workspace(V, H);                              // pre-split weights of the dm | dh kernel (+ pieces, old form)
     return (size_t)V * 6 * H * sizeof(float);                            // generic widths: (dgi | dgh)
 }
 
@@ -729,8 +751,8 @@ extern "C" int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const 
     // hidden 128 / 256: gate gradients as fp16 pieces, split once (gru_bwd128_f16.hip); MPNN_GRU_MATH=fp32 and other
     // widths: elementwise gate gradients into a (V, 6H) workspace + generic fp32 contractions below
     if ((H == 128 || H == 256) && !fp32_only)
-        return launch_gru_bwd_f16_wide(dout, m, h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, workspace, V, H,
-                                       nullptr, nullptr, nullptr, s);
+        return launch_gru_bwd_wide(dout, m, h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, workspace, V, H,
+                                   nullptr, nullptr, nullptr, s);
     hipLaunchKernelGGL(gru_gate_grad_kernel<false>, dim3((unsigned)g), dim3(256), 0, s, dout, h, mask, saved, ws, dh, V,
                        H);
     rc = launch_status("mpnn_gru_update_bwd_f32(gates)");
@@ -795,7 +817,7 @@ int mpnn_gru_update_norm_supported(int H);
 // at H = 64, whose plain backward is one fused kernel)
 extern "C" size_t mpnn_gru_norm_bwd_workspace_bytes(int64_t V, int H) {
     if (V < 0 || H <= 0) return 0;
-    if (mpnn_gru_update_norm_supported(H) == 2) return gru_bwd_f16_workspace_bytes(V, H);
+    if (mpnn_gru_update_norm_supported(H) == 2) return gru_bwd_wide_workspace(V, H);
     return (size_t)V * 6 * H * sizeof(float);
 }
 
@@ -837,6 +859,6 @@ extern "C" int mpnn_gru_update_norm_bwd_f32(const float* dout, const float* m, c
         if (in_norm_sums) return mpnn_norm_bwd_sums_f32(dh_norm, h_raw, nullptr, in_norm_sums, V, H, stream);
         return MPNN_OK;
     }
-    return launch_gru_bwd_f16_wide(dout, m, h_norm, mask, W_ih, W_hh, saved, dm, dh_norm, dW_ih, dW_hh, db_ih, db_hh, workspace,
-                                   V, H, out_norm_k, in_norm_sums, h_raw, (hipStream_t)stream);
+    return launch_gru_bwd_wide(dout, m, h_norm, mask, W_ih, W_hh, saved, dm, dh_norm, dW_ih, dW_hh, db_ih, db_hh, workspace,
+                               V, H, out_norm_k, in_norm_sums, h_raw, (hipStream_t)stream);
 }

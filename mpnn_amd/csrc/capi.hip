@@ -20,6 +20,8 @@ const Switches& switches() {
         Switches s;
         const char* m = getenv("MPNN_GRU_MATH");
         s.math_fp32 = m && !strcmp(m, "fp32");
+        const char* b = getenv("MPNN_GRU_BWD");
+        s.gru_bwd_pieces = b && !strcmp(b, "pieces");
         return s;
     }();
     return sw;

@@ -40,6 +40,7 @@ inline int lds_opt_in_failed(hipError_t e) {
 // mpnn_init() or by the first call that needs one (thread-safe static initialisation in capi.hip).
 struct Switches {
     bool math_fp32;          // MPNN_GRU_MATH=fp32: dense contractions on the fp32 matrix pipe (strict fp32 MFMA, no operand splits)
+    bool gru_bwd_pieces;     // MPNN_GRU_BWD=pieces: the round-3 wide GRU backward (gate gradients through an HBM workspace), for A/B runs
 };
 const Switches& switches();
 

@@ -1,0 +1,778 @@
+// GRU backward at H = 128 WITHOUT a gate-gradient workspace: the two consumers -- dm | dh and dW -- each form the gate
+// gradients they contract in registers, from the slices of (dout, h, r, z, n, gh_n) they read anyway.  Reference:
+// mpnn_functions/update/gru_update.py:26-35 (autograd of it).
+//
+// Why.  The gate gradients (dar daz dan dnh) are COLUMN-LOCAL: entry j of an atom depends on entry j of dout, h and the
+// four saved gate arrays only.  gru_bwd128_f16.hip computes them once in a kernel of their own and hands them to the two
+// contractions through HBM as fp16 pieces (16 H bytes per atom written, then read H / 128 times by dm | dh and again by
+// dW): 96 H bytes per atom for a backward whose operands are 36 H.  Here nothing travels: dm | dh reads 24 H and writes
+// 8 H, dW reads 28 H, 60 H in all, and one launch (and the 16 H B / atom workspace) is gone.
+//
+// dm | dh (gru_rc_dx_kernel) is written TRANSPOSED: out^T[feature][atom] = W[feature][gate column] . G^T[gate column][atom].
+//   * The weights are the A operand (pre-split fp16 images copied global -> LDS, as before); the gate gradients are the B
+//     operand, whose lane layout -- lane (atom = lane & 31, half = lane >> 5) holds 8 k-values of ITS atom -- is what a
+//     lane gets by loading its own atom's row: no exchange between lanes, and the per-atom power-of-two scale of the fp16
+//     pieces is a per-LANE scalar.
+//   * The k order inside a 16-wide step is chosen as k-slot (half, j) <-> column 16 s + 8 (j >> 2) + 4 half + (j & 3): these
+//     are exactly the FEATURES the lane owns in the accumulator of column block cc (row = 8 (i >> 2) + 4 half + (i & 3)), so
+//     the direct term dout * mask * z of dh is added to the accumulator in registers, where round 3 wrote it to HBM in one
+//     kernel and read it back in the next.
+//   * A row's scale cannot wait for the whole row (it would take a pass of its own): it is set from the first 16 columns
+//     with three bits of headroom and lowered -- accumulators multiplied by the ratio, a power of two -- when a later step
+//     outgrows it.  Headroom costs nothing: a value 2^k below its row's largest still has 22 - max(0, k - 10) bits.
+//   * Outputs leave as 16-byte stores (4 consecutive features of one atom); round 3 stored dwords.
+// dW (gru_rc_dw_kernel) keeps round 3's structure (32-atom tiles, row-major fp16 images in LDS, columns by transposed
+// reads) with the gate pieces made in place of copied: thread (row, 8 columns) computes them while the tile before is
+// being contracted, takes the row's exact maximum over its 16 neighbours, and parks the pieces; the bias gradients
+// (column sums) ride in the same registers.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+#include "common.h"
+
+namespace mpnn {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+constexpr int R_IMG = 32 * 256;                        // bytes of one [32 rows][128 x fp16] image (dW kernel)
+constexpr int R_SUB = 2 * 2 * 128 * 16;                // dm | dh: one (matrix, gate) weight sub-image of a 16-wide step: [piece][half][128 rows][8 x fp16]
+constexpr int R_STEP = 6 * R_SUB;                      // 48 KB: (r: ih hh) (z: ih hh) (n: ih) (gh_n: hh)
+
+// power of two s with maxabs * s in [2^(14 - HEAD), 2^(15 - HEAD)), as a biased exponent pair: s = 2^(141 - HEAD - e)
+__device__ __forceinline__ int r_exp(float maxabs) {
+    int e = (__float_as_int(maxabs) >> 23) & 0xff;
+    return e < 51 ? 51 : (e > 187 ? 187 : e);
+}
+__device__ __forceinline__ float r_pow2(int field) { return __int_as_float(field << 23); }
+
+__device__ __forceinline__ float r_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+__device__ __forceinline__ void r_split8(const f32x4& x0, const f32x4& x1, float sc, h16x8& ph, h16x8& pl) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = x0[j] * sc, b = x1[j] * sc;
+        ph[j] = (_Float16)a;
+        pl[j] = (_Float16)(a - (float)ph[j]);
+        ph[4 + j] = (_Float16)b;
+        pl[4 + j] = (_Float16)(b - (float)ph[4 + j]);
+    }
+}
+
+__device__ __forceinline__ void r_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// one wave copies 1 KB global -> LDS without registers (gru_bwd128_f16.hip has the reasons for the inline assembly)
+__device__ __forceinline__ void r_copy_to_lds(const char* src, const char* lds_dst) {
+    typedef __attribute__((address_space(3))) const char lds_char;
+    const unsigned dst = (unsigned)(uintptr_t)(lds_char*)lds_dst;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(dst)
+                 : "memory");
+}
+
+__device__ __forceinline__ h16x8 r_tr8(const char* a0, const char* a1) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a1);
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(h16x8, v);
+}
+
+// the gate gradients of four columns of one atom (gru_update.py:29-34 differentiated).  NORM: dout is the gradient of
+// norm(y), y = this update's output; dy = dout k1 + y k2 + k4 on rows with mask 1 (include/mpnn_amd.h).
+template <bool NORM>
+__device__ __forceinline__ void r_gate_grads4(const f32x4& dout, const f32x4& hv, const f32x4& r, const f32x4& z,
+                                              const f32x4& n, const f32x4& nh, float mk, const f32x4& k1, const f32x4& k2,
+                                              const f32x4& k4, f32x4& dar, f32x4& daz, f32x4& dan, f32x4& dnh, f32x4& gz) {
+    f32x4 g = dout * mk;
+    if (NORM) {
+        const f32x4 y = ((1.0f - z) * n + z * hv) * mk;
+        g = (dout * k1 + y * k2 + k4) * mk;
+    }
+    const f32x4 dn = g * (1.0f - z);
+    const f32x4 dz = g * (hv - n);
+    dan = dn * mk * (1.0f - n * n);                      // n = tanh(.) * mask
+    dar = dan * nh * mk * r * (1.0f - r);
+    daz = dz * mk * z * (1.0f - z);
+    dnh = dan * r;
+    gz = g * z;
+}
+
+__device__ __forceinline__ float r_max4(float m, const f32x4& v) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ dm | dh: weight images
+// grid = NS slices x (H / 16) steps.  Image of (slice, step): six sub-images (r: W_ih W_hh, z: W_ih W_hh, n: W_ih,
+// gh_n: W_hh), each [piece hi | lo][half][128 output features of the slice][8 x fp16]: an A fragment of 32 features is 32
+// consecutive 16-byte entries (conflict-free ds_read_b128).  Entry (half, feature) holds the k-slots j = 0..7 of that half:
+// gate column 16 step + 8 (j >> 2) + 4 half + (j & 3).  One power-of-two scale per slice (float `slice` of the region).
+template <int H>
+__global__ void __launch_bounds__(512) gru_rc_presplit_kernel(const float* __restrict__ W_ih, const float* __restrict__ W_hh,
+                                                              char* __restrict__ ws) {
+    constexpr int NSTEP = H / 16;
+    __shared__ float redw[8];
+    const int slice = blockIdx.x / NSTEP, step = blockIdx.x % NSTEP;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float mx = 0.f;
+    for (int idx = tid; idx < 2 * 128 * (3 * H / 4); idx += 512) {
+        const int mat = idx / (128 * (3 * H / 4)), rem = idx % (128 * (3 * H / 4));
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>((mat ? W_hh : W_ih) + (int64_t)(128 * slice) * 3 * H + 4 * rem);
+        mx = r_max4(mx, w4);
+    }
+    mx = r_wave_max(mx);
+    if (lane == 0) redw[wv] = mx;
+    __syncthreads();
+    mx = redw[0];
+#pragma unroll
+    for (int u = 1; u < 8; ++u) mx = fmaxf(mx, redw[u]);
+    int e = (__float_as_int(mx) >> 23) & 0xff;
+    e = e < 111 ? 111 : (e > 187 ? 187 : e);               // scale in [2^-46, 2^30] (as g_guard_scale<30>)
+    const float sw = r_pow2(268 - e), inv_sw = r_pow2(e - 14);
+    if (step == 0 && tid == 0) reinterpret_cast<float*>(ws)[slice] = inv_sw;
+    char* img = ws + 64 + (int64_t)(slice * NSTEP + step) * R_STEP;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int idx = it * 512 + tid;                    // (sub-image, feature, half)
+        const int sub = idx >> 8, n = (idx & 255) >> 1, hf = idx & 1;
+        const int gate = sub >> 1;                         // sub 0,1: r; 2,3: z; 4: n (W_ih); 5: gh_n (W_hh)
+        const float* src = ((sub & 1) ? W_hh : W_ih) + (int64_t)(128 * slice + n) * 3 * H + gate * H + 16 * step + 4 * hf;
+        h16x8 ph, pl;
+        r_split8(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 8), sw, ph, pl);
+        char* dst = img + sub * R_SUB + hf * 2048 + n * 16;
+        *reinterpret_cast<h16x8*>(dst) = ph;
+        *reinterpret_cast<h16x8*>(dst + 4096) = pl;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ dm | dh
+// Block = 8 waves in two ROLES: waves 4-7 are PRODUCERS (vector pipe: read the row slices, form the gate gradients, scale,
+// split), waves 0-3 are CONSUMERS (matrix pipe: hold the accumulators, 72 MFMAs per step); producer p + 4 and consumer p
+// share a SIMD and a tile of 32 atoms (lane = atom | half) and meet in LDS.  One role per wave because one wave cannot hold
+// both: 128 accumulator registers + the next step's 48 row registers in flight + pieces and fragments is more than the 256
+// registers of a wave at two per SIMD (it spilled), and a wave alone on its SIMD runs its vector and matrix phases one after
+// the other (profiles/r04_gru_bwd_ablation.md has both measurements).  Split, each role fits, and the two pipes of a SIMD
+// work at the same time.
+//   step g, phase 1:  consumers: start the copy of weight image g + 1 -> rescale / direct term of dh (from the producer's
+//                     note) -> 72 MFMAs on (weight image g, pieces g) -> the copy has landed;
+//                     producers: gate gradients of step g + 1 from the row slices requested two steps ago -> pieces in
+//                     registers -> request the slices of step g + 3 into the registers just consumed;
+//            barrier
+//            phase 2: producers park pieces g + 1 (+ direct term, scale note) in LDS;          barrier
+// The consumer's accumulators are transposed (rows = features, columns = atoms): see the head of this file.
+// NORM_OUT: the backward of the norm behind this update is applied to dout (column constants kn = k1 | k2 | k4, in LDS).
+// NORM_IN: `h` = norm(y_in): the column sums of dh and dh * y_in over all atoms go to `sums` (2 H doubles, accumulated).
+template <int H, bool HAS_MASK, bool NORM_OUT, bool NORM_IN>
+__global__ void __launch_bounds__(512) gru_rc_dx_kernel(const float* __restrict__ dout, const float* __restrict__ h,
+                                                        const float* __restrict__ mask, const float* __restrict__ saved,
+                                                        const float* __restrict__ kn, const char* __restrict__ wws,
+                                                        float* __restrict__ dm, float* __restrict__ dh, int64_t V,
+                                                        const float* __restrict__ y_in, double* sums) {
+    constexpr int NS = H / 128, NSTEP = H / 16;
+    // LDS: two weight images | per pair: 8 KB of pieces [segment][hi | lo][lane 16 B], 2 KB direct term [u][lane 16 B],
+    // 512 B note [ratio 64 floats | exponent 64 ints] | (NORM_OUT) kn | (NORM_IN) the sums
+    constexpr int R_PIECES = 2 * R_STEP, R_GZ = R_PIECES + 4 * 8192, R_NOTE = R_GZ + 4 * 2048, R_KN = R_NOTE + 4 * 512;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* kn_s = reinterpret_cast<float*>(smem + R_KN);
+    double* stat_s = reinterpret_cast<double*>(smem + R_KN + (NORM_OUT ? 3 * H * 4 : 0));   // [2][128]
+
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int slice = jb % NS;
+    const int pblock = (jb / NS) * 8 + xcd, pblocks = gridDim.x / NS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = wv & 3;
+    const bool producer = wv >= 4;
+    const int a = lane & 31, hi = lane >> 5;
+    char* my_pieces = smem + R_PIECES + pair * 8192 + lane * 16;
+    char* my_gz = smem + R_GZ + pair * 2048 + lane * 16;
+    float* my_ratio = reinterpret_cast<float*>(smem + R_NOTE + pair * 512) + lane;
+    int* my_exp = reinterpret_cast<int*>(smem + R_NOTE + pair * 512 + 256) + lane;
+
+    const int64_t tiles = (V + 31) / 32;
+    const int64_t rounds_total = (tiles + 3) / 4;              // a round = 4 tiles, one per pair
+    if (pblock >= rounds_total) return;
+    const int64_t nrounds = (rounds_total - pblock + pblocks - 1) / pblocks;
+    const int64_t total = nrounds * NSTEP;
+    if (NORM_OUT)
+        for (int i = tid; i < 3 * H; i += 512) kn_s[i] = kn[i];
+    if (NORM_IN)
+        for (int i = tid; i < 2 * 128; i += 512) stat_s[i] = 0.0;
+    if (NORM_OUT || NORM_IN) __syncthreads();
+    const float inv_sw = reinterpret_cast<const float*>(wws)[slice];
+
+    // the tile of this pair in round rd (clamped to the last tile: such a pair computes and stores nothing new), its row
+    auto tile_of = [&](int64_t rd) {
+        if (rd >= nrounds) rd = nrounds - 1;
+        return ((int64_t)pblock + rd * pblocks) * 4 + pair;
+    };
+    auto row_of = [&](int64_t t) {
+        int64_t rw = t * 32 + a;
+        return rw < V ? rw : V - 1;
+    };
+
+    if (producer) {
+        // ================================================================================================ producers
+        const float sw = 1.0f / inv_sw;
+        struct Rows { f32x4 d[2], hv[2], r[2], z[2], n[2], nh[2]; };
+        auto load_rows = [&](int64_t n) {                  // the slices of global step n (clamped to the last step)
+            Rows q;
+            if (n >= total) n = total - 1;
+            const int st = (int)(n % NSTEP);
+            int64_t rw = row_of(tile_of(n / NSTEP));
+#ifdef MPNN_ABL_RC_HOTROWS      // timing experiment only (wrong results): every tile reads the first 256 atoms' rows (L2-resident)
+            rw &= 255;
+#endif
+            const int c0 = 16 * st + 4 * hi;
+            const float* pd = dout + rw * H + c0;
+            const float* ph = h + rw * H + c0;
+            const float* ps = saved + rw * 4 * H + c0;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                q.d[u] = *reinterpret_cast<const f32x4*>(pd + 8 * u);
+                q.z[u] = *reinterpret_cast<const f32x4*>(ps + H + 8 * u);
+                q.n[u] = *reinterpret_cast<const f32x4*>(ps + 2 * H + 8 * u);
+                q.hv[u] = *reinterpret_cast<const f32x4*>(ph + 8 * u);
+                q.r[u] = *reinterpret_cast<const f32x4*>(ps + 8 * u);
+                q.nh[u] = *reinterpret_cast<const f32x4*>(ps + 3 * H + 8 * u);
+            }
+            return q;
+        };
+        int e_cur = 51;
+        float mk = 0.f;
+        h16x8 ph[4], pl[4];                                // pieces of (dar, daz, dan, dnh), this lane's 8 k-slots
+        f32x4 gz0, gz1;
+        float ratio = 1.0f;
+        // gate gradients of global step n from `q` -> pieces, direct term, scale note (all in registers)
+        auto produce = [&](int64_t n, const Rows& q) {
+            const int st = (int)(n % NSTEP);
+            if (st == 0) {
+                const int64_t t = tile_of(n / NSTEP);
+                const bool live = n / NSTEP < nrounds && t * 32 + a < V;
+                mk = live ? (HAS_MASK ? mask[row_of(t)] : 1.0f) : 0.0f;
+            }
+            f32x4 dar[2], daz[2], dan[2], dnh[2], gz[2];
+            float mx = 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                f32x4 k1 = {0.f, 0.f, 0.f, 0.f}, k2 = k1, k4 = k1;
+                if (NORM_OUT) {
+                    const int c = 16 * st + 4 * hi + 8 * u;
+                    k1 = *reinterpret_cast<const f32x4*>(kn_s + c);
+                    k2 = *reinterpret_cast<const f32x4*>(kn_s + H + c);
+                    k4 = *reinterpret_cast<const f32x4*>(kn_s + 2 * H + c);
+                }
+                r_gate_grads4<NORM_OUT>(q.d[u], q.hv[u], q.r[u], q.z[u], q.n[u], q.nh[u], mk, k1, k2, k4, dar[u], daz[u], dan[u],
+                                        dnh[u], gz[u]);
+                mx = r_max4(r_max4(r_max4(r_max4(mx, dar[u]), daz[u]), dan[u]), dnh[u]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));            // the atom's other half
+            const int e_mx = r_exp(mx);
+            ratio = 1.0f;
+            if (st == 0) {
+                e_cur = e_mx;
+            } else if (e_mx > e_cur + 3) {                 // three bits of headroom are used up
+                ratio = r_pow2(127 + e_cur - e_mx);
+                e_cur = e_mx;
+            }
+            const float sg = r_pow2(265 - e_cur);          // row maximum * sg in [2^11, 2^12) when set, < 2^16 always
+            const float gsc = sg * sw;
+            gz0 = gz[0] * gsc;
+            gz1 = gz[1] * gsc;
+            r_split8(dar[0], dar[1], sg, ph[0], pl[0]);
+            r_split8(daz[0], daz[1], sg, ph[1], pl[1]);
+            r_split8(dan[0], dan[1], sg, ph[2], pl[2]);
+            r_split8(dnh[0], dnh[1], sg, ph[3], pl[3]);
+        };
+        auto park = [&]() {
+#pragma unroll
+            for (int sgm = 0; sgm < 4; ++sgm) {
+                *reinterpret_cast<h16x8*>(my_pieces + sgm * 2048) = ph[sgm];
+                *reinterpret_cast<h16x8*>(my_pieces + sgm * 2048 + 1024) = pl[sgm];
+            }
+            *reinterpret_cast<f32x4*>(my_gz) = gz0;
+            *reinterpret_cast<f32x4*>(my_gz + 1024) = gz1;
+            *my_ratio = ratio;
+            *my_exp = e_cur;
+        };
+        Rows ra = load_rows(0), rb = load_rows(1);
+        produce(0, ra);
+        ra = load_rows(2);
+        park();
+        r_barrier_lds();                                   // (P0) pieces of step 0 are parked, weight image 0 has landed
+        // one step: pieces of step g + 1 from `q` (requested two steps ago), then `q` takes the slices of step g + 3
+#define RC_PRODUCER_STEP(G, Q)                                                                       \
+    {                                                                                                \
+        const bool more = (G) + 1 < total;                                                           \
+        if (more) produce((G) + 1, Q);                                                               \
+        Q = load_rows((G) + 3);                                                                      \
+        r_barrier_lds(); /* (B1) the consumers are done with pieces g */                             \
+        if (more) park();                                                                            \
+        r_barrier_lds(); /* (B2) */                                                                  \
+    }
+#pragma unroll 1
+        for (int64_t g = 0; g < total; g += 2) {
+            RC_PRODUCER_STEP(g, rb)
+            RC_PRODUCER_STEP(g + 1, ra)
+        }
+#undef RC_PRODUCER_STEP
+    } else {
+    // ==================================================================================================== consumers
+    // this wave's share of weight image `st` -> buffer buf: twelve 1 KB copies
+    auto w_issue = [&](int st, int buf) {
+        const char* src = wws + 64 + (int64_t)(slice * NSTEP + st) * R_STEP + lane * 16;
+        const char* dst = smem + buf * R_STEP;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) r_copy_to_lds(src + (12 * pair + i) * 1024, dst + (12 * pair + i) * 1024);
+    };
+    f32x16 d_m[4], d_h[4];
+    auto afrag = [&](const char* wb, int sub, int piece, int nb) {
+        return *reinterpret_cast<const h16x8*>(wb + sub * R_SUB + piece * 4096 + hi * 2048 + (32 * nb + a) * 16);
+    };
+    // one gate segment's pieces against the sub-images `sub0` -> d0 and (sub1 >= 0) `sub1` -> d1
+    auto product = [&](int sgm, const char* wb, f32x16 (&d0)[4], int sub0, f32x16 (&d1)[4], int sub1) {
+        const h16x8 gh = *reinterpret_cast<const h16x8*>(my_pieces + sgm * 2048);
+        const h16x8 gl = *reinterpret_cast<const h16x8*>(my_pieces + sgm * 2048 + 1024);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const h16x8 w0h = afrag(wb, sub0, 0, nb), w0l = afrag(wb, sub0, 1, nb);
+            d0[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0l, gh, d0[nb], 0, 0, 0);
+            if (sub1 >= 0) {
+                const h16x8 w1h = afrag(wb, sub1, 0, nb), w1l = afrag(wb, sub1, 1, nb);
+                d1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1l, gh, d1[nb], 0, 0, 0);
+                d0[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0h, gl, d0[nb], 0, 0, 0);
+                d1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h, gl, d1[nb], 0, 0, 0);
+                d0[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0h, gh, d0[nb], 0, 0, 0);
+                d1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h, gh, d1[nb], 0, 0, 0);
+            } else {
+                d0[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0h, gl, d0[nb], 0, 0, 0);
+                d0[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0h, gh, d0[nb], 0, 0, 0);
+            }
+        }
+    };
+    // the direct term of dh, into the accumulator entries this lane owns: block nb, entries 8 s + 4 u + t
+    auto add_gz = [&](int nb, int s, const f32x4& g0, const f32x4& g1) {
+#define RC_ADD(NB, S)                                                                                                  \
+    case 2 * NB + S:                                                                                                   \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) { d_h[NB][8 * S + t] += g0[t]; d_h[NB][8 * S + 4 + t] += g1[t]; } \
+        break;
+        switch (2 * nb + s) {
+            RC_ADD(0, 0) RC_ADD(0, 1) RC_ADD(1, 0) RC_ADD(1, 1) RC_ADD(2, 0) RC_ADD(2, 1) RC_ADD(3, 0) RC_ADD(3, 1)
+            default: break;
+        }
+#undef RC_ADD
+    };
+
+    w_issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    r_barrier_lds();                                       // (P0)
+    int st = 0;
+    int64_t rd = 0;
+#pragma unroll 1
+    for (int64_t g = 0; g < total; ++g) {
+        const int buf = (int)(g & 1);
+        if (g + 1 < total) w_issue(st + 1 == NSTEP ? 0 : st + 1, buf ^ 1);
+        if (st == 0) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { d_m[nb][i] = 0.f; d_h[nb][i] = 0.f; }
+        } else {
+            const float ratio = *my_ratio;                 // < 1 where this step's gradients outgrew the atom's scale
+            if (__builtin_amdgcn_ballot_w64(ratio != 1.0f) != 0) {
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { d_m[nb][i] *= ratio; d_h[nb][i] *= ratio; }
+            }
+        }
+        {
+            const int nb = (st >> 1) - 4 * slice;
+            if (nb >= 0 && nb < 4)
+                add_gz(nb, st & 1, *reinterpret_cast<const f32x4*>(my_gz), *reinterpret_cast<const f32x4*>(my_gz + 1024));
+        }
+        const char* wb = smem + buf * R_STEP;
+        product(0, wb, d_m, 0, d_h, 1);
+        product(1, wb, d_m, 2, d_h, 3);
+        product(2, wb, d_m, 4, d_h, -1);
+        product(3, wb, d_h, 5, d_m, -1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of weight image g + 1 has landed
+        if (st + 1 == NSTEP) {
+            // ---- epilogue: this lane's atom, 16 x 4 consecutive features of dm and of dh
+            const int64_t t = tile_of(rd);
+            const int64_t row = row_of(t);
+            const bool on = t * 32 + a < V;
+            const float un = r_pow2(*my_exp - 11) * inv_sw;                    // 1 / (sg * sw)
+            if (on) {
+                float* pm = dm + row * H + 128 * slice + 4 * hi;
+                float* pq = dh + row * H + 128 * slice + 4 * hi;
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 vm = {d_m[nb][4 * q], d_m[nb][4 * q + 1], d_m[nb][4 * q + 2], d_m[nb][4 * q + 3]};
+                        const f32x4 vh = {d_h[nb][4 * q], d_h[nb][4 * q + 1], d_h[nb][4 * q + 2], d_h[nb][4 * q + 3]};
+                        *reinterpret_cast<f32x4*>(pm + 32 * nb + 8 * q) = vm * un;
+                        *reinterpret_cast<f32x4*>(pq + 32 * nb + 8 * q) = vh * un;
+                    }
+            }
+            if (NORM_IN) {
+                // column sums over the tile's atoms of dh and dh * y_in: per accumulator entry a butterfly over the 32 lanes
+                // of the half, then one LDS add per feature
+                const float uz = on ? un : 0.0f;
+                const float* py = y_in + row * H + 128 * slice + 4 * hi;
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 yv = *reinterpret_cast<const f32x4*>(py + 32 * nb + 8 * q);
+#pragma unroll
+                        for (int t4 = 0; t4 < 4; ++t4) {
+                            float s1 = d_h[nb][4 * q + t4] * uz, s2 = s1 * yv[t4];
+#pragma unroll
+                            for (int o = 16; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+                            if (a == 0) {
+                                const int f = 32 * nb + 8 * q + 4 * hi + t4;
+                                atomicAdd(&stat_s[f], (double)s1);
+                                atomicAdd(&stat_s[128 + f], (double)s2);
+                            }
+                        }
+                    }
+            }
+            ++rd;
+            st = 0;
+        } else {
+            ++st;
+        }
+        r_barrier_lds();                                   // (B1) pieces g are consumed
+        r_barrier_lds();                                   // (B2) pieces g + 1 are parked
+    }
+    }   // consumers
+    if (NORM_IN) {
+        __syncthreads();                                   // both roles arrive here after the same number of barriers
+        if (tid < 256) atomicAdd(sums + (tid >> 7) * H + 128 * slice + (tid & 127), stat_s[tid]);
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------- dW
+// H = 128.  Block type = matrix: dW_ih = m^T [dar daz dan], dW_hh = h^T [dar daz dnh] (128 x 384 each = 4 x 12 tiles of
+// 32 x 32; wave = 2 a-tiles x 3 b-tiles).  LDS per buffer: four images x two pieces (slots 0-2 the gate segments, 3 = X), an
+// image = [kstep 8][32 rows][16 columns] of a 32-atom tile; two buffers.  Thread (row = tid >> 4, columns 8 (tid & 15) ..)
+// owns the SAME 8 columns of every array: it reads them two tiles ahead of their contraction (seven 32-byte slices), forms
+// the three gate segments while the tile before is contracted, takes the row's maximum over the 16 lanes that share the
+// row (the pieces' power-of-two scale sg_row: the largest magnitude lands in [2^14, 2^15)), parks the pieces, and keeps the
+// column sums (bias gradients).  m | h is split behind sx_row = C / sg_row, C = running minimum over the block's tiles of
+// (smallest sg_row of the tile) x (best scale of the tile's m | h): every product carries C (gru_bwd_f16.hip has the argument).
+template <bool HAS_MASK, bool NORM_OUT>
+__global__ void __launch_bounds__(512) gru_rc_dw_kernel(const float* __restrict__ dout, const float* __restrict__ m,
+                                                        const float* __restrict__ h, const float* __restrict__ mask,
+                                                        const float* __restrict__ saved, const float* __restrict__ kn,
+                                                        float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, int64_t V) {
+    constexpr int H = 128, NB = 3, NACC = 6;
+    constexpr int BUF = 8 * R_IMG;             // image (piece, slot) at (4 * piece + slot) * R_IMG
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem + 2 * BUF);              // [2 parities][max |x| 8 | max 1/sg 8]
+    float* bsum = reinterpret_cast<float*>(smem);                        // (after the loop) column sums across the waves
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int mat = jb & 1;                                    // the two matrices' blocks of a tile stream sit on one XCD
+    const float* X = mat == 0 ? m : h;
+    const int64_t tiles = (V + 31) / 32;
+    const int64_t t0 = (jb >> 1) * 8 + xcd, tstep = gridDim.x / 2;
+    if (t0 >= tiles) return;
+
+    const int srow = tid >> 4, c16 = tid & 15;
+    const int p_dst = (c16 >> 1) * 1024 + srow * 32 + (c16 & 1) * 16;   // this thread's 16 bytes inside an image
+    struct Rows { f32x4 d[2], hv[2], r[2], z[2], n[2], nh[2], x[2]; float mk; };
+    auto load_rows = [&](int64_t t) {
+        Rows q;
+        int64_t row = t * 32 + srow;
+        const bool ok = row < V;
+        if (!ok) row = V - 1;
+#ifdef MPNN_ABL_RC_HOTROWS      // timing experiment only (wrong results): every tile reads the first 256 atoms' rows (L2-resident)
+        row &= 255;
+#endif
+        q.mk = ok ? (HAS_MASK ? mask[row] : 1.0f) : 0.0f;
+        const int c8 = 8 * c16;
+        const float* ps = saved + row * 4 * H + c8;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            q.d[u] = *reinterpret_cast<const f32x4*>(dout + row * H + c8 + 4 * u);
+            q.hv[u] = *reinterpret_cast<const f32x4*>(h + row * H + c8 + 4 * u);
+            q.r[u] = *reinterpret_cast<const f32x4*>(ps + 4 * u);
+            q.z[u] = *reinterpret_cast<const f32x4*>(ps + H + 4 * u);
+            q.n[u] = *reinterpret_cast<const f32x4*>(ps + 2 * H + 4 * u);
+            q.nh[u] = *reinterpret_cast<const f32x4*>(ps + 3 * H + 4 * u);
+            q.x[u] = *reinterpret_cast<const f32x4*>(X + row * H + c8 + 4 * u) * (ok ? 1.0f : 0.0f);   // rows past V count as zeros
+        }
+        return q;
+    };
+    float cs[3][8];                                            // column sums of the three segments, this thread's 8 columns
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cs[s][u] = 0.f;
+    unsigned kofs = 0;
+    if (NORM_OUT) asm volatile("" : "+v"(kofs));               // (opaque: the column constants are re-read per tile, not kept)
+
+    // gate pieces of one tile -> buffer T; returns this row's 1 / sg
+    auto park_gates = [&](const Rows& q, char* T) {
+        f32x4 seg[3][2];
+        float mx = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f32x4 k1 = {0.f, 0.f, 0.f, 0.f}, k2 = k1, k4 = k1;
+            if (NORM_OUT) {
+                const float* kp = kn + kofs + 8 * c16 + 4 * u;
+                k1 = *reinterpret_cast<const f32x4*>(kp);
+                k2 = *reinterpret_cast<const f32x4*>(kp + H);
+                k4 = *reinterpret_cast<const f32x4*>(kp + 2 * H);
+            }
+            f32x4 dar, daz, dan, dnh, gz;
+            r_gate_grads4<NORM_OUT>(q.d[u], q.hv[u], q.r[u], q.z[u], q.n[u], q.nh[u], q.mk, k1, k2, k4, dar, daz, dan, dnh, gz);
+            seg[0][u] = dar;
+            seg[1][u] = daz;
+            seg[2][u] = mat == 0 ? dan : dnh;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                mx = r_max4(mx, seg[s][u]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) cs[s][4 * u + t] += seg[s][u][t];
+            }
+        }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        const int e = r_exp(mx);
+        const float sg = r_pow2(268 - e);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            h16x8 ph, pl;
+            r_split8(seg[s][0], seg[s][1], sg, ph, pl);
+            *reinterpret_cast<h16x8*>(T + s * R_IMG + p_dst) = ph;
+            *reinterpret_cast<h16x8*>(T + (4 + s) * R_IMG + p_dst) = pl;
+        }
+        return r_pow2(e - 14);
+    };
+    auto publish = [&](const Rows& q, float inv_sg, int par) {
+        float mx = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) mx = r_max4(mx, q.x[u]);
+        mx = r_wave_max(mx);
+        const float iv = r_wave_max(inv_sg);               // largest inverse = the scale of the tile's largest row
+        if (lane == 0) { red[16 * par + wv] = mx; red[16 * par + 8 + wv] = iv; }
+    };
+    float C_run = 3.0e38f;
+    auto park_x = [&](const Rows& q, float inv_sg, char* T, int par) {   // after the barrier that follows publish()
+        float xm = red[16 * par], ivm = red[16 * par + 8];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) { xm = fmaxf(xm, red[16 * par + u]); ivm = fmaxf(ivm, red[16 * par + 8 + u]); }
+        int ex = (__float_as_int(xm) >> 23) & 0xff;
+        ex = ex < 111 ? 111 : (ex > 187 ? 187 : ex);
+        const float sxo = r_pow2(268 - ex);
+        const float sgm = r_pow2(254 - ((__float_as_int(ivm) >> 23) & 0xff));
+        C_run = fminf(C_run, sgm * sxo);
+        const float sx = C_run * inv_sg;
+        h16x8 ph, pl;
+        r_split8(q.x[0], q.x[1], sx, ph, pl);
+        *reinterpret_cast<h16x8*>(T + 3 * R_IMG + p_dst) = ph;
+        *reinterpret_cast<h16x8*>(T + 7 * R_IMG + p_dst) = pl;
+    };
+
+    // transposed reads (as gru_bwd128_f16.hip): a 16-lane group takes rows 8 (g2 >> 1) + 4 j + (0..3), columns 16 (g2 & 1) +
+    // (0..15) of 32-column block cb of an image; lane 4 q + p supplies row q, columns 4 p .. 4 p + 3
+    const int ag = wv & 1, bg = wv >> 1;
+    const int g2 = lane >> 4, u16 = lane & 15, q4 = u16 >> 2, p4 = u16 & 3;
+    auto tr_addr = [&](int slot, int cb, int j) {
+        return slot * R_IMG + (2 * cb + (g2 & 1)) * 1024 + (8 * (g2 >> 1) + 4 * j + q4) * 32 + p4 * 8;
+    };
+    int LA[NB][2], LX[2][2];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) LA[b][j] = tr_addr((NB * bg + b) >> 2, (NB * bg + b) & 3, j);
+#pragma unroll
+    for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) LX[a2][j] = tr_addr(3, 2 * ag + a2, j);
+
+    f32x16 R[NACC];
+#pragma unroll
+    for (int j = 0; j < NACC; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) R[j][q] = 0.f;
+
+    Rows nxt;                                              // tile t + 1's slices while tile t is contracted
+    {
+        const Rows first = load_rows(t0);
+        nxt = load_rows(t0 + tstep < tiles ? t0 + tstep : t0);
+        const float iv = park_gates(first, smem);
+        publish(first, iv, 0);
+        __syncthreads();
+        park_x(first, iv, smem, 0);
+    }
+    float C_acc = C_run, C_cur = C_run;
+    int cur = 0;
+#pragma unroll 1
+    for (int64_t t = t0; t < tiles; t += tstep) {
+        r_barrier_lds();                                   // buffer `cur` is complete; the other one is free
+        const char* T = smem + cur * BUF;
+        char* Tn = smem + (cur ^ 1) * BUF;
+        const bool has1 = t + tstep < tiles;
+        // tile t + 1: gate pieces into the free buffer (vector work, beside the matrix work on tile t below), then its
+        // registers take tile t + 2
+        float iv = 0.f;
+        if (has1) iv = park_gates(nxt, Tn);
+        const f32x4 x0 = nxt.x[0], x1 = nxt.x[1];
+        const int64_t t2 = t + 2 * tstep;
+        Rows keep;                                         // (only x of tile t + 1 is still needed)
+        keep.x[0] = x0; keep.x[1] = x1;
+        nxt = load_rows(t2 < tiles ? t2 : t);              // unconditional, clamped
+        if (__builtin_amdgcn_readfirstlane(__float_as_int(C_cur)) != __builtin_amdgcn_readfirstlane(__float_as_int(C_acc))) {
+            const float ratio = C_cur / C_acc;             // < 1, a power of two
+#pragma unroll
+            for (int j = 0; j < NACC; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) R[j][q] *= ratio;
+            C_acc = C_cur;
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const char* Tb = T + 512 * st;                 // rows +16
+            const h16x8 a0h = r_tr8(Tb + LX[0][0], Tb + LX[0][1]);
+            const h16x8 a0l = r_tr8(Tb + 4 * R_IMG + LX[0][0], Tb + 4 * R_IMG + LX[0][1]);
+            const h16x8 a1h = r_tr8(Tb + LX[1][0], Tb + LX[1][1]);
+            const h16x8 a1l = r_tr8(Tb + 4 * R_IMG + LX[1][0], Tb + 4 * R_IMG + LX[1][1]);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const h16x8 bh = r_tr8(Tb + LA[b][0], Tb + LA[b][1]);
+                const h16x8 bl = r_tr8(Tb + 4 * R_IMG + LA[b][0], Tb + 4 * R_IMG + LA[b][1]);
+                R[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, bh, R[b], 0, 0, 0);
+                R[NB + b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, bh, R[NB + b], 0, 0, 0);
+                R[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bl, R[b], 0, 0, 0);
+                R[NB + b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bl, R[NB + b], 0, 0, 0);
+                R[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bh, R[b], 0, 0, 0);
+                R[NB + b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bh, R[NB + b], 0, 0, 0);
+            }
+        }
+        if (has1) {
+            publish(keep, iv, cur ^ 1);
+            r_barrier_lds();                               // the maxima of tile t + 1 are in LDS
+            park_x(keep, iv, Tn, cur ^ 1);
+            C_cur = C_run;
+        }
+        cur ^= 1;
+    }
+    const float inv_C = 1.0f / C_acc;
+    float* dW = mat == 0 ? dW_ih : dW_hh;
+#pragma unroll
+    for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int col = 32 * (NB * bg + b) + i;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = 32 * (2 * ag + a2) + acc_row(q, lane);
+                atomicAdd(dW + (int64_t)row * 3 * H + col, R[NB * a2 + b][q] * inv_C);
+            }
+        }
+    // bias gradients: rows of one column group sit 16 lanes apart in a wave; then across the eight waves through LDS
+    __syncthreads();                                        // (every wave is done with the tile buffers)
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            float v = cs[s][u];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (lane < 16) bsum[(wv * 16 + lane) * 25 + 8 * s + u] = v;
+        }
+    __syncthreads();
+    for (int idx = tid; idx < 16 * 24; idx += 512) {
+        const int cg = idx / 24, k = idx % 24, s = k >> 3;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += bsum[(w * 16 + cg) * 25 + k];
+        const int col = 8 * cg + (k & 7);
+        if (mat == 0) {                                    // dar, daz, dan: db_ih whole, and the r, z blocks of db_hh
+            atomicAdd(db_ih + s * H + col, v);
+            if (s < 2) atomicAdd(db_hh + s * H + col, v);
+        } else if (s == 2) {                               // dnh: the n block of db_hh
+            atomicAdd(db_hh + 2 * H + col, v);
+        }
+    }
+}
+
+// one float per slice, then the step images of the dm | dh kernel
+size_t gru_bwd_rc_workspace_bytes(int H) { return 64 + (size_t)(H / 128) * (H / 16) * R_STEP; }
+bool gru_bwd_rc_covers(int H) { return H == 128; }
+
+template <bool HAS_MASK, bool NORM_OUT, bool NORM_IN>
+static int launch_rc_128(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
+                         const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh,
+                         float* db_ih, float* db_hh, void* workspace, int64_t V, const float* out_norm_k, double* in_norm_sums,
+                         const float* in_norm_raw, hipStream_t s) {
+    constexpr int H = 128;
+    const int64_t tiles = (V + 31) / 32;
+    char* dxw = (char*)workspace;
+    const size_t lds_dx = (size_t)2 * R_STEP + 4 * (8192 + 2048 + 512) + (NORM_OUT ? 3 * H * 4 : 0) + (NORM_IN ? 2 * 128 * 8 : 0);
+    const size_t lds_dw = (size_t)2 * 8 * R_IMG + 128;
+    static const hipError_t attr_done = [&] {   // once per process and instantiation, thread-safe (C++11 static initialisation)
+        LdsOptIn opt_in_;
+        opt_in_((const void*)gru_rc_dx_kernel<H, HAS_MASK, NORM_OUT, NORM_IN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dx);
+        opt_in_((const void*)gru_rc_dw_kernel<HAS_MASK, NORM_OUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dw);
+        return opt_in_.err;
+    }();
+    if (attr_done != hipSuccess) return lds_opt_in_failed(attr_done);
+
+    hipLaunchKernelGGL(gru_rc_presplit_kernel<H>, dim3((unsigned)(H / 16)), dim3(512), 0, s, W_ih, W_hh, dxw);
+    {
+        const int64_t rounds = (tiles + 3) / 4;
+        int64_t pblocks = 256;                               // one block per CU
+        if (pblocks > rounds) pblocks = rounds;
+        pblocks = (pblocks + 7) / 8 * 8;
+        hipLaunchKernelGGL((gru_rc_dx_kernel<H, HAS_MASK, NORM_OUT, NORM_IN>), dim3((unsigned)pblocks), dim3(512), lds_dx, s,
+                           dout, h, mask, saved, out_norm_k, (const char*)dxw, dm, dh, V, in_norm_raw, in_norm_sums);
+    }
+    int rc = launch_status("mpnn_gru_update_bwd_f32(dm | dh, gate gradients in registers)");
+    if (rc) return rc;
+    int64_t gx = 128;                                        // tile streams per matrix: one block per CU, whole XCD groups
+    while (gx > 8 && gx - 8 >= tiles) gx -= 8;
+    hipLaunchKernelGGL((gru_rc_dw_kernel<HAS_MASK, NORM_OUT>), dim3((unsigned)(gx * 2)), dim3(512), lds_dw, s, dout, m, h, mask,
+                       saved, out_norm_k, dW_ih, dW_hh, db_ih, db_hh, V);
+    return launch_status("mpnn_gru_update_bwd_f32(dW, gate gradients in registers)");
+}
+
+int launch_gru_bwd_rc(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
+                      const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh, float* db_ih,
+                      float* db_hh, void* workspace, int64_t V, int H, const float* out_norm_k, double* in_norm_sums,
+                      const float* in_norm_raw, hipStream_t s) {
+#define RC_GO(M, NO, NI)                                                                                                  \
+    return launch_rc_128<M, NO, NI>(dout, m, h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, workspace, V,   \
+                                    out_norm_k, in_norm_sums, in_norm_raw, s)
+    const bool no = out_norm_k != nullptr, ni = in_norm_sums != nullptr;
+    if (mask) {
+        if (no && ni) RC_GO(true, true, true);
+        if (no) RC_GO(true, true, false);
+        if (ni) RC_GO(true, false, true);
+        RC_GO(true, false, false);
+    }
+    if (no && ni) RC_GO(false, true, true);
+    if (no) RC_GO(false, true, false);
+    if (ni) RC_GO(false, false, true);
+    RC_GO(false, false, false);
+#undef RC_GO
+}
+
+}  // namespace mpnn
