@@ -79,10 +79,22 @@ def _stale():
         return True
 
 
+def file_flags(src):
+    """Extra hipcc flags a source asks for in a `// hipcc-flags: ...` line among its first lines (they are part of the file,
+    so the content hash of the sources covers them)."""
+    with open(src) as f:
+        head = [next(f, "") for _ in range(8)]
+    out = []
+    for line in head:
+        if line.startswith("// hipcc-flags:"):
+            out += line[len("// hipcc-flags:"):].split("(")[0].split()
+    return out
+
+
 def _compile_one(job):
     hipcc, src, obj, verbose = job
     tmp = "%s.%d.tmp" % (obj, os.getpid())
-    cmd = [hipcc] + [f for f in FLAGS if f != "-shared"] + ["-c", src, "-o", tmp]
+    cmd = [hipcc] + [f for f in FLAGS if f != "-shared"] + file_flags(src) + ["-c", src, "-o", tmp]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -25,6 +25,8 @@
 // reads) with the gate pieces made in place of copied: thread (row, 8 columns) computes them while the tile before is
 // being contracted, takes the row's exact maximum over its 16 neighbours, and parks the pieces; the bias gradients
 // (column sums) ride in the same registers.
+// hipcc-flags: -fno-slp-vectorize      (mpnn_amd/build.py: per-file flags.  Adjacent scalar multiplies must stay scalar here:
+//                                      packed fp32 instructions are an anti-lever beside MFMAs, MI355X_MICROARCH.md)
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <string.h>
@@ -34,6 +36,14 @@ namespace mpnn {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+#ifdef RC_STAMP   // diagnostic build only (-DRC_STAMP): cycle sums per part of a step, block 3, consumer 0 and producer 4 (dm | dh), waves 0 and 7 (dW)
+__device__ unsigned long long g_rc_stamps[64];
+#define RC_T(var) unsigned long long var; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0)
+#define RC_ADD_STAMP(slot, val) atomicAdd(g_rc_stamps + (slot), (unsigned long long)(val))
+#else
+#define RC_T(var)
+#endif
 
 namespace {
 constexpr int R_IMG = 32 * 256;                        // bytes of one [32 rows][128 x fp16] image (dW kernel)
@@ -47,10 +57,22 @@ __device__ __forceinline__ int r_exp(float maxabs) {
 }
 __device__ __forceinline__ float r_pow2(int field) { return __int_as_float(field << 23); }
 
+// maximum over the 16 lanes of a DPP row (every lane gets it): two quad permutes, then rotations by 4 and 8 within the row
+__device__ __forceinline__ float r_row16_max(float v) {
+    int x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]
+    v = fmaxf(v, __int_as_float(x));
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true);          // quad_perm [2,3,0,1]
+    v = fmaxf(v, __int_as_float(x));
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, true);         // row_ror:4
+    v = fmaxf(v, __int_as_float(x));
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, true);         // row_ror:8
+    return fmaxf(v, __int_as_float(x));
+}
+
+// maximum over the wave (every lane gets it): the four rows' maxima by readlane
 __device__ __forceinline__ float r_wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    v = r_row16_max(v);
+    return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
 }
 
 __device__ __forceinline__ void r_split8(const f32x4& x0, const f32x4& x1, float sc, h16x8& ph, h16x8& pl) {
@@ -64,6 +86,16 @@ __device__ __forceinline__ void r_split8(const f32x4& x0, const f32x4& x1, float
     }
 }
 
+typedef _Float16 r_h16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void r_split4(const f32x4& x, float sc, r_h16x4& ph, r_h16x4& pl) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float v = x[j] * sc;
+        ph[j] = (_Float16)v;
+        pl[j] = (_Float16)(v - (float)ph[j]);
+    }
+}
+
 __device__ __forceinline__ void r_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // one wave copies 1 KB global -> LDS without registers (gru_bwd128_f16.hip has the reasons for the inline assembly)
@@ -74,6 +106,17 @@ __device__ __forceinline__ void r_copy_to_lds(const char* src, const char* lds_d
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(src), "s"(dst)
+                 : "memory");
+}
+
+// the same with a wave-uniform base in scalar registers and a 32-bit lane offset: no 64-bit address per copy and lane to keep
+__device__ __forceinline__ void r_copy_to_lds_s(const char* sbase, unsigned voff, const char* lds_dst) {
+    typedef __attribute__((address_space(3))) const char lds_char;
+    const unsigned dst = (unsigned)(uintptr_t)(lds_char*)lds_dst;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(dst)
                  : "memory");
 }
 
@@ -92,18 +135,32 @@ template <bool NORM>
 __device__ __forceinline__ void r_gate_grads4(const f32x4& dout, const f32x4& hv, const f32x4& r, const f32x4& z,
                                               const f32x4& n, const f32x4& nh, float mk, const f32x4& k1, const f32x4& k2,
                                               const f32x4& k4, f32x4& dar, f32x4& daz, f32x4& dan, f32x4& dnh, f32x4& gz) {
-    f32x4 g = dout * mk;
-    if (NORM) {
-        const f32x4 y = ((1.0f - z) * n + z * hv) * mk;
-        g = (dout * k1 + y * k2 + k4) * mk;
+    // (element by element on purpose: written on 4-vectors these become v_pk_* instructions, which cost the vector pipe
+    // three times a plain one while the SIMD's other wave issues MFMAs -- 12 cycles per instruction measured in the producers)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float g = dout[t] * mk;
+        if (NORM) {
+            const float y = ((1.0f - z[t]) * n[t] + z[t] * hv[t]) * mk;
+            g = (dout[t] * k1[t] + y * k2[t] + k4[t]) * mk;
+        }
+        const float omz = 1.0f - z[t];
+        const float gm = g * mk;
+        const float a_n = gm * omz * (1.0f - n[t] * n[t]);   // n = tanh(.) * mask
+        dan[t] = a_n;
+        dar[t] = a_n * nh[t] * mk * r[t] * (1.0f - r[t]);
+        daz[t] = gm * (hv[t] - n[t]) * z[t] * omz;
+        dnh[t] = a_n * r[t];
+        gz[t] = g * z[t];
     }
-    const f32x4 dn = g * (1.0f - z);
-    const f32x4 dz = g * (hv - n);
-    dan = dn * mk * (1.0f - n * n);                      // n = tanh(.) * mask
-    dar = dan * nh * mk * r * (1.0f - r);
-    daz = dz * mk * z * (1.0f - z);
-    dnh = dan * r;
-    gz = g * z;
+}
+
+// maximum over the 4 lanes of a quad, by DPP (no trip through the LDS crossbar, which the consumers keep busy)
+__device__ __forceinline__ float r_quad_max(float v) {
+    int x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]
+    v = fmaxf(v, __int_as_float(x));
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true);          // quad_perm [2,3,0,1]
+    return fmaxf(v, __int_as_float(x));
 }
 
 __device__ __forceinline__ float r_max4(float m, const f32x4& v) {
@@ -171,153 +228,202 @@ __global__ void __launch_bounds__(512) gru_rc_presplit_kernel(const float* __res
 // The consumer's accumulators are transposed (rows = features, columns = atoms): see the head of this file.
 // NORM_OUT: the backward of the norm behind this update is applied to dout (column constants kn = k1 | k2 | k4, in LDS).
 // NORM_IN: `h` = norm(y_in): the column sums of dh and dh * y_in over all atoms go to `sums` (2 H doubles, accumulated).
+// a value every lane holds alike, moved to scalar registers (what the callee of a non-inlined call cannot know by itself)
+template <typename T>
+__device__ __forceinline__ T* r_uniform(T* p) {
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (T*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ int64_t r_uniform(int64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ int r_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float r_uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+struct RcDxCtx {
+    const float *dout, *h, *mask, *saved, *y_in;
+    const char* wws;
+    float *dm, *dh;
+    int64_t V, tiles, nrounds, total;
+    int slice, pblock, pblocks, pair;
+    float inv_sw;
+};
+// LDS of the dm | dh kernel: two weight images | per pair: 8 KB of pieces [segment][hi | lo][position 16 B], 2 KB direct term
+// [u][position 16 B], 512 B note [ratio 64 floats | exponent 64 ints] | per consumer 4.5 KB for the epilogue's transposition
+// | (NORM_OUT) kn | (NORM_IN) the sums
+constexpr int R_PIECES = 2 * R_STEP, R_GZ = R_PIECES + 4 * 8192, R_NOTE = R_GZ + 4 * 2048, R_EPI = R_NOTE + 4 * 512;
+constexpr int R_KN = R_EPI + 4 * 4608;
+
+#define RC_DX_PROLOGUE()                                                                                                  \
+    constexpr int NSTEP = H / 16;                                                                                         \
+    extern __shared__ __attribute__((aligned(16))) char smem[];                                                           \
+    float* kn_s = reinterpret_cast<float*>(smem + R_KN);                                                                  \
+    double* stat_s = reinterpret_cast<double*>(smem + R_KN + (NORM_OUT ? 3 * H * 4 : 0));                                 \
+    (void)kn_s; (void)stat_s;                                                                                             \
+    const float *dout = r_uniform(c.dout), *h = r_uniform(c.h), *mask = r_uniform(c.mask), *saved = r_uniform(c.saved);   \
+    const float* y_in = r_uniform(c.y_in);                                                                                \
+    const char* wws = r_uniform(c.wws);                                                                                   \
+    float *dm = r_uniform(c.dm), *dh = r_uniform(c.dh);                                                                   \
+    (void)dout; (void)h; (void)mask; (void)saved; (void)y_in; (void)wws; (void)dm; (void)dh;                              \
+    const int64_t V = r_uniform(c.V), tiles = r_uniform(c.tiles), nrounds = r_uniform(c.nrounds), total = r_uniform(c.total); \
+    (void)tiles;                                                                                                          \
+    const int slice = r_uniform(c.slice), pblock = r_uniform(c.pblock), pblocks = r_uniform(c.pblocks), pair = r_uniform(c.pair); \
+    (void)slice;                                                                                                          \
+    const float inv_sw = r_uniform(c.inv_sw);                                                                             \
+    const int lane = threadIdx.x & 63;                                                                                    \
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                                                      \
+    (void)wv;                                                                                                             \
+    const int a = lane & 31, hi = lane >> 5;                                                                              \
+    (void)a; (void)hi;                                                                                                    \
+    /* the tile of this pair in round rd (clamped to the last round: such a pair computes and stores nothing new) */      \
+    auto tile_of = [&](int64_t rd) {                                                                                      \
+        if (rd >= nrounds) rd = nrounds - 1;                                                                              \
+        return ((int64_t)pblock + rd * pblocks) * 4 + pair;                                                               \
+    };                                                                                                                    \
+    auto row_of = [&](int64_t t) {                                                                                        \
+        int64_t rw = t * 32 + a;                                                                                          \
+        return rw < V ? rw : V - 1;                                                                                       \
+    };                                                                                                                    \
+    (void)row_of
+
+// The two roles are separate functions on purpose: compiled as two branches of one function, the invariants of one role
+// (store and copy addresses, LDS positions) stayed in registers through the other's loop and the kernel spilled.
 template <int H, bool HAS_MASK, bool NORM_OUT, bool NORM_IN>
-__global__ void __launch_bounds__(512) gru_rc_dx_kernel(const float* __restrict__ dout, const float* __restrict__ h,
-                                                        const float* __restrict__ mask, const float* __restrict__ saved,
-                                                        const float* __restrict__ kn, const char* __restrict__ wws,
-                                                        float* __restrict__ dm, float* __restrict__ dh, int64_t V,
-                                                        const float* __restrict__ y_in, double* sums) {
-    constexpr int NS = H / 128, NSTEP = H / 16;
-    // LDS: two weight images | per pair: 8 KB of pieces [segment][hi | lo][lane 16 B], 2 KB direct term [u][lane 16 B],
-    // 512 B note [ratio 64 floats | exponent 64 ints] | (NORM_OUT) kn | (NORM_IN) the sums
-    constexpr int R_PIECES = 2 * R_STEP, R_GZ = R_PIECES + 4 * 8192, R_NOTE = R_GZ + 4 * 2048, R_KN = R_NOTE + 4 * 512;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* kn_s = reinterpret_cast<float*>(smem + R_KN);
-    double* stat_s = reinterpret_cast<double*>(smem + R_KN + (NORM_OUT ? 3 * H * 4 : 0));   // [2][128]
-
-    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    const int slice = jb % NS;
-    const int pblock = (jb / NS) * 8 + xcd, pblocks = gridDim.x / NS;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pair = wv & 3;
-    const bool producer = wv >= 4;
-    const int a = lane & 31, hi = lane >> 5;
-    char* my_pieces = smem + R_PIECES + pair * 8192 + lane * 16;
-    char* my_gz = smem + R_GZ + pair * 2048 + lane * 16;
-    float* my_ratio = reinterpret_cast<float*>(smem + R_NOTE + pair * 512) + lane;
-    int* my_exp = reinterpret_cast<int*>(smem + R_NOTE + pair * 512 + 256) + lane;
-
-    const int64_t tiles = (V + 31) / 32;
-    const int64_t rounds_total = (tiles + 3) / 4;              // a round = 4 tiles, one per pair
-    if (pblock >= rounds_total) return;
-    const int64_t nrounds = (rounds_total - pblock + pblocks - 1) / pblocks;
-    const int64_t total = nrounds * NSTEP;
-    if (NORM_OUT)
-        for (int i = tid; i < 3 * H; i += 512) kn_s[i] = kn[i];
-    if (NORM_IN)
-        for (int i = tid; i < 2 * 128; i += 512) stat_s[i] = 0.0;
-    if (NORM_OUT || NORM_IN) __syncthreads();
-    const float inv_sw = reinterpret_cast<const float*>(wws)[slice];
-
-    // the tile of this pair in round rd (clamped to the last tile: such a pair computes and stores nothing new), its row
-    auto tile_of = [&](int64_t rd) {
-        if (rd >= nrounds) rd = nrounds - 1;
-        return ((int64_t)pblock + rd * pblocks) * 4 + pair;
-    };
-    auto row_of = [&](int64_t t) {
-        int64_t rw = t * 32 + a;
-        return rw < V ? rw : V - 1;
-    };
-
-    if (producer) {
+__device__ __attribute__((noinline)) void gru_rc_dx_producer(const RcDxCtx& c) {
+    RC_DX_PROLOGUE();
         // ================================================================================================ producers
+        // Lane = (chunk c = lane & 3: 4 columns of the step's 16, rows lane >> 2 and 16 + (lane >> 2) of the tile): a load
+        // instruction covers 16 rows x 64 contiguous bytes (lane = atom | half, the layout the matrix pipe wants, touches 32
+        // rows x 32 bytes and kept the producers waiting at the address unit: profiles/r04_gru_bwd_ablation.md).  The pieces
+        // are parked where the consumer's lane (atom, half) reads them: chunk c of row a is k-slots 4 (c >> 1) .. of lane
+        // (a, c & 1).  A row's maximum is a maximum over the 4 lanes of a quad.
         const float sw = 1.0f / inv_sw;
-        struct Rows { f32x4 d[2], hv[2], r[2], z[2], n[2], nh[2]; };
+        const int c4 = lane & 3, q16 = lane >> 2;
+        struct Rows { f32x4 d[2], hv[2], r[2], z[2], n[2], nh[2]; float mk[2]; };   // [i]: row q16 + 16 i
         auto load_rows = [&](int64_t n) {                  // the slices of global step n (clamped to the last step)
             Rows q;
             if (n >= total) n = total - 1;
             const int st = (int)(n % NSTEP);
-            int64_t rw = row_of(tile_of(n / NSTEP));
-#ifdef MPNN_ABL_RC_HOTROWS      // timing experiment only (wrong results): every tile reads the first 256 atoms' rows (L2-resident)
-            rw &= 255;
-#endif
-            const int c0 = 16 * st + 4 * hi;
-            const float* pd = dout + rw * H + c0;
-            const float* ph = h + rw * H + c0;
-            const float* ps = saved + rw * 4 * H + c0;
+            const int64_t t = tile_of(n / NSTEP);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                q.d[u] = *reinterpret_cast<const f32x4*>(pd + 8 * u);
-                q.z[u] = *reinterpret_cast<const f32x4*>(ps + H + 8 * u);
-                q.n[u] = *reinterpret_cast<const f32x4*>(ps + 2 * H + 8 * u);
-                q.hv[u] = *reinterpret_cast<const f32x4*>(ph + 8 * u);
-                q.r[u] = *reinterpret_cast<const f32x4*>(ps + 8 * u);
-                q.nh[u] = *reinterpret_cast<const f32x4*>(ps + 3 * H + 8 * u);
+            for (int i = 0; i < 2; ++i) {
+                int64_t rw = t * 32 + q16 + 16 * i;
+                if (rw >= V) rw = V - 1;
+#ifdef MPNN_ABL_RC_HOTROWS      // timing experiment only (wrong results): every tile reads the first 256 atoms' rows (L2-resident)
+                rw &= 255;
+#endif
+                const int c0 = 16 * st + 4 * c4;
+                const float* ps = saved + rw * 4 * H + c0;
+                q.d[i] = *reinterpret_cast<const f32x4*>(dout + rw * H + c0);
+                q.z[i] = *reinterpret_cast<const f32x4*>(ps + H);
+                q.n[i] = *reinterpret_cast<const f32x4*>(ps + 2 * H);
+                q.hv[i] = *reinterpret_cast<const f32x4*>(h + rw * H + c0);
+                q.r[i] = *reinterpret_cast<const f32x4*>(ps);
+                q.nh[i] = *reinterpret_cast<const f32x4*>(ps + 3 * H);
+                q.mk[i] = HAS_MASK ? mask[rw] : 1.0f;      // (times "row < V" where it is used)
             }
             return q;
         };
-        int e_cur = 51;
-        float mk = 0.f;
-        h16x8 ph[4], pl[4];                                // pieces of (dar, daz, dan, dnh), this lane's 8 k-slots
-        f32x4 gz0, gz1;
-        float ratio = 1.0f;
+        int e_cur[2] = {51, 51};
+        typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+        h16x4 ph[4][2], pl[4][2];                          // pieces of (dar, daz, dan, dnh), rows i, this lane's 4 columns
+        f32x4 gzv[2];
+        float ratio[2] = {1.0f, 1.0f};
         // gate gradients of global step n from `q` -> pieces, direct term, scale note (all in registers)
         auto produce = [&](int64_t n, const Rows& q) {
             const int st = (int)(n % NSTEP);
-            if (st == 0) {
-                const int64_t t = tile_of(n / NSTEP);
-                const bool live = n / NSTEP < nrounds && t * 32 + a < V;
-                mk = live ? (HAS_MASK ? mask[row_of(t)] : 1.0f) : 0.0f;
+            const int64_t t = tile_of(n / NSTEP);
+            f32x4 k1 = {0.f, 0.f, 0.f, 0.f}, k2 = k1, k4 = k1;
+            if (NORM_OUT) {
+                const int c = 16 * st + 4 * c4;
+                k1 = *reinterpret_cast<const f32x4*>(kn_s + c);
+                k2 = *reinterpret_cast<const f32x4*>(kn_s + H + c);
+                k4 = *reinterpret_cast<const f32x4*>(kn_s + 2 * H + c);
             }
-            f32x4 dar[2], daz[2], dan[2], dnh[2], gz[2];
-            float mx = 0.f;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                f32x4 k1 = {0.f, 0.f, 0.f, 0.f}, k2 = k1, k4 = k1;
-                if (NORM_OUT) {
-                    const int c = 16 * st + 4 * hi + 8 * u;
-                    k1 = *reinterpret_cast<const f32x4*>(kn_s + c);
-                    k2 = *reinterpret_cast<const f32x4*>(kn_s + H + c);
-                    k4 = *reinterpret_cast<const f32x4*>(kn_s + 2 * H + c);
+            for (int i = 0; i < 2; ++i) {
+                const float mk = (t * 32 + q16 + 16 * i < V) ? q.mk[i] : 0.0f;
+                f32x4 dar, daz, dan, dnh, gz;
+                r_gate_grads4<NORM_OUT>(q.d[i], q.hv[i], q.r[i], q.z[i], q.n[i], q.nh[i], mk, k1, k2, k4, dar, daz, dan, dnh, gz);
+                float mx = r_max4(r_max4(r_max4(r_max4(0.f, dar), daz), dan), dnh);
+                mx = r_quad_max(mx);                       // the row's other three chunks
+                const int e_mx = r_exp(mx);
+                ratio[i] = 1.0f;
+                if (st == 0) {
+                    e_cur[i] = e_mx;
+                } else if (e_mx > e_cur[i] + 3) {          // three bits of headroom are used up
+                    ratio[i] = r_pow2(127 + e_cur[i] - e_mx);
+                    e_cur[i] = e_mx;
                 }
-                r_gate_grads4<NORM_OUT>(q.d[u], q.hv[u], q.r[u], q.z[u], q.n[u], q.nh[u], mk, k1, k2, k4, dar[u], daz[u], dan[u],
-                                        dnh[u], gz[u]);
-                mx = r_max4(r_max4(r_max4(r_max4(mx, dar[u]), daz[u]), dan[u]), dnh[u]);
+                const float sg = r_pow2(265 - e_cur[i]);   // row maximum * sg in [2^11, 2^12) when set, < 2^16 always
+                const float gsc = sg * sw;
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) gzv[i][t4] = gz[t4] * gsc;
+                r_split4(dar, sg, ph[0][i], pl[0][i]);
+                r_split4(daz, sg, ph[1][i], pl[1][i]);
+                r_split4(dan, sg, ph[2][i], pl[2][i]);
+                r_split4(dnh, sg, ph[3][i], pl[3][i]);
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32));            // the atom's other half
-            const int e_mx = r_exp(mx);
-            ratio = 1.0f;
-            if (st == 0) {
-                e_cur = e_mx;
-            } else if (e_mx > e_cur + 3) {                 // three bits of headroom are used up
-                ratio = r_pow2(127 + e_cur - e_mx);
-                e_cur = e_mx;
-            }
-            const float sg = r_pow2(265 - e_cur);          // row maximum * sg in [2^11, 2^12) when set, < 2^16 always
-            const float gsc = sg * sw;
-            gz0 = gz[0] * gsc;
-            gz1 = gz[1] * gsc;
-            r_split8(dar[0], dar[1], sg, ph[0], pl[0]);
-            r_split8(daz[0], daz[1], sg, ph[1], pl[1]);
-            r_split8(dan[0], dan[1], sg, ph[2], pl[2]);
-            r_split8(dnh[0], dnh[1], sg, ph[3], pl[3]);
         };
+        // consumer lane (a, c & 1): pieces at 16 lane' + 8 (c >> 1); direct term u = c >> 1
+        char* dst_p = smem + R_PIECES + pair * 8192 + (2 * q16 + (c4 & 1)) * 16 + (c4 >> 1) * 8;
+        char* dst_g = smem + R_GZ + pair * 2048 + (c4 >> 1) * 1024 + (2 * q16 + (c4 & 1)) * 16;
+        float* dst_r = reinterpret_cast<float*>(smem + R_NOTE + pair * 512) + q16 + 32 * (c4 & 1);
         auto park = [&]() {
 #pragma unroll
-            for (int sgm = 0; sgm < 4; ++sgm) {
-                *reinterpret_cast<h16x8*>(my_pieces + sgm * 2048) = ph[sgm];
-                *reinterpret_cast<h16x8*>(my_pieces + sgm * 2048 + 1024) = pl[sgm];
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int sgm = 0; sgm < 4; ++sgm) {
+                    *reinterpret_cast<h16x4*>(dst_p + sgm * 2048 + i * 512) = ph[sgm][i];
+                    *reinterpret_cast<h16x4*>(dst_p + sgm * 2048 + 1024 + i * 512) = pl[sgm][i];
+                }
+                *reinterpret_cast<f32x4*>(dst_g + i * 512) = gzv[i];
+                if (c4 < 2) {
+                    dst_r[16 * i] = ratio[i];
+                    reinterpret_cast<int*>(dst_r + 64)[16 * i] = e_cur[i];
+                }
             }
-            *reinterpret_cast<f32x4*>(my_gz) = gz0;
-            *reinterpret_cast<f32x4*>(my_gz + 1024) = gz1;
-            *my_ratio = ratio;
-            *my_exp = e_cur;
         };
+        // the consumers are the older waves and would win every tie at the SIMD's issue port; they wait on the matrix pipe
+        // most of the time, so the vector work goes first
+        __builtin_amdgcn_s_setprio(2);
         Rows ra = load_rows(0), rb = load_rows(1);
         produce(0, ra);
         ra = load_rows(2);
         park();
         r_barrier_lds();                                   // (P0) pieces of step 0 are parked, weight image 0 has landed
         // one step: pieces of step g + 1 from `q` (requested two steps ago), then `q` takes the slices of step g + 3
+#ifdef RC_STAMP
+#define RC_PSTAMP()                                                                                                      \
+    if (blockIdx.x == 3 && lane == 0 && wv == 4) {                                                                        \
+        RC_ADD_STAMP(16, p1 - p0); RC_ADD_STAMP(17, p2 - p1); RC_ADD_STAMP(18, p3 - p2); RC_ADD_STAMP(19, p4 - p3);       \
+        RC_ADD_STAMP(20, p5 - p4); RC_ADD_STAMP(21, 1);                                                                   \
+    }
+#else
+#define RC_PSTAMP()
+#endif
 #define RC_PRODUCER_STEP(G, Q)                                                                       \
     {                                                                                                \
+        RC_T(p0);                                                                                    \
         const bool more = (G) + 1 < total;                                                           \
         if (more) produce((G) + 1, Q);                                                               \
+        /* (the pieces are FINISHED here: without this the conversions sink below the barrier, into the phase the    \
+           consumers spend waiting) */                                                                 \
+        _Pragma("unroll") for (int sgm_ = 0; sgm_ < 4; ++sgm_)                                        \
+            asm volatile("" ::"v"(ph[sgm_][0]), "v"(pl[sgm_][0]), "v"(ph[sgm_][1]), "v"(pl[sgm_][1]));   \
+        asm volatile("" ::"v"(gzv[0]), "v"(gzv[1]));                                                  \
+        RC_T(p1);                                                                                    \
         Q = load_rows((G) + 3);                                                                      \
+        RC_T(p2);                                                                                    \
         r_barrier_lds(); /* (B1) the consumers are done with pieces g */                             \
+        RC_T(p3);                                                                                    \
         if (more) park();                                                                            \
+        RC_T(p4);                                                                                    \
         r_barrier_lds(); /* (B2) */                                                                  \
+        RC_T(p5);                                                                                    \
+        RC_PSTAMP()                                                                                  \
     }
 #pragma unroll 1
         for (int64_t g = 0; g < total; g += 2) {
@@ -325,14 +431,25 @@ __global__ void __launch_bounds__(512) gru_rc_dx_kernel(const float* __restrict_
             RC_PRODUCER_STEP(g + 1, ra)
         }
 #undef RC_PRODUCER_STEP
-    } else {
-    // ==================================================================================================== consumers
+#undef RC_PSTAMP
+}
+
+template <int H, bool HAS_MASK, bool NORM_OUT, bool NORM_IN>
+__device__ __attribute__((noinline)) void gru_rc_dx_consumer(const RcDxCtx& c) {
+    RC_DX_PROLOGUE();
+    // consumer lane (a, half) reads its 16 bytes at position 2 a + half: the producers' 8-byte writes (4 lanes per atom: chunks
+    // 0..3 -> positions 2 a, 2 a + 1, each half-filled twice) then fall on 32 different banks
+    char* my_pieces = smem + R_PIECES + pair * 8192 + (2 * a + hi) * 16;
+    char* my_gz = smem + R_GZ + pair * 2048 + (2 * a + hi) * 16;
+    float* my_ratio = reinterpret_cast<float*>(smem + R_NOTE + pair * 512) + lane;
+    int* my_exp = reinterpret_cast<int*>(smem + R_NOTE + pair * 512 + 256) + lane;
     // this wave's share of weight image `st` -> buffer buf: twelve 1 KB copies
     auto w_issue = [&](int st, int buf) {
-        const char* src = wws + 64 + (int64_t)(slice * NSTEP + st) * R_STEP + lane * 16;
-        const char* dst = smem + buf * R_STEP;
+        const char* src = wws + 64 + (int64_t)(slice * NSTEP + st) * R_STEP + (12 * pair) * 1024;   // (wave-uniform)
+        const char* dst = smem + buf * R_STEP + (12 * pair) * 1024;
+        const unsigned voff = lane * 16;
 #pragma unroll
-        for (int i = 0; i < 12; ++i) r_copy_to_lds(src + (12 * pair + i) * 1024, dst + (12 * pair + i) * 1024);
+        for (int i = 0; i < 12; ++i) r_copy_to_lds_s(src + i * 1024, voff, dst + i * 1024);
     };
     f32x16 d_m[4], d_h[4];
     auto afrag = [&](const char* wb, int sub, int piece, int nb) {
@@ -372,6 +489,7 @@ __global__ void __launch_bounds__(512) gru_rc_dx_kernel(const float* __restrict_
 #undef RC_ADD
     };
 
+    __builtin_amdgcn_s_setprio(3);                         // short vector bursts of the consumer go first; its MFMA phase yields
     w_issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     r_barrier_lds();                                       // (P0)
@@ -380,14 +498,19 @@ __global__ void __launch_bounds__(512) gru_rc_dx_kernel(const float* __restrict_
 #pragma unroll 1
     for (int64_t g = 0; g < total; ++g) {
         const int buf = (int)(g & 1);
-        if (g + 1 < total) w_issue(st + 1 == NSTEP ? 0 : st + 1, buf ^ 1);
+        RC_T(c0);
+        // the producer's note for this step, requested before the copies are issued (their issue covers the LDS latency)
+        const float ratio = *my_ratio;                     // < 1 where this step's gradients outgrew the atom's scale
+        const f32x4 gz0 = *reinterpret_cast<const f32x4*>(my_gz), gz1 = *reinterpret_cast<const f32x4*>(my_gz + 1024);
+        const int e_note = *my_exp;
+        if (g + 1 < total) w_issue(st + 1 == NSTEP ? 0 : st + 1, buf ^ 1);   // (its issue covers the latency of the reads above)
+        RC_T(c1);
         if (st == 0) {
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { d_m[nb][i] = 0.f; d_h[nb][i] = 0.f; }
         } else {
-            const float ratio = *my_ratio;                 // < 1 where this step's gradients outgrew the atom's scale
             if (__builtin_amdgcn_ballot_w64(ratio != 1.0f) != 0) {
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb)
@@ -397,32 +520,52 @@ __global__ void __launch_bounds__(512) gru_rc_dx_kernel(const float* __restrict_
         }
         {
             const int nb = (st >> 1) - 4 * slice;
-            if (nb >= 0 && nb < 4)
-                add_gz(nb, st & 1, *reinterpret_cast<const f32x4*>(my_gz), *reinterpret_cast<const f32x4*>(my_gz + 1024));
+            if (nb >= 0 && nb < 4) add_gz(nb, st & 1, gz0, gz1);
         }
         const char* wb = smem + buf * R_STEP;
+        RC_T(c2);
+        __builtin_amdgcn_s_setprio(0);                     // (while this wave waits on the matrix pipe the producer's vector work goes first)
         product(0, wb, d_m, 0, d_h, 1);
         product(1, wb, d_m, 2, d_h, 3);
         product(2, wb, d_m, 4, d_h, -1);
         product(3, wb, d_h, 5, d_m, -1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of weight image g + 1 has landed
+        __builtin_amdgcn_s_setprio(3);
+        RC_T(c3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of weight image g + 1 (issued a step ago) has landed
+        RC_T(c4);
         if (st + 1 == NSTEP) {
             // ---- epilogue: this lane's atom, 16 x 4 consecutive features of dm and of dh
             const int64_t t = tile_of(rd);
             const int64_t row = row_of(t);
             const bool on = t * 32 + a < V;
-            const float un = r_pow2(*my_exp - 11) * inv_sw;                    // 1 / (sg * sw)
-            if (on) {
-                float* pm = dm + row * H + 128 * slice + 4 * hi;
-                float* pq = dh + row * H + 128 * slice + 4 * hi;
+            const float un = r_pow2(e_note - 11) * inv_sw;                     // 1 / (sg * sw)
+            {
+                // A lane holds 4 x 4 consecutive features of ITS atom per block: stored from here an instruction would touch 32
+                // rows x 32 bytes (measured: 10.7 k cycles per tile).  One 32 x 32 block at a time goes through this wave's
+                // 4.5 KB of LDS (rows of 36 floats) and leaves as whole 128-byte row pieces: lane -> row (lane >> 3) + 8 k,
+                // 16-byte chunk lane & 7.
+                char* epi = smem + R_EPI + pair * 4608;
+                unsigned ln = (unsigned)lane;              // opaque: keeps the lane's offsets from becoming loop invariants
+                asm volatile("" : "+v"(ln));               // (as invariants they sat in registers across the MFMA phase and spilled)
+                const int rr = ln >> 3, ch = ln & 7;
+                const int a = ln & 31, hi = ln >> 5;
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb)
+                for (int mat = 0; mat < 2; ++mat)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 vm = {d_m[nb][4 * q], d_m[nb][4 * q + 1], d_m[nb][4 * q + 2], d_m[nb][4 * q + 3]};
-                        const f32x4 vh = {d_h[nb][4 * q], d_h[nb][4 * q + 1], d_h[nb][4 * q + 2], d_h[nb][4 * q + 3]};
-                        *reinterpret_cast<f32x4*>(pm + 32 * nb + 8 * q) = vm * un;
-                        *reinterpret_cast<f32x4*>(pq + 32 * nb + 8 * q) = vh * un;
+                    for (int nb = 0; nb < 4; ++nb) {
+                        const f32x16& d = mat ? d_h[nb] : d_m[nb];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 v = {d[4 * q] * un, d[4 * q + 1] * un, d[4 * q + 2] * un, d[4 * q + 3] * un};
+                            *reinterpret_cast<f32x4*>(epi + a * 144 + (8 * q + 4 * hi) * 4) = v;
+                        }
+                        float* po = (mat ? dh : dm) + (t * 32) * H + 128 * slice + 32 * nb + 4 * ch;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int r = rr + 8 * k;
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(epi + r * 144 + ch * 16);
+                            if (t * 32 + r < V) *reinterpret_cast<f32x4*>(po + (int64_t)r * H) = v;
+                        }
                     }
             }
             if (NORM_IN) {
@@ -453,13 +596,56 @@ __global__ void __launch_bounds__(512) gru_rc_dx_kernel(const float* __restrict_
         } else {
             ++st;
         }
-        r_barrier_lds();                                   // (B1) pieces g are consumed
+        RC_T(c5);
+        r_barrier_lds();                                   // (B1) pieces g are consumed, and so is weight image g
+        RC_T(c6);
         r_barrier_lds();                                   // (B2) pieces g + 1 are parked
+        RC_T(c7);
+#ifdef RC_STAMP
+        if (blockIdx.x == 3 && lane == 0 && wv == 0) {
+            RC_ADD_STAMP(0, c1 - c0); RC_ADD_STAMP(1, c2 - c1); RC_ADD_STAMP(2, c3 - c2); RC_ADD_STAMP(3, c4 - c3);
+            RC_ADD_STAMP(4, c5 - c4); RC_ADD_STAMP(5, c6 - c5); RC_ADD_STAMP(6, c7 - c6); RC_ADD_STAMP(7, 1);
+        }
+#endif
     }
-    }   // consumers
+}
+#undef RC_DX_PROLOGUE
+
+template <int H, bool HAS_MASK, bool NORM_OUT, bool NORM_IN>
+__global__ void __launch_bounds__(512) gru_rc_dx_kernel(const float* __restrict__ dout, const float* __restrict__ h,
+                                                        const float* __restrict__ mask, const float* __restrict__ saved,
+                                                        const float* __restrict__ kn, const char* __restrict__ wws,
+                                                        float* __restrict__ dm, float* __restrict__ dh, int64_t V,
+                                                        const float* __restrict__ y_in, double* sums) {
+    constexpr int NS = H / 128, NSTEP = H / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* kn_s = reinterpret_cast<float*>(smem + R_KN);
+    double* stat_s = reinterpret_cast<double*>(smem + R_KN + (NORM_OUT ? 3 * H * 4 : 0));   // [2][128]
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    RcDxCtx c;
+    c.dout = dout; c.h = h; c.mask = mask; c.saved = saved; c.y_in = y_in; c.wws = wws; c.dm = dm; c.dh = dh; c.V = V;
+    c.slice = jb % NS;
+    c.pblock = (jb / NS) * 8 + xcd;
+    c.pblocks = gridDim.x / NS;
+    c.pair = wv & 3;
+    c.tiles = (V + 31) / 32;
+    const int64_t rounds_total = (c.tiles + 3) / 4;            // a round = 4 tiles, one per pair
+    if (c.pblock >= rounds_total) return;
+    c.nrounds = (rounds_total - c.pblock + c.pblocks - 1) / c.pblocks;
+    c.total = c.nrounds * NSTEP;
+    if (NORM_OUT)
+        for (int i = tid; i < 3 * H; i += 512) kn_s[i] = kn[i];
+    if (NORM_IN)
+        for (int i = tid; i < 2 * 128; i += 512) stat_s[i] = 0.0;
+    if (NORM_OUT || NORM_IN) __syncthreads();
+    c.inv_sw = reinterpret_cast<const float*>(wws)[c.slice];
+    if (wv >= 4) gru_rc_dx_producer<H, HAS_MASK, NORM_OUT, NORM_IN>(c);
+    else gru_rc_dx_consumer<H, HAS_MASK, NORM_OUT, NORM_IN>(c);
     if (NORM_IN) {
         __syncthreads();                                   // both roles arrive here after the same number of barriers
-        if (tid < 256) atomicAdd(sums + (tid >> 7) * H + 128 * slice + (tid & 127), stat_s[tid]);
+        if (tid < 256) atomicAdd(sums + (tid >> 7) * H + 128 * c.slice + (tid & 127), stat_s[tid]);
     }
 }
 
@@ -495,7 +681,7 @@ __global__ void __launch_bounds__(512) gru_rc_dw_kernel(const float* __restrict_
 
     const int srow = tid >> 4, c16 = tid & 15;
     const int p_dst = (c16 >> 1) * 1024 + srow * 32 + (c16 & 1) * 16;   // this thread's 16 bytes inside an image
-    struct Rows { f32x4 d[2], hv[2], r[2], z[2], n[2], nh[2], x[2]; float mk; };
+    struct Rows { f32x4 d[2], hv[2], r[2], z[2], n[2], nh[2], x[2]; float mk, live; };   // nothing here is USED before park_*: no wait at the requests
     auto load_rows = [&](int64_t t) {
         Rows q;
         int64_t row = t * 32 + srow;
@@ -504,7 +690,8 @@ __global__ void __launch_bounds__(512) gru_rc_dw_kernel(const float* __restrict_
 #ifdef MPNN_ABL_RC_HOTROWS      // timing experiment only (wrong results): every tile reads the first 256 atoms' rows (L2-resident)
         row &= 255;
 #endif
-        q.mk = ok ? (HAS_MASK ? mask[row] : 1.0f) : 0.0f;
+        q.mk = HAS_MASK ? mask[row] : 1.0f;               // (times `live` where it is used)
+        q.live = ok ? 1.0f : 0.0f;                         // rows past V count as zeros
         const int c8 = 8 * c16;
         const float* ps = saved + row * 4 * H + c8;
 #pragma unroll
@@ -515,7 +702,7 @@ __global__ void __launch_bounds__(512) gru_rc_dw_kernel(const float* __restrict_
             q.z[u] = *reinterpret_cast<const f32x4*>(ps + H + 4 * u);
             q.n[u] = *reinterpret_cast<const f32x4*>(ps + 2 * H + 4 * u);
             q.nh[u] = *reinterpret_cast<const f32x4*>(ps + 3 * H + 4 * u);
-            q.x[u] = *reinterpret_cast<const f32x4*>(X + row * H + c8 + 4 * u) * (ok ? 1.0f : 0.0f);   // rows past V count as zeros
+            q.x[u] = *reinterpret_cast<const f32x4*>(X + row * H + c8 + 4 * u);
         }
         return q;
     };
@@ -541,7 +728,7 @@ __global__ void __launch_bounds__(512) gru_rc_dw_kernel(const float* __restrict_
                 k4 = *reinterpret_cast<const f32x4*>(kp + 2 * H);
             }
             f32x4 dar, daz, dan, dnh, gz;
-            r_gate_grads4<NORM_OUT>(q.d[u], q.hv[u], q.r[u], q.z[u], q.n[u], q.nh[u], q.mk, k1, k2, k4, dar, daz, dan, dnh, gz);
+            r_gate_grads4<NORM_OUT>(q.d[u], q.hv[u], q.r[u], q.z[u], q.n[u], q.nh[u], q.mk * q.live, k1, k2, k4, dar, daz, dan, dnh, gz);
             seg[0][u] = dar;
             seg[1][u] = daz;
             seg[2][u] = mat == 0 ? dan : dnh;
@@ -552,8 +739,7 @@ __global__ void __launch_bounds__(512) gru_rc_dw_kernel(const float* __restrict_
                 for (int t = 0; t < 4; ++t) cs[s][4 * u + t] += seg[s][u][t];
             }
         }
-#pragma unroll
-        for (int o = 8; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        mx = r_row16_max(mx);                              // the 16 lanes that share the row are one DPP row
         const int e = r_exp(mx);
         const float sg = r_pow2(268 - e);
 #pragma unroll
@@ -569,7 +755,7 @@ __global__ void __launch_bounds__(512) gru_rc_dw_kernel(const float* __restrict_
         float mx = 0.f;
 #pragma unroll
         for (int u = 0; u < 2; ++u) mx = r_max4(mx, q.x[u]);
-        mx = r_wave_max(mx);
+        mx = r_wave_max(mx * q.live);
         const float iv = r_wave_max(inv_sg);               // largest inverse = the scale of the tile's largest row
         if (lane == 0) { red[16 * par + wv] = mx; red[16 * par + 8 + wv] = iv; }
     };
@@ -585,7 +771,7 @@ __global__ void __launch_bounds__(512) gru_rc_dw_kernel(const float* __restrict_
         C_run = fminf(C_run, sgm * sxo);
         const float sx = C_run * inv_sg;
         h16x8 ph, pl;
-        r_split8(q.x[0], q.x[1], sx, ph, pl);
+        r_split8(q.x[0], q.x[1], sx * q.live, ph, pl);
         *reinterpret_cast<h16x8*>(T + 3 * R_IMG + p_dst) = ph;
         *reinterpret_cast<h16x8*>(T + 7 * R_IMG + p_dst) = pl;
     };
@@ -626,7 +812,9 @@ __global__ void __launch_bounds__(512) gru_rc_dw_kernel(const float* __restrict_
     int cur = 0;
 #pragma unroll 1
     for (int64_t t = t0; t < tiles; t += tstep) {
+        RC_T(w0);
         r_barrier_lds();                                   // buffer `cur` is complete; the other one is free
+        RC_T(w1);
         const char* T = smem + cur * BUF;
         char* Tn = smem + (cur ^ 1) * BUF;
         const bool has1 = t + tstep < tiles;
@@ -634,10 +822,11 @@ __global__ void __launch_bounds__(512) gru_rc_dw_kernel(const float* __restrict_
         // registers take tile t + 2
         float iv = 0.f;
         if (has1) iv = park_gates(nxt, Tn);
+        RC_T(w2);
         const f32x4 x0 = nxt.x[0], x1 = nxt.x[1];
         const int64_t t2 = t + 2 * tstep;
         Rows keep;                                         // (only x of tile t + 1 is still needed)
-        keep.x[0] = x0; keep.x[1] = x1;
+        keep.x[0] = x0; keep.x[1] = x1; keep.live = nxt.live;
         nxt = load_rows(t2 < tiles ? t2 : t);              // unconditional, clamped
         if (__builtin_amdgcn_readfirstlane(__float_as_int(C_cur)) != __builtin_amdgcn_readfirstlane(__float_as_int(C_acc))) {
             const float ratio = C_cur / C_acc;             // < 1, a power of two
@@ -647,6 +836,7 @@ __global__ void __launch_bounds__(512) gru_rc_dw_kernel(const float* __restrict_
                 for (int q = 0; q < 16; ++q) R[j][q] *= ratio;
             C_acc = C_cur;
         }
+        RC_T(w3);
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             const char* Tb = T + 512 * st;                 // rows +16
@@ -666,11 +856,22 @@ __global__ void __launch_bounds__(512) gru_rc_dw_kernel(const float* __restrict_
                 R[NB + b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bh, R[NB + b], 0, 0, 0);
             }
         }
+        RC_T(w4);
         if (has1) {
             publish(keep, iv, cur ^ 1);
+            RC_T(w5);
             r_barrier_lds();                               // the maxima of tile t + 1 are in LDS
+            RC_T(w6);
             park_x(keep, iv, Tn, cur ^ 1);
             C_cur = C_run;
+            RC_T(w7);
+#ifdef RC_STAMP
+            if (blockIdx.x == 16 && lane == 0 && (wv == 0 || wv == 7)) {
+                const int b = 32 + 12 * (wv == 7);
+                RC_ADD_STAMP(b + 0, w1 - w0); RC_ADD_STAMP(b + 1, w2 - w1); RC_ADD_STAMP(b + 2, w3 - w2); RC_ADD_STAMP(b + 3, w4 - w3);
+                RC_ADD_STAMP(b + 4, w5 - w4); RC_ADD_STAMP(b + 5, w6 - w5); RC_ADD_STAMP(b + 6, w7 - w6); RC_ADD_STAMP(b + 7, 1);
+            }
+#endif
         }
         cur ^= 1;
     }
@@ -726,7 +927,7 @@ static int launch_rc_128(const float* dout, const float* m, const float* h, cons
     constexpr int H = 128;
     const int64_t tiles = (V + 31) / 32;
     char* dxw = (char*)workspace;
-    const size_t lds_dx = (size_t)2 * R_STEP + 4 * (8192 + 2048 + 512) + (NORM_OUT ? 3 * H * 4 : 0) + (NORM_IN ? 2 * 128 * 8 : 0);
+    const size_t lds_dx = (size_t)2 * R_STEP + 4 * (8192 + 2048 + 512 + 4608) + (NORM_OUT ? 3 * H * 4 : 0) + (NORM_IN ? 2 * 128 * 8 : 0);
     const size_t lds_dw = (size_t)2 * 8 * R_IMG + 128;
     static const hipError_t attr_done = [&] {   // once per process and instantiation, thread-safe (C++11 static initialisation)
         LdsOptIn opt_in_;
@@ -753,6 +954,16 @@ static int launch_rc_128(const float* dout, const float* m, const float* h, cons
                        saved, out_norm_k, dW_ih, dW_hh, db_ih, db_hh, V);
     return launch_status("mpnn_gru_update_bwd_f32(dW, gate gradients in registers)");
 }
+
+#ifdef RC_STAMP
+extern "C" int mpnn_debug_rc_stamps(unsigned long long* host64, int reset) {
+    if (reset) {
+        unsigned long long z[64] = {0};
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_rc_stamps), z, sizeof(z));
+    }
+    return (int)hipMemcpyFromSymbol(host64, HIP_SYMBOL(g_rc_stamps), 64 * sizeof(unsigned long long));
+}
+#endif
 
 int launch_gru_bwd_rc(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
                       const float* W_hh, const float* saved, float* dm, float* dh, float* dW_ih, float* dW_hh, float* db_ih,
