@@ -658,36 +658,26 @@ __global__ void __launch_bounds__(512) gru_rc_dx_kernel(const float* __restrict_
 // row (the pieces' power-of-two scale sg_row: the largest magnitude lands in [2^14, 2^15)), parks the pieces, and keeps the
 // column sums (bias gradients).  m | h is split behind sx_row = C / sg_row, C = running minimum over the block's tiles of
 // (smallest sg_row of the tile) x (best scale of the tile's m | h): every product carries C (gru_bwd_f16.hip has the argument).
-struct RcDwCtx {
-    const float *dout, *m, *h, *mask, *saved, *kn;
-    float *dW_ih, *dW_hh, *db_ih, *db_hh;
-    int64_t V, tiles, t0, tstep;
-    int mat;
-};
-
-// MFIRST: this wave contracts tile t BEFORE it forms the pieces of tile t + 1 (waves 4-7); the others the other way round.
-// The two waves of a SIMD (w and w + 4) then use its two pipes at the same time: in the same order -- every wave pieces, then
-// every wave MFMAs -- each pipe idled through the other's phase (7.8 k cycles per tile against 2 x 1.5 k of vector and
-// 2 x 1.2 k of matrix work per SIMD: profiles/r04_gru_bwd_ablation.md).  One function per order, not two branches of one
-// (the branches' register needs add up, see gru_rc_dx_producer).
-template <bool HAS_MASK, bool NORM_OUT, bool MFIRST>
-__device__ __attribute__((noinline)) void gru_rc_dw_role(const RcDwCtx& c) {
+template <bool HAS_MASK, bool NORM_OUT>
+__global__ void __launch_bounds__(512) gru_rc_dw_kernel(const float* __restrict__ dout, const float* __restrict__ m,
+                                                        const float* __restrict__ h, const float* __restrict__ mask,
+                                                        const float* __restrict__ saved, const float* __restrict__ kn,
+                                                        float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, int64_t V) {
     constexpr int H = 128, NB = 3, NACC = 6;
     constexpr int BUF = 8 * R_IMG;             // image (piece, slot) at (4 * piece + slot) * R_IMG
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem + 2 * BUF);              // [2 parities][max |x| 8 | max 1/sg 8]
     float* bsum = reinterpret_cast<float*>(smem);                        // (after the loop) column sums across the waves
-    const float *dout = r_uniform(c.dout), *m = r_uniform(c.m), *h = r_uniform(c.h), *mask = r_uniform(c.mask);
-    const float *saved = r_uniform(c.saved), *kn = r_uniform(c.kn);
-    float *dW_ih = r_uniform(c.dW_ih), *dW_hh = r_uniform(c.dW_hh), *db_ih = r_uniform(c.db_ih), *db_hh = r_uniform(c.db_hh);
-    const int64_t V = r_uniform(c.V), tiles = r_uniform(c.tiles), t0 = r_uniform(c.t0), tstep = r_uniform(c.tstep);
-    const int mat = r_uniform(c.mat);
-    (void)mask; (void)kn;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int mat = jb & 1;                                    // the two matrices' blocks of a tile stream sit on one XCD
     const float* X = mat == 0 ? m : h;
+    const int64_t tiles = (V + 31) / 32;
+    const int64_t t0 = (jb >> 1) * 8 + xcd, tstep = gridDim.x / 2;
+    if (t0 >= tiles) return;
 
     const int srow = tid >> 4, c16 = tid & 15;
     const int p_dst = (c16 >> 1) * 1024 + srow * 32 + (c16 & 1) * 16;   // this thread's 16 bytes inside an image
@@ -831,17 +821,13 @@ __device__ __attribute__((noinline)) void gru_rc_dw_role(const RcDwCtx& c) {
         // tile t + 1: gate pieces into the free buffer (vector work, beside the matrix work on tile t below), then its
         // registers take tile t + 2
         float iv = 0.f;
-        Rows keep;                                         // (only x of tile t + 1 is still needed after its gate pieces)
-#define RC_VECTOR_PART()                                                                              \
-    {                                                                                                 \
-        if (has1) iv = park_gates(nxt, Tn);                                                           \
-        const f32x4 x0 = nxt.x[0], x1 = nxt.x[1];                                                     \
-        const int64_t t2 = t + 2 * tstep;                                                             \
-        keep.x[0] = x0; keep.x[1] = x1; keep.live = nxt.live;                                         \
-        nxt = load_rows(t2 < tiles ? t2 : t); /* unconditional, clamped */                            \
-    }
-        if (!MFIRST) RC_VECTOR_PART()
+        if (has1) iv = park_gates(nxt, Tn);
         RC_T(w2);
+        const f32x4 x0 = nxt.x[0], x1 = nxt.x[1];
+        const int64_t t2 = t + 2 * tstep;
+        Rows keep;                                         // (only x of tile t + 1 is still needed)
+        keep.x[0] = x0; keep.x[1] = x1; keep.live = nxt.live;
+        nxt = load_rows(t2 < tiles ? t2 : t);              // unconditional, clamped
         if (__builtin_amdgcn_readfirstlane(__float_as_int(C_cur)) != __builtin_amdgcn_readfirstlane(__float_as_int(C_acc))) {
             const float ratio = C_cur / C_acc;             // < 1, a power of two
 #pragma unroll
@@ -871,8 +857,6 @@ __device__ __attribute__((noinline)) void gru_rc_dw_role(const RcDwCtx& c) {
             }
         }
         RC_T(w4);
-        if (MFIRST) RC_VECTOR_PART()
-#undef RC_VECTOR_PART
         if (has1) {
             publish(keep, iv, cur ^ 1);
             RC_T(w5);
@@ -929,25 +913,6 @@ __device__ __attribute__((noinline)) void gru_rc_dw_role(const RcDwCtx& c) {
             atomicAdd(db_hh + 2 * H + col, v);
         }
     }
-}
-
-template <bool HAS_MASK, bool NORM_OUT>
-__global__ void __launch_bounds__(512) gru_rc_dw_kernel(const float* __restrict__ dout, const float* __restrict__ m,
-                                                        const float* __restrict__ h, const float* __restrict__ mask,
-                                                        const float* __restrict__ saved, const float* __restrict__ kn,
-                                                        float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, int64_t V) {
-    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    RcDwCtx c;
-    c.dout = dout; c.m = m; c.h = h; c.mask = mask; c.saved = saved; c.kn = kn;
-    c.dW_ih = dW_ih; c.dW_hh = dW_hh; c.db_ih = db_ih; c.db_hh = db_hh;
-    c.V = V;
-    c.mat = jb & 1;                                            // the two matrices' blocks of a tile stream sit on one XCD
-    c.tiles = (V + 31) / 32;
-    c.t0 = (jb >> 1) * 8 + xcd;
-    c.tstep = gridDim.x / 2;
-    if (c.t0 >= c.tiles) return;
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < 4) gru_rc_dw_role<HAS_MASK, NORM_OUT, false>(c);
-    else gru_rc_dw_role<HAS_MASK, NORM_OUT, true>(c);
 }
 
 // one float per slice, then the step images of the dm | dh kernel
