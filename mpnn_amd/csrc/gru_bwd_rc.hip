@@ -650,13 +650,17 @@ __global__ void __launch_bounds__(512) gru_rc_dx_kernel(const float* __restrict_
 }
 
 // ----------------------------------------------------------------------------------------------------------- dW
-// H = 128.  Block type = matrix: dW_ih = m^T [dar daz dan], dW_hh = h^T [dar daz dnh] (128 x 384 each = 4 x 12 tiles of
-// 32 x 32; wave = 2 a-tiles x 3 b-tiles).  LDS per buffer: four images x two pieces (slots 0-2 the gate segments, 3 = X), an
-// image = [kstep 8][32 rows][16 columns] of a 32-atom tile; two buffers.  Thread (row = tid >> 4, columns 8 (tid & 15) ..)
-// owns the SAME 8 columns of every array: it reads them two tiles ahead of their contraction (seven 32-byte slices), forms
-// the three gate segments while the tile before is contracted, takes the row's maximum over the 16 lanes that share the
-// row (the pieces' power-of-two scale sg_row: the largest magnitude lands in [2^14, 2^15)), parks the pieces, and keeps the
-// column sums (bias gradients).  m | h is split behind sx_row = C / sg_row, C = running minimum over the block's tiles of
+// H = 128.  dW_ih = m^T [dar daz dan], dW_hh = h^T [dar daz dnh] (128 x 384 each).  Block type = COLUMN HALF: a block owns
+// columns 64 half .. 64 half + 63 of every gate segment, for BOTH matrices (2 x 4 x 6 tiles of 32 x 32; wave = matrix x 2
+// a-tiles x 3 b-tiles).  A block per matrix (the first form of this kernel) had every gate gradient formed twice, once per
+// matrix, and the kernel is bound by its vector instructions (profiles/r04_gru_bwd_ablation.md); here each is formed once,
+// and what is read twice is m | h (128 columns of each per block: the A operand of both products).
+// LDS per buffer: four images x two pieces: slot 0 = dar | daz, slot 1 = dan | dnh (64 columns each), slot 2 = m, slot 3 = h;
+// an image = [kstep 8][32 rows][16 columns] of a 32-atom tile; two buffers.  Thread (row = tid >> 4, c16 = tid & 15) owns
+// gate columns 64 half + 4 c16 .. + 3 and m | h columns 8 c16 .. + 7: it requests them two tiles ahead of their contraction,
+// forms the four gate segments while the tile before is contracted, takes the row's maximum over the 16 lanes that share
+// the row (the pieces' power-of-two scale sg_row: the largest magnitude lands in [2^14, 2^15)), parks the pieces, and keeps
+// the column sums (bias gradients).  m | h are split behind sx_row = C / sg_row, C = running minimum over the block's tiles of
 // (smallest sg_row of the tile) x (best scale of the tile's m | h): every product carries C (gru_bwd_f16.hip has the argument).
 template <bool HAS_MASK, bool NORM_OUT>
 __global__ void __launch_bounds__(512) gru_rc_dw_kernel(const float* __restrict__ dout, const float* __restrict__ m,
@@ -673,15 +677,15 @@ __global__ void __launch_bounds__(512) gru_rc_dw_kernel(const float* __restrict_
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31;
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    const int mat = jb & 1;                                    // the two matrices' blocks of a tile stream sit on one XCD
-    const float* X = mat == 0 ? m : h;
+    const int half = jb & 1;                                   // the two halves' blocks of a tile stream sit on one XCD
     const int64_t tiles = (V + 31) / 32;
     const int64_t t0 = (jb >> 1) * 8 + xcd, tstep = gridDim.x / 2;
     if (t0 >= tiles) return;
 
     const int srow = tid >> 4, c16 = tid & 15;
-    const int p_dst = (c16 >> 1) * 1024 + srow * 32 + (c16 & 1) * 16;   // this thread's 16 bytes inside an image
-    struct Rows { f32x4 d[2], hv[2], r[2], z[2], n[2], nh[2], x[2]; float mk, live; };   // nothing here is USED before park_*: no wait at the requests
+    const int g_dst = (c16 >> 2) * 1024 + srow * 32 + (c16 & 3) * 8;    // this thread's 8 bytes (4 gate columns) inside 64 columns of an image
+    const int x_dst = (c16 >> 1) * 1024 + srow * 32 + (c16 & 1) * 16;   // this thread's 16 bytes (8 columns of m or h) inside an image
+    struct Rows { f32x4 d, hv, r, z, n, nh, xm[2], xh[2]; float mk, live; };   // nothing here is USED before park_*: no wait at the requests
     auto load_rows = [&](int64_t t) {
         Rows q;
         int64_t row = t * 32 + srow;
@@ -692,69 +696,64 @@ __global__ void __launch_bounds__(512) gru_rc_dw_kernel(const float* __restrict_
 #endif
         q.mk = HAS_MASK ? mask[row] : 1.0f;               // (times `live` where it is used)
         q.live = ok ? 1.0f : 0.0f;                         // rows past V count as zeros
-        const int c8 = 8 * c16;
-        const float* ps = saved + row * 4 * H + c8;
+        const int c4 = 64 * half + 4 * c16;
+        const float* ps = saved + row * 4 * H + c4;
+        q.d = *reinterpret_cast<const f32x4*>(dout + row * H + c4);
+        q.hv = *reinterpret_cast<const f32x4*>(h + row * H + c4);
+        q.r = *reinterpret_cast<const f32x4*>(ps);
+        q.z = *reinterpret_cast<const f32x4*>(ps + H);
+        q.n = *reinterpret_cast<const f32x4*>(ps + 2 * H);
+        q.nh = *reinterpret_cast<const f32x4*>(ps + 3 * H);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            q.d[u] = *reinterpret_cast<const f32x4*>(dout + row * H + c8 + 4 * u);
-            q.hv[u] = *reinterpret_cast<const f32x4*>(h + row * H + c8 + 4 * u);
-            q.r[u] = *reinterpret_cast<const f32x4*>(ps + 4 * u);
-            q.z[u] = *reinterpret_cast<const f32x4*>(ps + H + 4 * u);
-            q.n[u] = *reinterpret_cast<const f32x4*>(ps + 2 * H + 4 * u);
-            q.nh[u] = *reinterpret_cast<const f32x4*>(ps + 3 * H + 4 * u);
-            q.x[u] = *reinterpret_cast<const f32x4*>(X + row * H + c8 + 4 * u);
+            q.xm[u] = *reinterpret_cast<const f32x4*>(m + row * H + 8 * c16 + 4 * u);
+            q.xh[u] = *reinterpret_cast<const f32x4*>(h + row * H + 8 * c16 + 4 * u);
         }
         return q;
     };
-    float cs[3][8];                                            // column sums of the three segments, this thread's 8 columns
+    float cs[4][4];                                            // column sums of the four segments, this thread's 4 columns
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) cs[s][u] = 0.f;
+        for (int u = 0; u < 4; ++u) cs[s][u] = 0.f;
     unsigned kofs = 0;
     if (NORM_OUT) asm volatile("" : "+v"(kofs));               // (opaque: the column constants are re-read per tile, not kept)
 
     // gate pieces of one tile -> buffer T; returns this row's 1 / sg
     auto park_gates = [&](const Rows& q, char* T) {
-        f32x4 seg[3][2];
+        f32x4 k1 = {0.f, 0.f, 0.f, 0.f}, k2 = k1, k4 = k1;
+        if (NORM_OUT) {
+            const float* kp = kn + kofs + 64 * half + 4 * c16;
+            k1 = *reinterpret_cast<const f32x4*>(kp);
+            k2 = *reinterpret_cast<const f32x4*>(kp + H);
+            k4 = *reinterpret_cast<const f32x4*>(kp + 2 * H);
+        }
+        f32x4 seg[4], gz;
+        r_gate_grads4<NORM_OUT>(q.d, q.hv, q.r, q.z, q.n, q.nh, q.mk * q.live, k1, k2, k4, seg[0], seg[1], seg[2], seg[3], gz);
         float mx = 0.f;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            f32x4 k1 = {0.f, 0.f, 0.f, 0.f}, k2 = k1, k4 = k1;
-            if (NORM_OUT) {
-                const float* kp = kn + kofs + 8 * c16 + 4 * u;
-                k1 = *reinterpret_cast<const f32x4*>(kp);
-                k2 = *reinterpret_cast<const f32x4*>(kp + H);
-                k4 = *reinterpret_cast<const f32x4*>(kp + 2 * H);
-            }
-            f32x4 dar, daz, dan, dnh, gz;
-            r_gate_grads4<NORM_OUT>(q.d[u], q.hv[u], q.r[u], q.z[u], q.n[u], q.nh[u], q.mk * q.live, k1, k2, k4, dar, daz, dan, dnh, gz);
-            seg[0][u] = dar;
-            seg[1][u] = daz;
-            seg[2][u] = mat == 0 ? dan : dnh;
+        for (int s = 0; s < 4; ++s) {
+            mx = r_max4(mx, seg[s]);
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                mx = r_max4(mx, seg[s][u]);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) cs[s][4 * u + t] += seg[s][u][t];
-            }
+            for (int t = 0; t < 4; ++t) cs[s][t] += seg[s][t];
         }
         mx = r_row16_max(mx);                              // the 16 lanes that share the row are one DPP row
         const int e = r_exp(mx);
         const float sg = r_pow2(268 - e);
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            h16x8 ph, pl;
-            r_split8(seg[s][0], seg[s][1], sg, ph, pl);
-            *reinterpret_cast<h16x8*>(T + s * R_IMG + p_dst) = ph;
-            *reinterpret_cast<h16x8*>(T + (4 + s) * R_IMG + p_dst) = pl;
+        for (int s = 0; s < 4; ++s) {                      // image slot s >> 1, columns 64 (s & 1) ..
+            r_h16x4 ph, pl;
+            r_split4(seg[s], sg, ph, pl);
+            char* dst = T + (s >> 1) * R_IMG + (s & 1) * 4096 + g_dst;
+            *reinterpret_cast<r_h16x4*>(dst) = ph;
+            *reinterpret_cast<r_h16x4*>(dst + 4 * R_IMG) = pl;
         }
         return r_pow2(e - 14);
     };
     auto publish = [&](const Rows& q, float inv_sg, int par) {
         float mx = 0.f;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) mx = r_max4(mx, q.x[u]);
+        for (int u = 0; u < 2; ++u) mx = r_max4(r_max4(mx, q.xm[u]), q.xh[u]);
         mx = r_wave_max(mx * q.live);
         const float iv = r_wave_max(inv_sg);               // largest inverse = the scale of the tile's largest row
         if (lane == 0) { red[16 * par + wv] = mx; red[16 * par + 8 + wv] = iv; }
@@ -769,29 +768,38 @@ __global__ void __launch_bounds__(512) gru_rc_dw_kernel(const float* __restrict_
         const float sxo = r_pow2(268 - ex);
         const float sgm = r_pow2(254 - ((__float_as_int(ivm) >> 23) & 0xff));
         C_run = fminf(C_run, sgm * sxo);
-        const float sx = C_run * inv_sg;
+        const float sx = C_run * inv_sg * q.live;
         h16x8 ph, pl;
-        r_split8(q.x[0], q.x[1], sx * q.live, ph, pl);
-        *reinterpret_cast<h16x8*>(T + 3 * R_IMG + p_dst) = ph;
-        *reinterpret_cast<h16x8*>(T + 7 * R_IMG + p_dst) = pl;
+        r_split8(q.xm[0], q.xm[1], sx, ph, pl);
+        *reinterpret_cast<h16x8*>(T + 2 * R_IMG + x_dst) = ph;
+        *reinterpret_cast<h16x8*>(T + 6 * R_IMG + x_dst) = pl;
+        r_split8(q.xh[0], q.xh[1], sx, ph, pl);
+        *reinterpret_cast<h16x8*>(T + 3 * R_IMG + x_dst) = ph;
+        *reinterpret_cast<h16x8*>(T + 7 * R_IMG + x_dst) = pl;
     };
 
     // transposed reads (as gru_bwd128_f16.hip): a 16-lane group takes rows 8 (g2 >> 1) + 4 j + (0..3), columns 16 (g2 & 1) +
     // (0..15) of 32-column block cb of an image; lane 4 q + p supplies row q, columns 4 p .. 4 p + 3
-    const int ag = wv & 1, bg = wv >> 1;
+    const int mat = wv & 1, ag = (wv >> 1) & 1, bg = wv >> 2;
     const int g2 = lane >> 4, u16 = lane & 15, q4 = u16 >> 2, p4 = u16 & 3;
     auto tr_addr = [&](int slot, int cb, int j) {
         return slot * R_IMG + (2 * cb + (g2 & 1)) * 1024 + (8 * (g2 >> 1) + 4 * j + q4) * 32 + p4 * 8;
     };
+    // b-tile bt = 3 bg + b of this wave's matrix: segment bt >> 1 (the third one is dan for W_ih, dnh for W_hh), 32-column
+    // half bt & 1 of the block's 64 columns
+    auto seg_of = [&](int bt) { return (bt >> 1) < 2 ? (bt >> 1) : 2 + mat; };
     int LA[NB][2], LX[2][2];
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) LA[b][j] = tr_addr((NB * bg + b) >> 2, (NB * bg + b) & 3, j);
+        for (int j = 0; j < 2; ++j) {
+            const int bt = NB * bg + b, sg_ = seg_of(bt);
+            LA[b][j] = tr_addr(sg_ >> 1, 2 * (sg_ & 1) + (bt & 1), j);
+        }
 #pragma unroll
     for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) LX[a2][j] = tr_addr(3, 2 * ag + a2, j);
+        for (int j = 0; j < 2; ++j) LX[a2][j] = tr_addr(2 + mat, 2 * ag + a2, j);
 
     f32x16 R[NACC];
 #pragma unroll
@@ -818,15 +826,13 @@ __global__ void __launch_bounds__(512) gru_rc_dw_kernel(const float* __restrict_
         const char* T = smem + cur * BUF;
         char* Tn = smem + (cur ^ 1) * BUF;
         const bool has1 = t + tstep < tiles;
-        // tile t + 1: gate pieces into the free buffer (vector work, beside the matrix work on tile t below), then its
-        // registers take tile t + 2
+        // tile t + 1: gate pieces into the free buffer, then its registers take tile t + 2
         float iv = 0.f;
         if (has1) iv = park_gates(nxt, Tn);
         RC_T(w2);
-        const f32x4 x0 = nxt.x[0], x1 = nxt.x[1];
+        Rows keep;                                         // (only m | h of tile t + 1 are still needed)
+        keep.xm[0] = nxt.xm[0]; keep.xm[1] = nxt.xm[1]; keep.xh[0] = nxt.xh[0]; keep.xh[1] = nxt.xh[1]; keep.live = nxt.live;
         const int64_t t2 = t + 2 * tstep;
-        Rows keep;                                         // (only x of tile t + 1 is still needed)
-        keep.x[0] = x0; keep.x[1] = x1; keep.live = nxt.live;
         nxt = load_rows(t2 < tiles ? t2 : t);              // unconditional, clamped
         if (__builtin_amdgcn_readfirstlane(__float_as_int(C_cur)) != __builtin_amdgcn_readfirstlane(__float_as_int(C_acc))) {
             const float ratio = C_cur / C_acc;             // < 1, a power of two
@@ -881,7 +887,8 @@ __global__ void __launch_bounds__(512) gru_rc_dw_kernel(const float* __restrict_
     for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const int col = 32 * (NB * bg + b) + i;
+            const int bt = NB * bg + b;
+            const int col = (bt >> 1) * H + 64 * half + 32 * (bt & 1) + i;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int row = 32 * (2 * ag + a2) + acc_row(q, lane);
@@ -891,25 +898,27 @@ __global__ void __launch_bounds__(512) gru_rc_dw_kernel(const float* __restrict_
     // bias gradients: rows of one column group sit 16 lanes apart in a wave; then across the eight waves through LDS
     __syncthreads();                                        // (every wave is done with the tile buffers)
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 4; ++u) {
             float v = cs[s][u];
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
-            if (lane < 16) bsum[(wv * 16 + lane) * 25 + 8 * s + u] = v;
+            if (lane < 16) bsum[(wv * 16 + lane) * 17 + 4 * s + u] = v;
         }
     __syncthreads();
-    for (int idx = tid; idx < 16 * 24; idx += 512) {
-        const int cg = idx / 24, k = idx % 24, s = k >> 3;
+    for (int idx = tid; idx < 16 * 16; idx += 512) {
+        const int cg = idx >> 4, k = idx & 15, s = k >> 2;
         float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) v += bsum[(w * 16 + cg) * 25 + k];
-        const int col = 8 * cg + (k & 7);
-        if (mat == 0) {                                    // dar, daz, dan: db_ih whole, and the r, z blocks of db_hh
+        for (int w = 0; w < 8; ++w) v += bsum[(w * 16 + cg) * 17 + k];
+        const int col = 64 * half + 4 * cg + (k & 3);
+        if (s < 2) {                                       // dar, daz: the r, z blocks of both bias gradients
             atomicAdd(db_ih + s * H + col, v);
-            if (s < 2) atomicAdd(db_hh + s * H + col, v);
-        } else if (s == 2) {                               // dnh: the n block of db_hh
+            atomicAdd(db_hh + s * H + col, v);
+        } else if (s == 2) {                               // dan
+            atomicAdd(db_ih + 2 * H + col, v);
+        } else {                                           // dnh
             atomicAdd(db_hh + 2 * H + col, v);
         }
     }
