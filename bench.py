@@ -590,6 +590,58 @@ def main():
                         "tile plan when the fused message+sum kernel runs"}
         del g2
 
+    streaming = None
+    if world == 1 and args.scaling == "weak" and args.mode == "train" and args.workload != "c1" and not args.no_side:
+        # The same training step on a FRESH batch every step (as the reference's DataLoader loop, test_lipo.py:157-165): batch
+        # t + 1 is uploaded, indexed and planned on a side stream by a worker thread while step t runs (mpnn_amd/streaming.py).
+        # Three host batches of the workload's shape in rotation (structure only; every turn builds a new MolGraph from the
+        # host arrays).  Atom features: made on the device from the atom index ("device_features"), or copied from pinned host
+        # memory ("uploaded_features": 4 * H * V bytes more over PCIe per batch).
+        from mpnn_amd.graph import MolGraph as _MG
+        from mpnn_amd.streaming import BatchStream
+        try:
+            hosts = [synth.make_molecules(mols, hidden, seed=9000 + i, dist=dist_name, edge_features=4, atom_features=False)
+                     for i in range(2)]
+            hosts.append(synth.make_molecules(mols, hidden, seed=317, dist=dist_name, edge_features=4, atom_features=False))
+            vmax = max(hb.num_atoms for hb in hosts)
+            pool = torch.rand(vmax, hidden).mul_(2.0).sub_(1.0).pin_memory()
+            n_steps = max(args.steps, 6)
+
+            def run(upload):
+                def make(hb, device):
+                    g2 = _MG.from_molbatch(hb, device)
+                    g2.prepare(tile_plan=(hidden == 64), wide_plan=(hidden in (128, 256)))
+                    if upload:
+                        f = pool[:g2.num_nodes].to(device, non_blocking=True)
+                    else:
+                        f = synth.hashed_features(torch.arange(g2.num_nodes, device=device), hidden)
+                    return f, g2, torch.ones(g2.num_nodes, 1, device=device)
+                bs = BatchStream((hosts[i % 3] for i in range(n_steps + 2)), dev, hidden, make_device_batch=make)
+                t0, k, edges = None, 0, 0
+                for b in bs:
+                    if k == 2:                             # two warm-up steps (allocator, first launches)
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                    bucket.zero()
+                    state, _ = model.message_passing(b.feats, b.graph, b.graph, b.mask)
+                    state.backward(gradient=torch.full_like(state, 1.0 / float(total_mols)))
+                    bs.done_with(b)
+                    if k >= 2:
+                        edges += b.graph.num_edges
+                    k += 1
+                torch.cuda.synchronize()
+                dt_s = time.perf_counter() - t0
+                return {"ms_per_step": dt_s / n_steps * 1e3, "edges_per_s": edges * T / dt_s}
+            streaming = {"steps": n_steps, "device_features": run(False), "uploaded_features": run(True),
+                         "resident_ms_per_step": dt / args.steps * 1e3,
+                         "upload_bytes_per_batch_with_features": int(4 * hidden * vmax),
+                         "note": "NOT the headline: every step takes a NEW batch (three host batches of the workload's shape in "
+                                 "rotation, each turn re-uploaded and re-indexed: MolGraph.from_molbatch + prepare incl. the tile "
+                                 "plan), prepared one batch ahead on a side stream by a worker thread (mpnn_amd/streaming.py)"}
+            del pool, hosts
+        except Exception as e:                            # a side figure must not take the headline down
+            streaming = {"error": repr(e)[:300]}
+
     fp32_pipe = None
     if world == 1 and rank == 0 and not args.no_side and ops.math_mode() != "fp32":
         # the same step with every contraction on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32, MPNN_GRU_MATH=fp32): what
@@ -729,6 +781,8 @@ def main():
                         "one optimizer-sized step per batch, ~60 kernel launches each"}
         if cold is not None:
             out["cold_batch"] = cold
+        if streaming is not None:
+            out["streaming"] = streaming
         if fp32_pipe is not None:
             out["fp32_pipe"] = fp32_pipe
         if unfused_norm is not None:

@@ -36,6 +36,7 @@ def test_bench_contract_tiny_workload():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == d["unit"]
     assert d["forward"]["value"] > d["value"]                      # inference pass is faster than the training step
     assert d["cold_batch"]["total_ms"] > 0                          # CSR + plan build per new batch, beside the step time
+    assert d["streaming"]["device_features"]["ms_per_step"] > 0 and d["streaming"]["uploaded_features"]["ms_per_step"] > 0
     if os.environ.get("MPNN_GRU_MATH") != "fp32":                   # (a run that is on the fp32 pipe already has no side leg)
         assert d["fp32_pipe"]["ms_per_step"] > 0                    # strict fp32 MFMA step (child process)
     assert cb["host_cpu_count"] >= cb["cores"] and cb["extrapolated_seconds_for_2k_molecules"] > 0
@@ -50,3 +51,41 @@ def test_bench_contract_tiny_workload():
         assert w["dominant_kernel"]["ms_per_step"] > 0 and w["dominant_kernel"]["kernel"] in w["kernels_ms_per_launch"]
     assert (wl["c3"]["hidden"], wl["c4"]["hidden"], wl["c5"]["hidden"]) == (128, 128, 256) and wl["c3"]["mp_steps"] == 5
     assert wl["c1"]["batches_of_16"]["train_edges_per_s"] > 0 and wl["c1"]["batches_of_16"]["batches"] >= 2
+
+
+def test_batch_stream_hands_over_fresh_batches_one_ahead():
+    """mpnn_amd/streaming.py: batches prepared on a side stream by a worker thread give the same step results as batches
+    prepared in line, in order, and every batch exactly once."""
+    import numpy as np
+    import torch
+    from mpnn_amd import parallel, synth
+    from mpnn_amd.graph import MolGraph
+    from mpnn_amd.models.basic_model import BasicModel
+    from mpnn_amd.streaming import BatchStream
+    dev = torch.device("cuda:0")
+    H = 64
+    hosts = [synth.make_molecules(300 + 50 * i, H, seed=40 + i) for i in range(5)]
+    torch.manual_seed(3)
+    model = BasicModel(H, 4, H, 50, 8, message_opts={}, agg_opts={}, update_opts={}, readout_opts={}, message_steps=2).to(dev)
+    bucket = parallel.GradientBucket([p for n, p in model.named_parameters() if not n.startswith("of.")])
+
+    def step(feats, g, mask):
+        bucket.zero()
+        state, _ = model.message_passing(feats, g, g, mask)
+        state.backward(gradient=torch.full_like(state, 1e-3))
+        return state.detach().clone(), bucket.flat.clone()
+
+    want = []
+    for hb in hosts:
+        g = MolGraph.from_molbatch(hb, dev).prepare()
+        want.append(step(torch.from_numpy(hb.atom_feat).to(dev), g, torch.ones(g.num_nodes, 1, device=dev)))
+    bs = BatchStream(hosts, dev, H)
+    got = []
+    for b in bs:
+        got.append(step(b.feats, b.graph, b.mask))
+        bs.done_with(b)
+    torch.cuda.synchronize()
+    assert len(got) == len(want)
+    for (s1, g1), (s2, g2) in zip(got, want):
+        assert torch.equal(s1, s2)
+        assert float((g1 - g2).abs().max()) <= 2e-6 * float(g2.abs().max())
