@@ -614,7 +614,7 @@ def main():
                     if upload:
                         f = pool[:g2.num_nodes].to(device, non_blocking=True)
                     else:
-                        f = synth.hashed_features(torch.arange(g2.num_nodes, device=device), hidden)
+                        f = torch.empty(g2.num_nodes, hidden, device=device).uniform_(-1.0, 1.0)
                     return f, g2, torch.ones(g2.num_nodes, 1, device=device)
                 bs = BatchStream((hosts[i % 3] for i in range(n_steps + 2)), dev, hidden, make_device_batch=make)
                 t0, k, edges = None, 0, 0

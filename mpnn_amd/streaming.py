@@ -39,7 +39,10 @@ class BatchStream:
         self.hidden = int(hidden)
         self.source = iter(source)
         self.make = make_device_batch or self._default_make
-        self.side = torch.cuda.Stream(device=self.device)
+        # HIGH priority: the indexing work is ~60 launches of a few microseconds each; behind the step's chip-filling kernels
+        # at equal priority each of them waited for a whole kernel of the step (measured: 25.7 ms per step against 11.8
+        # resident); ahead of them they take the workgroup slots that free up all the time
+        self.side = torch.cuda.Stream(device=self.device, priority=-1)
         self.q = queue.Queue(maxsize=1)
         self.free = queue.Queue()                      # events: "the caller's stream is done with the batch before last"
         self.err = None
