@@ -362,6 +362,47 @@ int mpnn_norm_bwd_consts_f32(const double* sums, const float* mean, const float*
                              const float* weight, float* out_norm_k, float* dweight, float* dbias, int F, float eps,
                              int flags, void* stream);
 
+/* ------------------------------------------------------------------ per-batch index work (round 4) */
+/*
+ * The CSR-derived arrays of a molecule batch and the work lists of the fused message + sum kernels, built tile by tile (one
+ * workgroup per tile of whole molecules) instead of by generic sorts; replaces per NEW batch what the reference's collate
+ * does on the host (pre_process/data_loader.py:50-70) plus this package's own index work (mpnn_amd/graph.py holds the same
+ * builders in torch ops: the CPU path, and the fallback when a batch is not separate molecules).  All device pointers.
+ *   mpnn_plan_index_tiles: tile_ptr [T+1] = molecule-aligned tiles of at most mpnn_plan_index_tile_atoms() atoms
+ *     (mpnn_plan_tiles_host).  Writes edge_dst [E], t_row_ptr [V+1] / t_eid [E] (edges grouped by source atom, ascending
+ *     edge id inside a group) and hist [T,K] (edges of type k per tile; skipped when K > mpnn_plan_index_max_types()).
+ *     flags [1] (caller zeroes): |= 1 an edge leaves its tile, |= 2 a tile with too many edges -- results invalid then.
+ *   mpnn_plan_type_order: offsets [K,T] = exclusive scan of hist in (type, tile) order (int64) -> order [E] (edge ids
+ *     stably sorted by type), type_ptr [K+1].
+ *   mpnn_tile_plan_count / _fill: graph.py::TilePlan (tiles of <= 128 atoms): count writes need [T,8,K] (row-tiles per
+ *     relabelled block and type, int64), tile_atom [T,128], atom_slot [V] (block << 4 | row), flags |= 4 for an edge that
+ *     leaves its tile; the caller scans need (rt_start [T*8*K+1], int64, exclusive + total) and fill writes
+ *     slots / slot_eid [16 * total] and rt_ptr [T*8+1].  K <= 8.
+ *   mpnn_wide_plan_count / _fill: graph.py::WidePlan (tiles of <= 256 atoms, blocks of 32): need [T,8,K], tile_atom
+ *     [T,256], atom_slot [V] (position in the tile); fill writes slots (int16) / slot_eid [32 * total], tile_rec [T,4],
+ *     blk_off [T,8K+1].
+ */
+int mpnn_plan_index_tile_atoms(void);
+int mpnn_plan_index_max_types(void);
+int mpnn_plan_index_tiles(const int32_t* row_ptr, const int32_t* col_idx, const int32_t* edge_type,
+                          const int32_t* tile_ptr, int64_t V, int64_t E, int64_t T, int K, int32_t* edge_dst,
+                          int32_t* t_row_ptr, int32_t* t_eid, int32_t* hist, int32_t* flags, void* stream);
+int mpnn_plan_type_order(const int32_t* row_ptr, const int32_t* edge_type, const int32_t* tile_ptr,
+                         const int64_t* offsets, int64_t E, int64_t T, int K, int32_t* order, int32_t* type_ptr,
+                         void* stream);
+int mpnn_tile_plan_count(const int32_t* row_ptr, const int32_t* col_idx, const int32_t* edge_type,
+                         const int32_t* tile_ptr, int64_t T, int K, int64_t* need, int32_t* tile_atom,
+                         int32_t* atom_slot, int32_t* flags, void* stream);
+int mpnn_tile_plan_fill(const int32_t* row_ptr, const int32_t* col_idx, const int32_t* edge_type,
+                        const int32_t* tile_ptr, int64_t T, int K, const int64_t* rt_start, const int32_t* atom_slot,
+                        int32_t* slots, int32_t* slot_eid, int32_t* rt_ptr, void* stream);
+int mpnn_wide_plan_count(const int32_t* row_ptr, const int32_t* col_idx, const int32_t* edge_type,
+                         const int32_t* tile_ptr, int64_t T, int K, int64_t* need, int32_t* tile_atom,
+                         int32_t* atom_slot, int32_t* flags, void* stream);
+int mpnn_wide_plan_fill(const int32_t* row_ptr, const int32_t* col_idx, const int32_t* edge_type,
+                        const int32_t* tile_ptr, int64_t T, int K, const int64_t* start, const int32_t* atom_slot,
+                        int16_t* slots, int32_t* slot_eid, int32_t* tile_rec, int32_t* blk_off, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

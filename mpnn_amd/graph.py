@@ -24,22 +24,43 @@ from . import _lib
 def _i32(t):
     return t.to(torch.int32).contiguous()
 
+def _host_tiles(g, tv, lib):
+    """Molecule-aligned tiles of at most `tv` atoms (greedy, whole molecules; mpnn_plan_tiles_host) -> (nt, host int32
+    tile_ptr) or (0, None) when a molecule is larger than a tile.  Cached per tile size; the molecule boundaries are read
+    from the host copy `from_molbatch` keeps, so no device -> host copy is needed for batches that came from the host."""
+    import ctypes
+    cache = g.__dict__.setdefault("_host_tiles_cache", {})
+    if tv not in cache:
+        gp = getattr(g, "_graph_ptr_host", None)
+        if gp is None:
+            gp = g.graph_ptr.to("cpu", torch.int32).contiguous()
+            g._graph_ptr_host = gp
+        tp = torch.empty(g.num_graphs + 2, dtype=torch.int32)
+        nt = lib.mpnn_plan_tiles_host(ctypes.c_void_p(gp.data_ptr()), g.num_graphs, tv, ctypes.c_void_p(tp.data_ptr()))
+        cache[tv] = (int(nt), tp[:nt + 1].contiguous()) if nt > 0 else (0, None)
+    return cache[tv]
+
+
+def _fast_path(g, K, kmax):
+    """The purpose-made index kernels (csrc/plan.hip) serve device-resident batches with few bond types; everything else
+    (CPU tensors: the tests' walk-throughs; continuous bond features) takes the torch builders below."""
+    return g.device.type == "cuda" and 1 <= K <= kmax and g.num_nodes > 0 and g.num_graphs > 0 and \
+        g.edge_type.dtype == torch.int32
+
+
 def _tile_layout(g, tv, lib):
     """What both tile plans start from: the batch's atoms cut into molecule-aligned tiles of at most `tv` atoms (greedy,
     whole molecules) and, inside every tile, sorted by their per-type in-degree pattern (rare types lead the key, high
     counts first).  None when the batch does not fit (no atoms, a molecule larger than a tile, an edge that leaves its
     tile).  -> (nt, tile_ptr, tp64, n_t, tile_of_atom, dst, src, et, cnt, pos_in_tile)"""
-    import ctypes
     K, E, V = g.num_types, g.num_edges, g.num_nodes
     if V == 0 or g.num_graphs == 0:
         return None
-    gp = g.graph_ptr.to("cpu", torch.int32).contiguous()
-    tp = torch.empty(g.num_graphs + 2, dtype=torch.int32)
-    nt = lib.mpnn_plan_tiles_host(ctypes.c_void_p(gp.data_ptr()), g.num_graphs, tv, ctypes.c_void_p(tp.data_ptr()))
+    nt, tp = _host_tiles(g, tv, lib)
     if nt <= 0:
         return None                                       # a molecule larger than a tile
     dev = g.device
-    tile_ptr = tp[:nt + 1].to(dev)
+    tile_ptr = tp.to(dev)
     tp64 = tile_ptr.to(torch.int64)
     n_t = tp64[1:] - tp64[:-1]
     tile_of_atom = torch.repeat_interleave(torch.arange(nt, device=dev), n_t, output_size=V)
@@ -108,6 +129,10 @@ class TilePlan:
         self.nbytes = 4 * (16 * T + tile_atoms * T + 16 * self.num_row_tiles)
 
     @classmethod
+    def _build_kernels(cls, g, lib, tv, rtmax):
+        return _tile_plan_kernels(cls, g, lib, tv, rtmax)
+
+    @classmethod
     def build(cls, g):
         lib = _lib.load()
         tv, kmax = lib.mpnn_message_aggregate_tile_atoms(), lib.mpnn_message_aggregate_max_types()
@@ -115,6 +140,8 @@ class TilePlan:
         K, E, V = g.num_types, g.num_edges, g.num_nodes
         if K > kmax:
             return None
+        if _fast_path(g, K, kmax) and tv == 128:
+            return cls._build_kernels(g, lib, tv, rtmax)
         lay = _tile_layout(g, tv, lib)
         if lay is None:
             return None
@@ -161,6 +188,43 @@ class TilePlan:
         return cls(tile_ptr, _i32(tile_atom).view(nt, tv), _i32(rt_ptr64), _i32(slots), _i32(slot_eid), tv, rt_start, K)
 
 
+def _tile_plan_kernels(cls, g, lib, tv, rtmax):
+    """TilePlan.build on the index kernels (csrc/plan.hip: mpnn_tile_plan_count / _fill); same arrays, bit for bit."""
+    K = g.num_types
+    nt, tp = _host_tiles(g, tv, lib)
+    if nt <= 0:
+        return None                                       # a molecule larger than a tile
+    dev = g.device
+    tile_ptr = tp.to(dev)
+    need, start, tile_atom, atom_slot, flags = _plan_count(lib, lib.mpnn_tile_plan_count, g, tile_ptr, nt, K, tv)
+    per_block = start[::K]
+    head = torch.stack([start[-1], (per_block[1:] - per_block[:-1]).max(), flags[0].to(torch.int64)]).cpu()
+    R, worst, bad = int(head[0]), int(head[1]), int(head[2])
+    if bad or (R and worst > rtmax):
+        return None                                       # an edge leaves its tile / a block with more row-tiles than fit
+    slots = torch.empty(16 * R, dtype=torch.int32, device=dev)
+    slot_eid = torch.empty(16 * R, dtype=torch.int32, device=dev)
+    rt_ptr = torch.empty(nt * 8 + 1, dtype=torch.int32, device=dev)
+    _lib.check(lib.mpnn_tile_plan_fill(_lib.iptr(g.row_ptr), _lib.iptr(g.col_idx), _lib.iptr(g.edge_type), _lib.iptr(tile_ptr),
+                                       nt, K, _lib.ptr(start), _lib.iptr(atom_slot), _lib.iptr(slots), _lib.iptr(slot_eid),
+                                       _lib.iptr(rt_ptr), _lib.stream()), "mpnn_tile_plan_fill")
+    return cls(tile_ptr, tile_atom, rt_ptr, slots, slot_eid, tv, start, K)
+
+
+def _plan_count(lib, fn, g, tile_ptr, nt, K, tile_atoms):
+    """count kernel + scan: -> (start int64 [nt*8*K + 1], tile_atom, atom_slot, total rows, flags) with ONE host read."""
+    dev = g.device
+    need = torch.empty(nt * 8 * K, dtype=torch.int64, device=dev)
+    tile_atom = torch.empty(nt, tile_atoms, dtype=torch.int32, device=dev)
+    atom_slot = torch.empty(g.num_nodes, dtype=torch.int32, device=dev)
+    flags = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(fn(_lib.iptr(g.row_ptr), _lib.iptr(g.col_idx), _lib.iptr(g.edge_type), _lib.iptr(tile_ptr), nt, K,
+                  _lib.ptr(need), _lib.iptr(tile_atom), _lib.iptr(atom_slot), _lib.iptr(flags), _lib.stream()), "plan count")
+    start = torch.zeros(need.numel() + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(need, 0, out=start[1:])
+    return need, start, tile_atom, atom_slot, flags
+
+
 class WidePlan:
     """Work list of the fused message+sum kernel at widths 128 / 256 (csrc/message_tile_wide.hip): typed
     aggregate-then-contract on molecule-aligned tiles.
@@ -193,12 +257,39 @@ class WidePlan:
         self.nbytes = 4 * int(tile_rec.numel() + tile_atom.numel() + blk_off.numel()) + 2 * int(slots.numel())
 
     @classmethod
+    def _build_kernels(cls, g, lib):
+        """build() on the index kernels (csrc/plan.hip: mpnn_wide_plan_count / _fill); same arrays, bit for bit."""
+        K, tv = g.num_types, cls.TILE_ATOMS
+        nt, tp = _host_tiles(g, tv, lib)
+        if nt <= 0:
+            return None                                   # a molecule larger than a tile
+        dev = g.device
+        tile_ptr = tp.to(dev)
+        need, start, tile_atom, atom_slot, flags = _plan_count(lib, lib.mpnn_wide_plan_count, g, tile_ptr, nt, K, tv)
+        per_tile = start[::8 * K]
+        head = torch.stack([start[-1], (per_tile[1:] - per_tile[:-1]).max(), flags[0].to(torch.int64)]).cpu()
+        R, worst, bad = int(head[0]), int(head[1]), int(head[2])
+        if bad or worst > cls.MAX_ROWS:
+            return None                                   # an edge leaves its tile / more slot rows than the kernel parks in LDS
+        slots = torch.empty(cls.BLOCK * R, dtype=torch.int16, device=dev)
+        slot_eid = torch.empty(cls.BLOCK * R, dtype=torch.int32, device=dev)
+        tile_rec = torch.empty(nt, 4, dtype=torch.int32, device=dev)
+        blk_off = torch.empty(nt, 8 * K + 1, dtype=torch.int32, device=dev)
+        _lib.check(lib.mpnn_wide_plan_fill(_lib.iptr(g.row_ptr), _lib.iptr(g.col_idx), _lib.iptr(g.edge_type),
+                                           _lib.iptr(tile_ptr), nt, K, _lib.ptr(start), _lib.iptr(atom_slot),
+                                           _lib.ptr(slots, torch.int16), _lib.iptr(slot_eid), _lib.iptr(tile_rec),
+                                           _lib.iptr(blk_off), _lib.stream()), "mpnn_wide_plan_fill")
+        return cls(tile_ptr, tile_rec, tile_atom, blk_off, slots, slot_eid, K)
+
+    @classmethod
     def build(cls, g):
         lib = _lib.load()
         tv, nb32 = cls.TILE_ATOMS, cls.BLOCK
         K, E, V = g.num_types, g.num_edges, g.num_nodes
         if K > cls.MAX_TYPES:
             return None
+        if _fast_path(g, K, cls.MAX_TYPES):
+            return cls._build_kernels(g, lib)
         lay = _tile_layout(g, tv, lib)
         if lay is None:
             return None
@@ -272,12 +363,47 @@ class MolGraph:
         """Build every derived index array now (type order, transposed graph, destination list and the tile plans of
         the fused message+sum kernels the caller will run: `tile_plan` for width 64, `wide_plan` for 128 / 256), so
         that none of it lands inside a timed or captured region."""
+        self._index_kernels()
         self.order, self.type_ptr, self.transpose, self.edge_dst, self.agg_weight
         if tile_plan:
             self.tile_plan
         if wide_plan:
             self.wide_plan
         return self
+
+    def _index_kernels(self):
+        """Destination list, type order and transposed graph from the tile kernels of csrc/plan.hip (a device-resident batch
+        of separate molecules with few bond types); leaves them to the lazy torch builders otherwise."""
+        if self._order is not None and self._transpose is not None and self._edge_dst is not None:
+            return
+        lib = _lib.load()
+        K, V, E = self.num_types, self.num_nodes, self.num_edges
+        if not _fast_path(self, K, lib.mpnn_plan_index_max_types()) or E == 0:
+            return
+        nt, tp = _host_tiles(self, lib.mpnn_plan_index_tile_atoms(), lib)
+        if nt <= 0:
+            return
+        dev = self.device
+        tile_ptr = tp.to(dev)
+        edge_dst = torch.empty(E, dtype=torch.int32, device=dev)
+        t_row_ptr = torch.empty(V + 1, dtype=torch.int32, device=dev)
+        t_eid = torch.empty(E, dtype=torch.int32, device=dev)
+        hist = torch.empty(nt, K, dtype=torch.int32, device=dev)
+        flags = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(lib.mpnn_plan_index_tiles(_lib.iptr(self.row_ptr), _lib.iptr(self.col_idx), _lib.iptr(self.edge_type),
+                                             _lib.iptr(tile_ptr), V, E, nt, K, _lib.iptr(edge_dst), _lib.iptr(t_row_ptr),
+                                             _lib.iptr(t_eid), _lib.iptr(hist), _lib.iptr(flags), _lib.stream()),
+                   "mpnn_plan_index_tiles")
+        off = torch.zeros(K * nt + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(hist.t().reshape(-1), 0, out=off[1:])
+        order = torch.empty(E, dtype=torch.int32, device=dev)
+        type_ptr = torch.empty(K + 1, dtype=torch.int32, device=dev)
+        _lib.check(lib.mpnn_plan_type_order(_lib.iptr(self.row_ptr), _lib.iptr(self.edge_type), _lib.iptr(tile_ptr),
+                                            _lib.ptr(off), E, nt, K, _lib.iptr(order), _lib.iptr(type_ptr), _lib.stream()),
+                   "mpnn_plan_type_order")
+        if int(flags.item()) != 0:
+            return                                        # not a batch of separate molecules: the generic builders
+        self._edge_dst, self._transpose, self._order, self._type_ptr = edge_dst, (t_row_ptr, t_eid), order, type_ptr
 
     def plan_bytes(self):
         """Bytes of index data the fused message+sum kernel reads per launch (0 without a plan)."""
@@ -433,11 +559,12 @@ class MolGraph:
         if dedupe and mb.edge_feat is not None:
             type_feat, inv = torch.unique(type_feat, dim=0, return_inverse=True)
             edge_type = _i32(inv)
-        E = mb.num_edges
-        return cls(up(mb.row_ptr, torch.int32), up(mb.col_idx, torch.int32),
-                   None, edge_type, type_feat.contiguous(),
-                   up(mb.atom_ptr, torch.int32), dense_shape=None,
-                   edge_feat=(up(mb.edge_feat, torch.float32) if mb.edge_feat is not None else None))
+        g = cls(up(mb.row_ptr, torch.int32), up(mb.col_idx, torch.int32),
+                None, edge_type, type_feat.contiguous(),
+                up(mb.atom_ptr, torch.int32), dense_shape=None,
+                edge_feat=(up(mb.edge_feat, torch.float32) if mb.edge_feat is not None else None))
+        g._graph_ptr_host = torch.from_numpy(mb.atom_ptr).to(torch.int32).contiguous()   # (the tile cutter runs on the host)
+        return g
 
     # ------------------------------------------------------------------ views
     def node_view(self, x):
