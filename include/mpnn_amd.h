@@ -106,6 +106,18 @@ int mpnn_edge_message_agg_bwd_da_f32(const float* dagg, const float* h, const in
                                      float* dA, int64_t V, int64_t E, int K, int nf, int mf, void* stream);
 
 /*
+ * The same with AttEdgeNetwork's gate evaluated in flight, no (E, nf) gate tensor:
+ *   gate[e, c] = exp2(log2(e) * (z_atom[dst e, c] + q[type e, c]) - stats[dst e, type e].x) * stats[dst e, type e].y,
+ * stats_by_atom [V, K, 2] = (log2(e) * max_c(z + q), 1 / sum_c exp(z + q - max)) as mpnn_message_aggregate_wide_gated_bwd_f32
+ * writes them.  replaces: the autograd of att_edge_network.py:26-31 composed with adjacent_message_agg.py:18 for the
+ * matrices.  nf = mf = 128 only.
+ */
+int mpnn_edge_message_agg_bwd_da_att_f32(const float* dagg, const float* h, const int32_t* src, const int32_t* dst,
+                                         const int32_t* order, const int32_t* type_ptr, const float* z_atom,
+                                         const float* q, const float* stats_by_atom, float* dA,
+                                         int64_t V, int64_t E, int K, int nf, int mf, void* stream);
+
+/*
  * Feature gate of AttEdgeNetwork: gate[e, :] = softmax_f( z_atom[dst[e], :] + q[type[e], :] )
  * replaces: mpnn_functions/message/att_edge_network.py:18-21 (cat[h_i, e_ij], Linear(nf+ef -> nf), Softmax(dim=-1))
  * after the caller split the Linear into its atom part z_atom[i] = W_h h_i + b  [V,F] and its bond part
@@ -198,6 +210,29 @@ int mpnn_message_aggregate_wide_gated_f32(const float* h, const float* A, const 
                                           const int32_t* tile_rec, const int32_t* tile_atom, const int32_t* blk_off,
                                           const int16_t* slots, float* out, void* workspace, size_t workspace_bytes,
                                           int64_t V, int64_t num_tiles, int K, int nf, int mf, void* stream);
+
+/*
+ * Backward of the gated form for the gate logits, per (atom, type) on the forward's plan -- no (E, nf) gate or
+ * gate-gradient tensor (replaces: the autograd of att_edge_network.py:18-31 composed with adjacent_message_agg.py:18 for
+ * z_atom and q).  With X_ik = gate_ik * S_ik (S_ik = the typed neighbour sum), T_ik = A_k^T dagg_i, u = X * T,
+ * D_ik = sum_f u_ikf:   dz_atom[i] = sum_k (u_ik - gate_ik D_ik),   dq[k] = sum_i (u_ik - gate_ik D_ik).
+ *   fwd_workspace   the workspace mpnn_message_aggregate_wide_gated_f32 was given for the same (z_atom, q, plan): its
+ *                   softmax statistics are read back
+ *   dz_atom [V,nf]  written (every row)
+ *   dq_part         [mpnn_message_aggregate_wide_gated_bwd_parts()][K][nf], ZERO-FILLED by the caller: partial sums of
+ *                   sum_i gate_ik D_ik;  dq[k] = colsum_over_mf(A[k] * dA[k]) - sum_over_parts(dq_part[:, k])  with dA the
+ *                   weight gradient (sum_i u_ik = the column sums of A_k * dA_k)
+ *   stats_by_atom   [V,K,2] written: the statistics in atom order, for mpnn_edge_message_agg_bwd_da_att_f32
+ * nf = mf = 128, K <= 4; workspace: mpnn_message_aggregate_wide_gated_bwd_workspace_bytes(K, nf).
+ */
+size_t mpnn_message_aggregate_wide_gated_bwd_workspace_bytes(int K, int nf);
+int mpnn_message_aggregate_wide_gated_bwd_parts(void);
+int mpnn_message_aggregate_wide_gated_bwd_f32(const float* h, const float* A, const float* z_atom, const float* q,
+                                              const float* dagg, const void* fwd_workspace, size_t fwd_workspace_bytes,
+                                              const int32_t* tile_rec, const int32_t* tile_atom, const int32_t* blk_off,
+                                              const int16_t* slots, float* dz_atom, float* dq_part, float* stats_by_atom,
+                                              void* workspace, size_t workspace_bytes, int64_t V, int64_t num_tiles,
+                                              int K, int nf, int mf, void* stream);
 
 /*
  * BiLiniearEdgeNetwork message on the dense padded batch: out[b,i,j,k] = sum_{a,c} afm[b,j,a] T[b,i,j][a,k,c] afm[b,i,c]

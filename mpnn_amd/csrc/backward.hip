@@ -564,6 +564,9 @@ __global__ void __launch_bounds__(256) gru_gate_grad_kernel(const float* __restr
 int launch_message_dx_resident(const float* dmsg, const float* A, const int32_t* order, const int32_t* type_ptr,
                                float* dx, int64_t E, int K, int nf, int mf, hipStream_t s);
 // nf = mf = 128 weight gradient on the bf16x6 pipe (edge_da128.hip)
+int launch_edge_da_att128(const float* Y, const float* h, const int32_t* src, const int32_t* dst, const int32_t* order,
+                          const int32_t* type_ptr, const float* z_atom, const float* q, const float* stats_by_atom, float* dA,
+                          int64_t E, int K, hipStream_t s);
 int launch_edge_da_split128(const float* Y, const float* h, const int32_t* src, const int32_t* dst, const float* w,
                             const int32_t* order, const int32_t* type_ptr, const float* gate, float* dA, int64_t E,
                             int K, hipStream_t s);
@@ -809,6 +812,19 @@ extern "C" int mpnn_edge_message_agg_bwd_da_f32(const float* dagg, const float* 
     else { if (gate) MPNN_DA64(false, true); else MPNN_DA64(false, false); }
 #undef MPNN_DA64
     return launch_status("mpnn_edge_message_agg_bwd_da_f32");
+}
+
+extern "C" int mpnn_edge_message_agg_bwd_da_att_f32(const float* dagg, const float* h, const int32_t* src,
+                                                    const int32_t* dst, const int32_t* order, const int32_t* type_ptr,
+                                                    const float* z_atom, const float* q, const float* stats_by_atom,
+                                                    float* dA, int64_t V, int64_t E, int K, int nf, int mf, void* stream) {
+    MPNN_REQUIRE(E >= 0 && V >= 0, "mpnn_edge_message_agg_bwd_da_att_f32: negative size");
+    MPNN_REQUIRE(nf == mf && nf == 128 && K >= 1 && K <= 64 && !math_fp32_only(),
+                 "mpnn_edge_message_agg_bwd_da_att_f32: nf = mf = 128, split math only (got %d, %d, K = %d)", nf, mf, K);
+    if (E == 0) return MPNN_OK;
+    MPNN_REQUIRE(dagg && h && src && dst && order && type_ptr && z_atom && q && stats_by_atom && dA,
+                 "mpnn_edge_message_agg_bwd_da_att_f32: NULL buffer");
+    return launch_edge_da_att128(dagg, h, src, dst, order, type_ptr, z_atom, q, stats_by_atom, dA, E, K, (hipStream_t)stream);
 }
 
 int mpnn_gru_update_norm_supported(int H);

@@ -11,11 +11,20 @@
 
 namespace mpnn {
 
-template <int F, bool HAS_DST, bool HAS_W, bool GATED>
+// ATT: the gate is AttEdgeNetwork's feature softmax, evaluated in flight instead of read from an (E, F) tensor:
+//   gate[e][c] = exp2(log2e * (z_atom[dst e][c] + q[type e][c]) - stats[dst e][type e].x) * stats[dst e][type e].y
+// (`gate` then points at z_atom; the statistics come from the forward's kernel, in atom order)
+struct AttGateArgs {
+    const float* q;          // (K, F) bond part of the logits
+    const float2* stats;     // (V, K): log2e * max_f, 1 / sum_f exp
+};
+
+template <int F, bool HAS_DST, bool HAS_W, bool GATED, bool ATT = false>
 __global__ void __launch_bounds__(F >= 128 ? 512 : 256) edge_da_split_kernel(
     const float* __restrict__ Y, const float* __restrict__ h, const int32_t* __restrict__ src,
     const int32_t* __restrict__ dst, const float* __restrict__ w, const int32_t* __restrict__ order,
-    const int32_t* __restrict__ type_ptr, const float* __restrict__ gate, float* dA, int K) {
+    const int32_t* __restrict__ type_ptr, const float* __restrict__ gate, float* dA, int K, AttGateArgs att) {
+    static_assert(!ATT || (GATED && HAS_DST), "the in-flight gate needs the destination list");
     constexpr int NC = 2 * F;                              // staged columns [y | x]
     constexpr int SLOT = NC * 16;                          // bytes of one (piece, octet) plane
     constexpr int NWV = F >= 128 ? 8 : 4;                  // waves per block
@@ -37,10 +46,12 @@ __global__ void __launch_bounds__(F >= 128 ? 512 : 256) edge_da_split_kernel(
 
     f32x16 acc[NT];
     float raw0[16], raw1[16], aux0[16], aux1[16];
+    float2 sta0 = {0.f, 0.f}, sta1 = {0.f, 0.f};           // ATT: softmax statistics of this lane's edge slot, per buffer
     for (int k = 0; k < K; ++k) {
         const int tb = type_ptr[k], te = type_ptr[k + 1];
         if (te == tb) continue;
         const int steps = (te - tb + EPS - 1) / EPS;
+        const float qk = ATT ? att.q[k * F + fcol] * 1.4426950408889634f : 0.f;
 #pragma unroll
         for (int b = 0; b < NT; ++b)
 #pragma unroll
@@ -57,11 +68,13 @@ __global__ void __launch_bounds__(F >= 128 ? 512 : 256) edge_da_split_kernel(
             const int pos = tb + EPS * st + slot;
             return order[pos < te ? pos : tb];
         };
-        auto fetch_r = [&](int e_l, int& r_l, float& w_l) {
+        auto fetch_r = [&](int e_l, int& r_l, float& w_l, int& d_l) {
             r_l = is_y ? (HAS_DST ? dst[e_l] : e_l) : src[e_l];
             w_l = (HAS_W && is_y) ? w[e_l] : 1.0f;
+            d_l = (ATT && !is_y) ? dst[e_l] : 0;
         };
-        auto load_raw = [&](float (&raw)[16], float (&aux)[16], int e_l, int r_l, float w_l) {
+        auto load_raw = [&](float (&raw)[16], float (&aux)[16], float2& sta, int e_l, int r_l, float w_l, int d_l) {
+            if (ATT && !is_y) sta = att.stats[(int64_t)d_l * K + k];
             if (is_y) {                                    // one wave-uniform branch around the whole batch
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
@@ -72,11 +85,13 @@ __global__ void __launch_bounds__(F >= 128 ? 512 : 256) edge_da_split_kernel(
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
                     raw[u] = h[(int64_t)__builtin_amdgcn_readlane(r_l, u) * F + fcol];
-                    aux[u] = GATED ? gate[(int64_t)__builtin_amdgcn_readlane(e_l, u) * F + fcol] : 1.0f;
+                    aux[u] = ATT     ? gate[(int64_t)__builtin_amdgcn_readlane(d_l, u) * F + fcol]
+                             : GATED ? gate[(int64_t)__builtin_amdgcn_readlane(e_l, u) * F + fcol]
+                                     : 1.0f;
                 }
             }
         };
-        auto park = [&](int buf, int st, const float (&raw)[16], const float (&aux)[16]) {
+        auto park = [&](int buf, int st, const float (&raw)[16], const float (&aux)[16], const float2& sta) {
             const int p0 = tb + EPS * st + 16 * og;
 #pragma unroll
             for (int o = 0; o < 2; ++o) {
@@ -85,7 +100,10 @@ __global__ void __launch_bounds__(F >= 128 ? 512 : 256) edge_da_split_kernel(
                 for (int j = 0; j < 4; ++j) {
                     const int u0 = 8 * o + j, u1 = 8 * o + 4 + j;
                     float v0 = raw[u0], v1 = raw[u1];
-                    if (HAS_W || GATED) { v0 *= aux[u0]; v1 *= aux[u1]; }
+                    if (ATT && !is_y) {
+                        v0 *= __builtin_amdgcn_exp2f(fmaf(aux[u0], 1.4426950408889634f, qk - readlane_f(sta.x, u0))) * readlane_f(sta.y, u0);
+                        v1 *= __builtin_amdgcn_exp2f(fmaf(aux[u1], 1.4426950408889634f, qk - readlane_f(sta.x, u1))) * readlane_f(sta.y, u1);
+                    } else if (HAS_W || GATED) { v0 *= aux[u0]; v1 *= aux[u1]; }
                     x0[j] = p0 + u0 < te ? v0 : 0.f;
                     x1[j] = p0 + u1 < te ? v1 : 0.f;
                 }
@@ -105,30 +123,31 @@ __global__ void __launch_bounds__(F >= 128 ? 512 : 256) edge_da_split_kernel(
         const int g = gridDim.x;
         int cur = 0;
         __syncthreads();                                    // the previous type's last buffer is no longer read
-        int e2 = 0, e3 = 0, r2 = 0;
+        int e2 = 0, e3 = 0, r2 = 0, d2 = 0;
         float w2 = 1.0f;
         if (st < steps) {
-            int e0 = fetch_e(st), r0;
+            int e0 = fetch_e(st), r0, d0;
             float w0;
-            fetch_r(e0, r0, w0);
-            load_raw(raw0, aux0, e0, r0, w0);
-            park(0, st, raw0, aux0);
-            int e1 = fetch_e(st + g), r1;
+            fetch_r(e0, r0, w0, d0);
+            load_raw(raw0, aux0, sta0, e0, r0, w0, d0);
+            park(0, st, raw0, aux0, sta0);
+            int e1 = fetch_e(st + g), r1, d1;
             float w1;
-            fetch_r(e1, r1, w1);
-            load_raw(raw0, aux0, e1, r1, w1);               // step st+g, parked by the first iteration
+            fetch_r(e1, r1, w1, d1);
+            load_raw(raw0, aux0, sta0, e1, r1, w1, d1);     // step st+g, parked by the first iteration
             e2 = fetch_e(st + 2 * g);
-            fetch_r(e2, r2, w2);
+            fetch_r(e2, r2, w2, d2);
             e3 = fetch_e(st + 3 * g);
         }
         // one step: fetch step st+2g into `rin`, multiply step st out of LDS, park step st+g (already in `rout`)
-        auto step = [&](int st_now, float (&rout)[16], float (&aout)[16], float (&rin)[16], float (&ain)[16]) {
+        auto step = [&](int st_now, float (&rout)[16], float (&aout)[16], float2& sout, float (&rin)[16], float (&ain)[16],
+                        float2& sin) {
             __syncthreads();
             const int e4 = fetch_e(st_now + 4 * g);         // consumed two iterations from now
-            int r3;
+            int r3, d3;
             float w3;
-            fetch_r(e3, r3, w3);                            // consumed next iteration
-            load_raw(rin, ain, e2, r2, w2);                 // harmless clamped re-read past the last step
+            fetch_r(e3, r3, w3, d3);                        // consumed next iteration
+            load_raw(rin, ain, sin, e2, r2, w2, d2);        // harmless clamped re-read past the last step
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < EPS / 16; ++ks) {
@@ -142,16 +161,17 @@ __global__ void __launch_bounds__(F >= 128 ? 512 : 256) edge_da_split_kernel(
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (st_now + g < steps) park(cur ^ 1, st_now + g, rout, aout);
+            if (st_now + g < steps) park(cur ^ 1, st_now + g, rout, aout, sout);
             cur ^= 1;
             e2 = e3;
             r2 = r3;
             w2 = w3;
+            d2 = d3;
             e3 = e4;
         };
         for (; st < steps; st += 2 * g) {
-            step(st, raw0, aux0, raw1, aux1);
-            if (st + g < steps) step(st + g, raw1, aux1, raw0, aux0);
+            step(st, raw0, aux0, sta0, raw1, aux1, sta1);
+            if (st + g < steps) step(st + g, raw1, aux1, sta1, raw0, aux0, sta0);
         }
         if ((int)blockIdx.x < steps) {
             float* out = dA + (int64_t)k * F * F;
@@ -181,7 +201,7 @@ static int launch_edge_da_split(const float* Y, const float* h, const int32_t* s
         static const hipError_t attr_done = [&] { LdsOptIn opt_in_; opt_in_((const void*)edge_da_split_kernel<F, D, W, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); return opt_in_.err; }();  /* once, thread-safe */ \
         if (attr_done != hipSuccess) return lds_opt_in_failed(attr_done);                                                                                                           \
         hipLaunchKernelGGL((edge_da_split_kernel<F, D, W, G>), dim3((unsigned)gx), dim3(F >= 128 ? 512 : 256), lds, s, Y, h, src, dst, \
-                           w, order, type_ptr, gate, dA, K);                                                        \
+                           w, order, type_ptr, gate, dA, K, AttGateArgs{nullptr, nullptr});                         \
     } while (0)
     const bool hw = dst && w;
     if (!dst) { if (gate) MPNN_DA(false, false, true); else MPNN_DA(false, false, false); }
@@ -189,6 +209,26 @@ static int launch_edge_da_split(const float* Y, const float* h, const int32_t* s
     else { if (gate) MPNN_DA(true, true, true); else MPNN_DA(true, true, false); }
 #undef MPNN_DA
     return launch_status("mpnn_edge_message_bwd_f32(dA, bf16x6)");
+}
+
+// width 128 with AttEdgeNetwork's gate evaluated in flight (see AttGateArgs)
+int launch_edge_da_att128(const float* Y, const float* h, const int32_t* src, const int32_t* dst, const int32_t* order,
+                          const int32_t* type_ptr, const float* z_atom, const float* q, const float* stats_by_atom, float* dA,
+                          int64_t E, int K, hipStream_t s) {
+    constexpr int F = 128;
+    const size_t lds = (size_t)2 * 3 * 4 * (2 * F) * 16;
+    static const hipError_t attr_done = [&] {
+        LdsOptIn opt_in_;
+        opt_in_((const void*)edge_da_split_kernel<F, true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return opt_in_.err;
+    }();
+    if (attr_done != hipSuccess) return lds_opt_in_failed(attr_done);
+    int64_t gx = 256;
+    const int64_t need = ceil_div(E, 32) + K;
+    if (gx > need) gx = need;
+    hipLaunchKernelGGL((edge_da_split_kernel<F, true, false, true, true>), dim3((unsigned)gx), dim3(512), lds, s, Y, h, src, dst,
+                       nullptr, order, type_ptr, z_atom, dA, K, AttGateArgs{q, reinterpret_cast<const float2*>(stats_by_atom)});
+    return launch_status("mpnn_edge_message_agg_bwd_da_att_f32");
 }
 
 int launch_edge_da_split128(const float* Y, const float* h, const int32_t* src, const int32_t* dst, const float* w,

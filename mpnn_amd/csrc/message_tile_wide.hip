@@ -33,6 +33,14 @@ namespace mpnn {
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
+#ifdef MB_STAMP   // diagnostic build only (-DMB_STAMP): cycle sums of the gated backward kernel, block 3, wave 0
+__device__ unsigned long long g_mb_stamps[16];
+#define MB_T(var) unsigned long long var; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0)
+#define MB_ADD(i, v) do { if (blockIdx.x == 3 && tid == 0) g_mb_stamps[i] += (v); } while (0)
+#else
+#define MB_T(var)
+#define MB_ADD(i, v)
+#endif
 #ifdef MW_STAMP   // diagnostic build only (-DMW_STAMP): cycle sums per phase part of block 3, waves 0 and 7
 __device__ unsigned long long g_mw_stamps[32];
 #define MW_T(var) unsigned long long var; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0)
@@ -520,6 +528,378 @@ __global__ void __launch_bounds__(512) message_sum_wide_kernel(
 
 #undef MW_ZLOAD
 
+// ------------------------------------------------------------------------------ gated message + sum: backward per (atom, type)
+// att_edge_network.py:18-31 composed with adjacent_message_agg.py:18, differentiated for the gate logits.  With
+//   out[i] = sum_k A_k X_ik,   X_ik = g_ik * S_ik,   g_ik = softmax_f(z_i + q_k),   S_ik = sum_{e in row i, type k} h[src e]
+// the gradient of the logits l_ik = z_i + q_k of an (atom, type) pair with edges is
+//   T_ik = A_k^T dout_i,   u_ik = X_ik * T_ik,   D_ik = sum_f u_ikf,   dl_ik = u_ik - g_ik D_ik
+// and dz_i = sum_k dl_ik, dq_k = sum_i dl_ik.  No (E, F) gate or gate-gradient tensor exists: the kernel walks the forward's
+// plan -- the same tiles, blocks, phases (32-column chunk kc of the h rows x bond type k), LDS images and copies -- and per
+// phase forms S (from the h chunk image), g (from the atom's logits and the forward's softmax statistics) and the chunk of
+// T^T = (A_k^T chunk) . dout^T on the matrix pipe: the chunk of A_k^T is the A operand (from the pre-split LDS image), the
+// block's 32 dout rows are the B operand -- split ONCE per tile behind an exact per-atom power-of-two scale and held in
+// registers (64) for the tile's 16 phases.  The accumulator lane (atom, half) then holds the T entries of ITS atom: S, g and
+// the logits are fetched in that layout (16-byte pieces at columns 8 q + 4 half), and every later step is per-lane.
+//   * D_ik spans all four chunks, so the first term sum_k u_ik is written to dz per chunk (16 registers, not 64) and the
+//     second term is subtracted when the tile's phases are done (the rows are still in L2): g is re-evaluated, one exp each;
+//   * dq: the atom sums of the first term are column sums of A_k * dA_k (dA_k = sum_i dout_i (x) X_ik is the weight gradient
+//     the caller has anyway), so the kernel only reduces the second term over its block's atoms (through a per-wave LDS
+//     transposition: 80 dependent DPP adds per (chunk, type) took 30 % of the kernel) into per-wave LDS accumulators,
+//     written once per wave as dq_part rows; the caller adds them up (fixed order: deterministic);
+//   * stats_atom: the forward's softmax statistics in ATOM order, for the weight-gradient kernel's in-flight gate.
+constexpr int MB_DQ = MW_NB * 4 * 128 * 4;              // per-wave dq accumulators: [wave][type <= 4][128 columns] floats
+__host__ __device__ constexpr int mb_lds_bytes() { return ((mw_lds_bytes<128>() + 15) & ~15) + MB_DQ; }
+
+// A_k^T chunk images: chunk (kc, k) at 64 + (kc * K + k) * 16 KB: [piece hi | lo][nf column n of the chunk (32)][16 slots of
+// 8 halves]; slot oc ^ (n & 15) holds A_k[mf = 8 oc + j][nf = 32 kc + n] * scale, j = 0..7 (an A fragment = 32 rows x 16
+// bytes with the slots of 16 consecutive rows all different: conflict-free ds_read_b128)
+__global__ void __launch_bounds__(256) mw_split_t_kernel(const float* __restrict__ A, char* __restrict__ ws, int K) {
+    constexpr int F = 128;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int per_k = F * (F / 8);
+    if (idx >= (int64_t)K * per_k) return;
+    const int k = (int)(idx / per_k), rem = (int)(idx % per_k);
+    const int oc = rem / F, col = rem % F;               // consecutive threads: consecutive nf columns of one mf octet
+    const int kc = col >> 5, n = col & 31;
+    const float sc = reinterpret_cast<const float*>(ws)[0];
+    const float* p = A + ((int64_t)k * F + 8 * oc) * F + col;
+    h16x8 ph, pl;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float a = p[(int64_t)j * F] * sc;
+        ph[j] = (_Float16)a;
+        pl[j] = (_Float16)(a - (float)ph[j]);
+    }
+    char* dst = ws + 64 + ((int64_t)kc * K + k) * (F * 128) + n * (2 * F) + ((oc ^ (n & 15)) << 4);
+    *reinterpret_cast<h16x8*>(dst) = ph;
+    *reinterpret_cast<h16x8*>(dst + F * 64) = pl;
+}
+
+__global__ void __launch_bounds__(512) att_message_bwd_tile_kernel(
+    const float* __restrict__ h, const float* __restrict__ dout, const char* __restrict__ ws,
+    const int32_t* __restrict__ tile_rec, const int32_t* __restrict__ tile_atom, const int32_t* __restrict__ blk_off,
+    const int16_t* __restrict__ slots, MwGate gt, float* __restrict__ dz, float* __restrict__ dq_part,
+    float2* __restrict__ stats_atom, int num_tiles, int K) {
+    constexpr int F = 128, NKC = 4, ABUF = F * 128;
+    __shared__ float qs_s[4 * F];                         // log2(e) * q
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const HB = smem;
+    char* const AB = smem + 2 * MW_HB;
+    int16_t* const SL = reinterpret_cast<int16_t*>(AB + 2 * ABUF);
+    int* const AT = reinterpret_cast<int*>(reinterpret_cast<char*>(SL) + MW_ROWS * 64);
+    int* const OFF = AT + MW_TV;
+    float* const DQ = reinterpret_cast<float*>(smem + ((mw_lds_bytes<128>() + 15) & ~15));
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hi = lane >> 5;
+    const float a_inv = reinterpret_cast<const float*>(ws)[1];
+    const char* const wsA = ws + 64;
+    const int nphase = NKC * K;
+    for (int i = tid; i < 4 * F; i += 512) qs_s[i] = i < K * F ? gt.q[i] * MW_LOG2E : 0.f;
+    for (int i = lane; i < 4 * F; i += 64) DQ[wv * 4 * F + i] = 0.f;
+    if (tid < 16) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(HB + MW_TV * 128 + 16 * (tid & 7) + (tid >> 3) * MW_HB) = z;
+    }
+    auto copy_h = [&](int a0, int n, int kc, int buf, int rank, int share) {
+        for (int row8 = rank; row8 < 32; row8 += share) {
+            const int row = 8 * row8 + (lane >> 3), c = lane & 7;
+            const int rr = row < n ? row : n - 1;
+            const char* src = reinterpret_cast<const char*>(h + (int64_t)(a0 + rr) * F + 32 * kc) + ((c ^ (row & 7)) << 4);
+            mw_copy(src, lds_addr(HB + buf * MW_HB + row8 * 1024));
+        }
+    };
+    auto copy_a = [&](int phase, int buf, int rank, int share) {
+        const char* src = wsA + (int64_t)phase * ABUF + lane * 16;
+        for (int blk = rank; blk < F / 8; blk += share) mw_copy(src + blk * 1024, lds_addr(AB + buf * ABUF + blk * 1024));
+    };
+    // S in the accumulator's layout: lane (atom r, half) takes the 16-byte pieces 2 q + half of a source row (columns 8 q + 4 half ..)
+    auto add_row = [&](const char* hb, int w, f32x4 (&s)[4]) {
+        const char* row = hb + w * 128;
+        const int sw = w & 7;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[q] += *reinterpret_cast<const f32x4*>(row + (((2 * q + hi) ^ sw) << 4));
+    };
+    auto gather = [&](const char* hb, int base, int cnt, f32x4 (&s)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int16_t* sl = SL + base * 32 + r;
+        int w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ww = sl[32 * (q < cnt ? q : 0)];
+            w[q] = q < cnt ? ww : MW_TV;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) add_row(hb, w[q], s);
+        if (cnt > 2) {
+#pragma unroll
+            for (int q = 2; q < 4; ++q) add_row(hb, w[q], s);
+            if (cnt > 4) {
+                int wq = sl[32 * 4];
+                for (int q = 4; q < cnt; ++q) {
+                    const int wn = sl[32 * (q + 1 < cnt ? q + 1 : q)];
+                    add_row(hb, wq, s);
+                    wq = wn;
+                }
+            }
+        }
+    };
+
+    // this lane's dout row (columns 16 s + 8 hi ..): requested a tile ahead -- before the loop, then at the start of the
+    // finishing part of the tile before (the registers of the split pieces are free then) -- and split at the tile's top
+    f32x4 x[16];
+    auto load_dout = [&](int atom) {
+        const float* dp = dout + (int64_t)(atom < 0 ? 0 : atom) * F + 8 * hi;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            x[2 * s] = *reinterpret_cast<const f32x4*>(dp + 16 * s);
+            x[2 * s + 1] = *reinterpret_cast<const f32x4*>(dp + 16 * s + 4);
+        }
+    };
+    int t = blockIdx.x;
+    int a0 = 0, n = 1, at_next = -1;
+    if (t < num_tiles) {
+        a0 = tile_rec[4 * t];
+        n = tile_rec[4 * t + 1];
+        copy_h(a0, n, 0, 0, wv, 8);
+        copy_a(0, 0, wv, 8);
+        at_next = tile_atom[(int64_t)t * MW_TV + 32 * wv + r];
+        load_dout(at_next);
+    }
+    for (; t < num_tiles; t += gridDim.x) {
+        const int row0 = tile_rec[4 * t + 2], nrows = tile_rec[4 * t + 3];
+        const int tn = t + (int)gridDim.x;
+        const bool more = tn < num_tiles;
+        const int a0n = more ? tile_rec[4 * tn] : a0, nn = more ? tile_rec[4 * tn + 1] : n;
+        const int at = at_next;                           // (= AT[32 wv + r] below)
+        at_next = more ? tile_atom[(int64_t)tn * MW_TV + 32 * wv + r] : -1;
+        mw_barrier();
+        {
+            const int4* sp = reinterpret_cast<const int4*>(slots + (int64_t)row0 * 32);
+            const int nq = nrows * 4;
+            int4 q0 = {0, 0, 0, 0}, q1 = {0, 0, 0, 0};
+            int at_v = 0, off_v = 0;
+            if (tid < nq) q0 = sp[tid];
+            if (tid + 512 < nq) q1 = sp[tid + 512];
+            if (tid < MW_TV) at_v = tile_atom[(int64_t)t * MW_TV + tid];
+            if (tid < MW_NB * K + 1) off_v = blk_off[(int64_t)t * (MW_NB * K + 1) + tid];
+            __builtin_amdgcn_sched_barrier(0);
+            if (tid < nq) reinterpret_cast<int4*>(SL)[tid] = q0;
+            if (tid + 512 < nq) reinterpret_cast<int4*>(SL)[tid + 512] = q1;
+            if (tid < MW_TV) AT[tid] = at_v;
+            if (tid < MW_NB * K + 1) OFF[tid] = off_v;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        mw_barrier();
+        int amask = 0;
+        for (int k = 0; k < K; ++k)
+            amask |= (__builtin_amdgcn_readfirstlane(OFF[wv * K + k + 1]) > __builtin_amdgcn_readfirstlane(OFF[wv * K + k])) << k;
+        const unsigned long long pairs = __builtin_amdgcn_ballot_w64(lane < MW_NB * K && OFF[lane < MW_NB * K ? lane + 1 : 1] >
+                                                                                       OFF[lane < MW_NB * K ? lane : 0]);
+        // ---- this lane's atom: logits row, softmax statistics, dout row (split once, exact row scale)
+        MB_T(t0);
+        const bool live = at >= 0;
+        const int64_t arow = (int64_t)(live ? at : 0) * F;
+        const float* zp = gt.z_atom + arow + 4 * hi;
+        const float2* sp2 = gt.stats + ((int64_t)t * MW_TV + 32 * wv + r) * K;
+        float2 st0 = sp2[0], st1 = sp2[K > 1 ? 1 : 0], st2 = sp2[K > 2 ? 2 : 0], st3 = sp2[K > 3 ? 3 : 0];
+        if (!live) st0 = st1 = st2 = st3 = float2{3.0e38f, 0.f};   // (positions past the tile's atoms were never written): gate 0
+        if (live && hi == 0) {
+            float2* so = stats_atom + (int64_t)at * K;
+            so[0] = st0;
+            if (K > 1) so[1] = st1;
+            if (K > 2) so[2] = st2;
+            if (K > 3) so[3] = st3;
+        }
+        h16x8 dh[8], dl[8];
+        float tsc = 0.f;                                   // un-scale of an accumulator entry: 1 / (matrix scale * row scale)
+        if (amask != 0) {
+            float mx = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mx = fmaxf(mx, fabsf(x[s][j]));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            int e = (__float_as_int(mx) >> 23) & 0xff;
+            e = e < 20 ? 20 : (e > 250 ? 250 : e);
+            const float dsc = live ? __int_as_float((267 - e) << 23) : 0.f;     // largest |dout| of the row lands in [2^13, 2^14)
+            tsc = __int_as_float((e - 13) << 23) * a_inv;
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = x[2 * s][j] * dsc, b = x[2 * s + 1][j] * dsc;
+                    dh[s][j] = (_Float16)a;
+                    dl[s][j] = (_Float16)(a - (float)dh[s][j]);
+                    dh[s][4 + j] = (_Float16)b;
+                    dl[s][4 + j] = (_Float16)(b - (float)dh[s][4 + j]);
+                }
+        }
+        f32x4 zc[4];
+#define MB_ZLOAD(Z, KC)                                                                        \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) Z[q] = *reinterpret_cast<const f32x4*>(zp + 32 * (KC) + 8 * q)
+        f32x4 P[4];                                       // first term of dz, current chunk
+#pragma unroll
+        for (int q = 0; q < 4; ++q) P[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float D0 = 0.f, D1 = 0.f, D2 = 0.f, D3 = 0.f;     // this lane's part of D_ik (its 64 of the atom's 128 columns)
+        MB_T(t1);
+        MB_ADD(0, t1 - t0);
+        MB_ADD(15, 1);
+
+        for (int ph = 0; ph < nphase; ++ph) {
+            const int kc = ph / K, k = ph - kc * K;
+            MB_T(p0);
+            mw_barrier();
+            MB_T(p1);
+            int idle = 0;
+            for (int b = 0; b < MW_NB; ++b) idle |= (int)(((pairs >> (b * K + k)) & 1ull) ^ 1ull) << b;
+            const bool i_copy = idle == 0 || ((idle >> wv) & 1);
+            const int share = idle == 0 ? MW_NB : __builtin_popcount(idle);
+            const int rank = idle == 0 ? wv : __builtin_popcount(idle & ((1 << wv) - 1));
+            if (i_copy) {
+                if (ph + 1 < nphase) copy_a(ph + 1, (ph + 1) & 1, rank, share);
+                else if (more) copy_a(0, 0, rank, share);
+                if (k == 0) {
+                    if (kc + 1 < NKC) copy_h(a0, n, kc + 1, (kc + 1) & 1, rank, share);
+                    else if (more) copy_h(a0n, nn, 0, 0, rank, share);
+                }
+            }
+            if (k == 0 && amask != 0) { MB_ZLOAD(zc, kc); }   // first used behind this phase's products
+            MB_T(p2);
+            MB_ADD(1, p1 - p0);
+            MB_ADD(2, p2 - p1);
+            if ((amask >> k) & 1) {
+                const char* hb = HB + (kc & 1) * MW_HB;
+                const char* ab = AB + (ph & 1) * ABUF + r * (2 * F);
+                // T^T chunk: rows = the chunk's 32 nf columns, columns = the block's atoms; contraction over mf in 8 steps
+                f32x16 acc, acc2;                          // two chains: a product does not wait for the one before it
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = acc2[i] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 8; s += 2) {
+                    const char* p = ab + (((2 * s + hi) ^ (r & 15)) << 4);
+                    const char* p2 = ab + (((2 * s + 2 + hi) ^ (r & 15)) << 4);
+                    const h16x8 wh = *reinterpret_cast<const h16x8*>(p), wl = *reinterpret_cast<const h16x8*>(p + F * 64);
+                    const h16x8 vh = *reinterpret_cast<const h16x8*>(p2), vl = *reinterpret_cast<const h16x8*>(p2 + F * 64);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, dh[s], acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, dh[s + 1], acc2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, dl[s], acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, dl[s + 1], acc2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, dh[s], acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, dh[s + 1], acc2, 0, 0, 0);
+                }
+                MB_T(p3);
+                f32x4 s[4];
+                const int b0 = __builtin_amdgcn_readfirstlane(OFF[wv * K + k]);
+                gather(hb, b0, __builtin_amdgcn_readfirstlane(OFF[wv * K + k + 1]) - b0, s);
+                MB_T(p4);
+                const float m = k == 0 ? st0.x : k == 1 ? st1.x : k == 2 ? st2.x : st3.x;
+                const float iv = (k == 0 ? st0.y : k == 1 ? st1.y : k == 2 ? st2.y : st3.y) * tsc;
+                const float* qp = qs_s + k * F + 32 * kc + 4 * hi;
+                float dsum = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 qv = *reinterpret_cast<const f32x4*>(qp + 8 * q);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float xg = __builtin_amdgcn_exp2f(fmaf(zc[q][j], MW_LOG2E, qv[j] - m)) * iv * s[q][j];   // X * un-scale
+                        const float u = xg * (acc[4 * q + j] + acc2[4 * q + j]);
+                        dsum += u;
+                        P[q][j] += u;
+                    }
+                }
+                D0 += k == 0 ? dsum : 0.f;
+                D1 += k == 1 ? dsum : 0.f;
+                D2 += k == 2 ? dsum : 0.f;
+                D3 += k == 3 ? dsum : 0.f;
+                MB_T(p5);
+                MB_ADD(3, p3 - p2);
+                MB_ADD(4, p4 - p3);
+                MB_ADD(5, p5 - p4);
+                MB_ADD(14, 1);
+            }
+            MB_T(p6);
+            if (k == K - 1) {                              // the chunk is done: first term of its dz columns
+                if (live) {
+                    float* o = dz + arow + 32 * kc + 4 * hi;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(o + 8 * q) = P[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) P[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            MB_T(p7);
+            if (i_copy) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            MB_T(p8);
+            MB_ADD(6, p7 - p6);
+            MB_ADD(7, p8 - p7);
+        }
+        // ---- second term: dz -= sum_k g_k D_k, dq_k -= sum_atoms g_k D_k
+        MB_T(f0);
+        mw_barrier();                                      // every wave is done with the last chunk's h image (buffer 1): its
+                                                           // first 32 KB are the waves' transposition areas until the next tile
+        load_dout(at_next);                                // (no next tile: row 0, never used)
+        if (amask != 0) {
+            char* const SC = HB + MW_HB + wv * 4096;       // 32 atoms x 32 columns
+            D0 += __shfl_xor(D0, 32);
+            D1 += __shfl_xor(D1, 32);
+            D2 += __shfl_xor(D2, 32);
+            D3 += __shfl_xor(D3, 32);
+            if (!live) D0 = D1 = D2 = D3 = 0.f;
+            for (int kc = 0; kc < NKC; ++kc) {
+                float* o = dz + arow + 32 * kc + 4 * hi;
+                f32x4 zz[4], pp[4];
+                MB_ZLOAD(zz, kc);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pp[q] = *reinterpret_cast<const f32x4*>(o + 8 * q);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (!((amask >> k) & 1)) continue;
+                    const float m = k == 0 ? st0.x : k == 1 ? st1.x : k == 2 ? st2.x : st3.x;
+                    const float gd = (k == 0 ? st0.y : k == 1 ? st1.y : k == 2 ? st2.y : st3.y) *
+                                     (k == 0 ? D0 : k == 1 ? D1 : k == 2 ? D2 : D3);
+                    const float* qp = qs_s + k * F + 32 * kc + 4 * hi;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 qv = *reinterpret_cast<const f32x4*>(qp + 8 * q);
+                        f32x4 v;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            v[j] = __builtin_amdgcn_exp2f(fmaf(zz[q][j], MW_LOG2E, qv[j] - m)) * gd;
+                            pp[q][j] -= v[j];
+                        }
+                        *reinterpret_cast<f32x4*>(SC + r * 128 + (((2 * q + hi) ^ (r & 7)) << 4)) = v;
+                    }
+                    // sum over the block's atoms: lane (column c, half) adds 16 atoms of its column, the halves meet by a swap
+                    float sum = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int a = 16 * hi + j;
+                        sum += *reinterpret_cast<const float*>(SC + a * 128 + (((r >> 2) ^ (a & 7)) << 4) + 4 * (r & 3));
+                    }
+                    sum += __shfl_xor(sum, 32);
+                    if (hi == 0) DQ[(wv * 4 + k) * F + 32 * kc + r] += sum;
+                }
+                if (live) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(o + 8 * q) = pp[q];
+                }
+            }
+        }
+        MB_T(f1);
+        MB_ADD(8, f1 - f0);
+        a0 = a0n;
+        n = nn;
+    }
+    // ---- this wave's dq sums (second term; the caller subtracts them from the column sums of A * dA)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int i = lane; i < 4 * F; i += 64)
+        if (i < K * F) dq_part[((int64_t)blockIdx.x * MW_NB + wv) * K * F + i] = DQ[wv * 4 * F + i];
+}
+#undef MB_ZLOAD
+
 // ------------------------------------------------------------------------------------------ width 64: resident matrices
 // At nf = mf = 64 the K <= 4 matrices fit in LDS as fp16 piece pairs (16 KB per type) next to a whole 256-atom tile of h
 // rows (64 KB as fp32), so nothing is streamed in phases: after the tile's rows are parked (they were fetched into
@@ -795,10 +1175,40 @@ static int launch_message_wide_t(const float* h, const float* A, const int32_t* 
     return launch_status("mpnn_message_aggregate_wide_f32");
 }
 
+constexpr int MB_BLOCKS = 256;                           // one block per CU
+static int launch_att_message_bwd(const float* h, const float* A, const float* z_atom, const float* q, const float* dout,
+                                  const float2* stats, const int32_t* tile_rec, const int32_t* tile_atom,
+                                  const int32_t* blk_off, const int16_t* slots, float* dz, float* dq_part, float2* stats_atom,
+                                  void* workspace, int64_t num_tiles, int K, hipStream_t s) {
+    static const hipError_t attr = [] {
+        LdsOptIn opt_in_;
+        opt_in_((const void*)att_message_bwd_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, mb_lds_bytes());
+        return opt_in_.err;
+    }();
+    if (attr != hipSuccess) return lds_opt_in_failed(attr);
+    char* ws = (char*)workspace;
+    hipLaunchKernelGGL(mw_absmax_kernel, dim3(1), dim3(1024), 0, s, A, (int64_t)K * 128 * 128, (float*)ws);
+    hipLaunchKernelGGL(mw_split_t_kernel, dim3((unsigned)((K * 2048 + 255) / 256)), dim3(256), 0, s, A, ws, K);
+    int64_t blocks = MB_BLOCKS;
+    if (blocks > num_tiles) blocks = num_tiles;
+    hipLaunchKernelGGL(att_message_bwd_tile_kernel, dim3((unsigned)blocks), dim3(512), mb_lds_bytes(), s, h, dout, ws, tile_rec,
+                       tile_atom, blk_off, slots, MwGate{z_atom, q, stats}, dz, dq_part, stats_atom, (int)num_tiles, K);
+    return launch_status("mpnn_message_aggregate_wide_gated_bwd_f32");
+}
+
 }  // namespace mpnn
 
 using namespace mpnn;
 
+#ifdef MB_STAMP
+extern "C" int mpnn_debug_mb_stamps(unsigned long long* host16, int reset) {
+    if (reset) {
+        unsigned long long z[16] = {0};
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_mb_stamps), z, sizeof(z));
+    }
+    return (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_mb_stamps), 16 * sizeof(unsigned long long));
+}
+#endif
 #ifdef MW_STAMP
 extern "C" int mpnn_debug_mw_stamps(unsigned long long* host32, int reset) {
     if (reset) {
@@ -857,4 +1267,34 @@ extern "C" int mpnn_message_aggregate_wide_gated_f32(const float* h, const float
                  message_wide_gated_workspace_bytes(K, nf, num_tiles));
     return launch_message_wide_t<128>(h, A, tile_rec, tile_atom, blk_off, slots, out, workspace, num_tiles, K,
                                       (hipStream_t)stream, z_atom, q);
+}
+
+extern "C" size_t mpnn_message_aggregate_wide_gated_bwd_workspace_bytes(int K, int nf) {
+    return message_wide_workspace_bytes(K, nf);
+}
+extern "C" int mpnn_message_aggregate_wide_gated_bwd_parts(void) { return MB_BLOCKS * MW_NB; }
+
+extern "C" int mpnn_message_aggregate_wide_gated_bwd_f32(const float* h, const float* A, const float* z_atom, const float* q,
+                                                         const float* dagg, const void* fwd_workspace,
+                                                         size_t fwd_workspace_bytes, const int32_t* tile_rec,
+                                                         const int32_t* tile_atom, const int32_t* blk_off,
+                                                         const int16_t* slots, float* dz_atom, float* dq_part,
+                                                         float* stats_by_atom, void* workspace, size_t workspace_bytes,
+                                                         int64_t V, int64_t num_tiles, int K, int nf, int mf, void* stream) {
+    MPNN_REQUIRE(nf == mf && nf == 128, "mpnn_message_aggregate_wide_gated_bwd_f32: nf = mf = 128 only (got %d, %d)", nf, mf);
+    MPNN_REQUIRE(K >= 1 && K <= 4, "mpnn_message_aggregate_wide_gated_bwd_f32: 1 <= K <= 4 bond types (got %d)", K);
+    MPNN_REQUIRE(V >= 0 && num_tiles >= 0 && num_tiles < (1ll << 24), "mpnn_message_aggregate_wide_gated_bwd_f32: bad sizes");
+    if (V == 0 || num_tiles == 0) return MPNN_OK;
+    MPNN_REQUIRE(h && A && z_atom && q && dagg && fwd_workspace && tile_rec && tile_atom && blk_off && slots && dz_atom &&
+                     dq_part && stats_by_atom && workspace,
+                 "mpnn_message_aggregate_wide_gated_bwd_f32: NULL buffer");
+    MPNN_REQUIRE(fwd_workspace_bytes >= message_wide_gated_workspace_bytes(K, nf, num_tiles),
+                 "mpnn_message_aggregate_wide_gated_bwd_f32: forward workspace of %zu bytes, need %zu", fwd_workspace_bytes,
+                 message_wide_gated_workspace_bytes(K, nf, num_tiles));
+    MPNN_REQUIRE(workspace_bytes >= message_wide_workspace_bytes(K, nf),
+                 "mpnn_message_aggregate_wide_gated_bwd_f32: workspace of %zu bytes, need %zu", workspace_bytes,
+                 message_wide_workspace_bytes(K, nf));
+    const float2* stats = reinterpret_cast<const float2*>((const char*)fwd_workspace + message_wide_workspace_bytes(K, nf));
+    return launch_att_message_bwd(h, A, z_atom, q, dagg, stats, tile_rec, tile_atom, blk_off, slots, dz_atom, dq_part,
+                                  reinterpret_cast<float2*>(stats_by_atom), workspace, num_tiles, K, (hipStream_t)stream);
 }

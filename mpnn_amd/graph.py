@@ -44,7 +44,7 @@ def _host_tiles(g, tv, lib):
 def _fast_path(g, K, kmax):
     """The purpose-made index kernels (csrc/plan.hip) serve device-resident batches with few bond types; everything else
     (CPU tensors: the tests' walk-throughs; continuous bond features) takes the torch builders below."""
-    return g.device.type == "cuda" and 1 <= K <= kmax and g.num_nodes > 0 and g.num_graphs > 0 and \
+    return g.device.type == "cuda" and 1 <= K <= kmax and g.num_nodes > 0 and g.num_graphs > 0 and g.num_edges > 0 and \
         g.edge_type.dtype == torch.int32
 
 

@@ -201,13 +201,14 @@ def wide_gated_applies(A, w, graph):
     return nf == 128 and K <= 4 and wide_kernel_applies(A, None, w, graph)
 
 
-def message_aggregate_wide_gated_raw(h, A, z_atom, q, graph):
+def message_aggregate_wide_gated_raw(h, A, z_atom, q, graph, keep_workspace=False):
     lib = _lib.load()
     K, mf, nf = (int(s) for s in A.shape)
     V = graph.num_nodes
     plan = graph.wide_plan
     if V == 0 or graph.num_edges == 0:
-        return torch.zeros(V, mf, dtype=torch.float32, device=h.device)
+        out = torch.zeros(V, mf, dtype=torch.float32, device=h.device)
+        return (out, None) if keep_workspace else out
     out = _empty((V, mf), h)
     ws_bytes = lib.mpnn_message_aggregate_wide_gated_workspace_bytes(K, nf, plan.num_tiles)
     ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=h.device)
@@ -215,7 +216,38 @@ def message_aggregate_wide_gated_raw(h, A, z_atom, q, graph):
         _lib.fptr(h), _lib.fptr(A), _lib.fptr(z_atom), _lib.fptr(q), _lib.iptr(plan.tile_rec), _lib.iptr(plan.tile_atom),
         _lib.iptr(plan.blk_off), _lib.ptr(plan.slots, torch.int16), _lib.fptr(out), _lib.ptr(ws), ws_bytes, V,
         plan.num_tiles, K, nf, mf, _lib.stream())), "mpnn_message_aggregate_wide_gated_f32")
+    if keep_workspace:
+        return out, ws
     return out
+
+
+def message_aggregate_wide_gated_bwd_raw(h, A, z_atom, q, dout, fwd_ws, graph):
+    """Backward of the gated message + sum per (atom, type) on the forward's plan -> (dA, dz_atom, dq); no (E, nf) tensor.
+    Two kernels: the logits' gradient on the plan (mpnn_message_aggregate_wide_gated_bwd_f32, which also hands the softmax
+    statistics over in atom order), then the matrices' gradient with the gate evaluated in flight
+    (mpnn_edge_message_agg_bwd_da_att_f32); dq's first term is read off A * dA (include/mpnn_amd.h has the algebra)."""
+    lib = _lib.load()
+    K, mf, nf = (int(s) for s in A.shape)
+    V, E = graph.num_nodes, graph.num_edges
+    plan = graph.wide_plan
+    dz = _empty((V, nf), h)
+    parts = int(lib.mpnn_message_aggregate_wide_gated_bwd_parts())
+    dq_part = torch.zeros((parts, K, nf), dtype=torch.float32, device=h.device)
+    stats_atom = _empty((V, K, 2), h)
+    ws_bytes = lib.mpnn_message_aggregate_wide_gated_bwd_workspace_bytes(K, nf)
+    ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=h.device)
+    _lib.check(_timed("att_message_bwd", lambda: lib.mpnn_message_aggregate_wide_gated_bwd_f32(
+        _lib.fptr(h), _lib.fptr(A), _lib.fptr(z_atom), _lib.fptr(q), _lib.fptr(dout), _lib.ptr(fwd_ws), fwd_ws.numel() * 4,
+        _lib.iptr(plan.tile_rec), _lib.iptr(plan.tile_atom), _lib.iptr(plan.blk_off), _lib.ptr(plan.slots, torch.int16),
+        _lib.fptr(dz), _lib.fptr(dq_part), _lib.fptr(stats_atom), _lib.ptr(ws), ws_bytes, V, plan.num_tiles, K, nf, mf,
+        _lib.stream())), "mpnn_message_aggregate_wide_gated_bwd_f32")
+    dA = torch.zeros_like(A)
+    _lib.check(_timed("message_aggregate_bwd", lambda: lib.mpnn_edge_message_agg_bwd_da_att_f32(
+        _lib.fptr(dout), _lib.fptr(h), _lib.iptr(graph.col_idx), _lib.iptr(graph.edge_dst), _lib.iptr(graph.order),
+        _lib.iptr(graph.type_ptr), _lib.fptr(z_atom), _lib.fptr(q), _lib.fptr(stats_atom), _lib.fptr(dA), V, E, K, nf, mf,
+        _lib.stream())), "mpnn_edge_message_agg_bwd_da_att_f32")
+    dq = (A * dA).sum(1) - dq_part.sum(0)
+    return dA, dz, dq
 
 
 def edge_message_bwd_raw(h, A, graph, gate, dmsg, need_dx=True, need_dA=True):
@@ -996,10 +1028,16 @@ class LazyAttGate:
         return self._gate
 
 
+# True: GatedMessageAggregate's backward on per-EDGE tensors (the gate re-evaluated into an (E, nf) tensor, then the kernels of
+# the unfused path) -- what the fp32-only mode runs, and the reference the per-(atom, type) kernels are tested against
+ATT_BWD_PER_EDGE = False
+
+
 class GatedMessageAggregate(torch.autograd.Function):
     """out[i] = sum_{e in row i} A[type e] . (softmax_f(z_atom[i] + q[type e]) * h[src e]): AttEdgeNetwork followed by
     AdjMsgAgg (att_edge_network.py:18-31, adjacent_message_agg.py:18) as ONE kernel without an (E, F) gate tensor
-    (mpnn_message_aggregate_wide_gated_f32).  Backward: the gate is re-evaluated (mpnn_att_gate_f32), then the kernels of
+    (mpnn_message_aggregate_wide_gated_f32).  Backward: per (atom, type) on the same plan
+    (message_aggregate_wide_gated_bwd_raw); in fp32-only mode the gate is re-evaluated (mpnn_att_gate_f32) and the kernels of
     the unfused path -- weight gradient and gate gradient straight from dout[dst e], softmax backward -- run on it."""
 
     @staticmethod
@@ -1007,7 +1045,8 @@ class GatedMessageAggregate(torch.autograd.Function):
         h, A, z_atom, q = h.contiguous(), A.contiguous(), z_atom.contiguous(), q.contiguous()
         ctx.graph = graph
         ctx.save_for_backward(h, A, z_atom, q)
-        return message_aggregate_wide_gated_raw(h, A, z_atom, q, graph)
+        out, ctx.fwd_ws = message_aggregate_wide_gated_raw(h, A, z_atom, q, graph, keep_workspace=True)
+        return out
 
     @staticmethod
     def backward(ctx, dout):
@@ -1026,6 +1065,11 @@ class GatedMessageAggregate(torch.autograd.Function):
             want = [t for t in leaves if t.requires_grad]
             got = iter(torch.autograd.grad(out, want, dout, allow_unused=True)) if want else iter(())
             return tuple(next(got) if t.requires_grad else None for t in leaves) + (None,)
+        if (not ATT_BWD_PER_EDGE and ctx.fwd_ws is not None and os.environ.get("MPNN_GRU_MATH") != "fp32"
+                and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])):
+            dA, dz_atom, dq = message_aggregate_wide_gated_bwd_raw(h, A, z_atom, q, dout, ctx.fwd_ws, g)
+            return (None, dA if ctx.needs_input_grad[1] else None, dz_atom if ctx.needs_input_grad[2] else None,
+                    dq if ctx.needs_input_grad[3] else None, None)
         gate = _empty((E, nf), h)
         _lib.check(lib.mpnn_att_gate_f32(_lib.fptr(z_atom), _lib.fptr(q), _lib.iptr(g.edge_dst), _lib.iptr(g.edge_type),
                                          _lib.fptr(gate), V, E, K, nf, _lib.stream()), "mpnn_att_gate_f32")
