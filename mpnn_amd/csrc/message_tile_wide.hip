@@ -548,7 +548,8 @@ __global__ void __launch_bounds__(512) message_sum_wide_kernel(
 //     written once per wave as dq_part rows; the caller adds them up (fixed order: deterministic);
 //   * stats_atom: the forward's softmax statistics in ATOM order, for the weight-gradient kernel's in-flight gate.
 constexpr int MB_DQ = MW_NB * 4 * 128 * 4;              // per-wave dq accumulators: [wave][type <= 4][128 columns] floats
-__host__ __device__ constexpr int mb_lds_bytes() { return ((mw_lds_bytes<128>() + 15) & ~15) + MB_DQ; }
+constexpr int MB_STG = MW_NB * 2048;                    // per-wave staging: 16 rows x 128 bytes
+__host__ __device__ constexpr int mb_lds_bytes() { return ((mw_lds_bytes<128>() + 15) & ~15) + MB_DQ + MB_STG; }
 
 // A_k^T chunk images: chunk (kc, k) at 64 + (kc * K + k) * 16 KB: [piece hi | lo][nf column n of the chunk (32)][16 slots of
 // 8 halves]; slot oc ^ (n & 15) holds A_k[mf = 8 oc + j][nf = 32 kc + n] * scale, j = 0..7 (an A fragment = 32 rows x 16
@@ -589,13 +590,16 @@ __global__ void __launch_bounds__(512) att_message_bwd_tile_kernel(
     int* const AT = reinterpret_cast<int*>(reinterpret_cast<char*>(SL) + MW_ROWS * 64);
     int* const OFF = AT + MW_TV;
     float* const DQ = reinterpret_cast<float*>(smem + ((mw_lds_bytes<128>() + 15) & ~15));
+    char* const STG = reinterpret_cast<char*>(DQ) + MB_DQ;    // per wave: 16 rows x 128 bytes, slot j of row p at j ^ (p & 7)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hi = lane >> 5;
+    const int cr = lane >> 3, cp = lane & 7;              // the "row" layout of a 128-byte chunk: row cr of 8, 16-byte piece cp
     const float a_inv = reinterpret_cast<const float*>(ws)[1];
     const char* const wsA = ws + 64;
     const int nphase = NKC * K;
+    char* const st = STG + wv * 2048;
     for (int i = tid; i < 4 * F; i += 512) qs_s[i] = i < K * F ? gt.q[i] * MW_LOG2E : 0.f;
     for (int i = lane; i < 4 * F; i += 64) DQ[wv * 4 * F + i] = 0.f;
     if (tid < 16) {
@@ -646,9 +650,51 @@ __global__ void __launch_bounds__(512) att_message_bwd_tile_kernel(
             }
         }
     };
+    // lanes of ONE wave exchanging data through LDS: the hardware runs a wave's LDS instructions in order, but the compiler
+    // sees independent threads and may let the lanes that skip a divergent store run ahead to the load behind it
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // a 32-row x 128-byte chunk between the row layout (lane: row 8 j + cr, piece cp; a wave instruction covers eight whole
+    // 128-byte lines) and the accumulator's layout (lane (atom r, half): pieces 2 q + half), 16 rows at a time through `st`.
+    // As direct 16-byte accesses in the accumulator's layout every instruction touched 32 lines for 32 bytes each: the
+    // kernel's six row streams made ~3,000 line requests per wave and tile, four times what the bytes need
+    auto rows_to_lanes = [&](f32x4 (&v)[4]) {              // in place
+        const f32x4 v2 = v[2], v3 = v[3];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            *reinterpret_cast<f32x4*>(st + cr * 128 + ((cp ^ cr) << 4)) = half ? v2 : v[0];
+            *reinterpret_cast<f32x4*>(st + (8 + cr) * 128 + ((cp ^ cr) << 4)) = half ? v3 : v[1];
+            wave_sync();
+            if ((r >> 4) == half) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    v[q] = *reinterpret_cast<const f32x4*>(st + (r & 15) * 128 + (((2 * q + hi) ^ (r & 7)) << 4));
+            }
+            wave_sync();
+        }
+    };
+    auto lanes_to_rows = [&](const f32x4 (&v)[4], f32x4 (&o)[4]) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if ((r >> 4) == half) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<f32x4*>(st + (r & 15) * 128 + (((2 * q + hi) ^ (r & 7)) << 4)) = v[q];
+            }
+            wave_sync();
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                o[2 * half + j] = *reinterpret_cast<const f32x4*>(st + (8 * j + cr) * 128 + ((cp ^ cr) << 4));
+            wave_sync();
+        }
+    };
 
-    // this lane's dout row (columns 16 s + 8 hi ..): requested a tile ahead -- before the loop, then at the start of the
-    // finishing part of the tile before (the registers of the split pieces are free then) -- and split at the tile's top
+    // this lane's dout row (columns 16 s + 8 hi ..), split once per tile.  (Requested a tile ahead -- during the second-term
+    // pass of the tile before -- the 64 registers in flight pushed loop invariants to scratch and bought nothing: the pass is
+    // bound by the bytes it moves.)
     f32x4 x[16];
     auto load_dout = [&](int atom) {
         const float* dp = dout + (int64_t)(atom < 0 ? 0 : atom) * F + 8 * hi;
@@ -659,22 +705,18 @@ __global__ void __launch_bounds__(512) att_message_bwd_tile_kernel(
         }
     };
     int t = blockIdx.x;
-    int a0 = 0, n = 1, at_next = -1;
+    int a0 = 0, n = 1;
     if (t < num_tiles) {
         a0 = tile_rec[4 * t];
         n = tile_rec[4 * t + 1];
         copy_h(a0, n, 0, 0, wv, 8);
         copy_a(0, 0, wv, 8);
-        at_next = tile_atom[(int64_t)t * MW_TV + 32 * wv + r];
-        load_dout(at_next);
     }
     for (; t < num_tiles; t += gridDim.x) {
         const int row0 = tile_rec[4 * t + 2], nrows = tile_rec[4 * t + 3];
         const int tn = t + (int)gridDim.x;
         const bool more = tn < num_tiles;
         const int a0n = more ? tile_rec[4 * tn] : a0, nn = more ? tile_rec[4 * tn + 1] : n;
-        const int at = at_next;                           // (= AT[32 wv + r] below)
-        at_next = more ? tile_atom[(int64_t)tn * MW_TV + 32 * wv + r] : -1;
         mw_barrier();
         {
             const int4* sp = reinterpret_cast<const int4*>(slots + (int64_t)row0 * 32);
@@ -698,11 +740,11 @@ __global__ void __launch_bounds__(512) att_message_bwd_tile_kernel(
             amask |= (__builtin_amdgcn_readfirstlane(OFF[wv * K + k + 1]) > __builtin_amdgcn_readfirstlane(OFF[wv * K + k])) << k;
         const unsigned long long pairs = __builtin_amdgcn_ballot_w64(lane < MW_NB * K && OFF[lane < MW_NB * K ? lane + 1 : 1] >
                                                                                        OFF[lane < MW_NB * K ? lane : 0]);
-        // ---- this lane's atom: logits row, softmax statistics, dout row (split once, exact row scale)
+        // ---- this lane's atom: softmax statistics, dout row (split once, exact row scale)
         MB_T(t0);
+        const int at = AT[32 * wv + r];
         const bool live = at >= 0;
-        const int64_t arow = (int64_t)(live ? at : 0) * F;
-        const float* zp = gt.z_atom + arow + 4 * hi;
+        load_dout(at);
         const float2* sp2 = gt.stats + ((int64_t)t * MW_TV + 32 * wv + r) * K;
         float2 st0 = sp2[0], st1 = sp2[K > 1 ? 1 : 0], st2 = sp2[K > 2 ? 2 : 0], st3 = sp2[K > 3 ? 3 : 0];
         if (!live) st0 = st1 = st2 = st3 = float2{3.0e38f, 0.f};   // (positions past the tile's atoms were never written): gate 0
@@ -737,9 +779,8 @@ __global__ void __launch_bounds__(512) att_message_bwd_tile_kernel(
                     dl[s][4 + j] = (_Float16)(b - (float)dh[s][4 + j]);
                 }
         }
-        f32x4 zc[4];
-#define MB_ZLOAD(Z, KC)                                                                        \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) Z[q] = *reinterpret_cast<const f32x4*>(zp + 32 * (KC) + 8 * q)
+        f32x4 zc[4];                                      // the chunk's logits: row layout until `zlanes`, then the accumulator's
+        bool zlanes = false;
         f32x4 P[4];                                       // first term of dz, current chunk
 #pragma unroll
         for (int q = 0; q < 4; ++q) P[q] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -766,7 +807,14 @@ __global__ void __launch_bounds__(512) att_message_bwd_tile_kernel(
                     else if (more) copy_h(a0n, nn, 0, 0, rank, share);
                 }
             }
-            if (k == 0 && amask != 0) { MB_ZLOAD(zc, kc); }   // first used behind this phase's products
+            if (k == 0 && amask != 0) {                    // the chunk's logits, row layout; first used behind a phase's products
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ra = AT[32 * wv + 8 * j + cr];   // the atom of row 8 j + cr of the block
+                    zc[j] = *reinterpret_cast<const f32x4*>(gt.z_atom + (int64_t)(ra < 0 ? 0 : ra) * F + 32 * kc + 4 * cp);
+                }
+                zlanes = false;
+            }
             MB_T(p2);
             MB_ADD(1, p1 - p0);
             MB_ADD(2, p2 - p1);
@@ -774,23 +822,22 @@ __global__ void __launch_bounds__(512) att_message_bwd_tile_kernel(
                 const char* hb = HB + (kc & 1) * MW_HB;
                 const char* ab = AB + (ph & 1) * ABUF + r * (2 * F);
                 // T^T chunk: rows = the chunk's 32 nf columns, columns = the block's atoms; contraction over mf in 8 steps
-                f32x16 acc, acc2;                          // two chains: a product does not wait for the one before it
+                f32x16 acc;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = acc2[i] = 0.f;
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-                for (int s = 0; s < 8; s += 2) {
+                for (int s = 0; s < 8; ++s) {
                     const char* p = ab + (((2 * s + hi) ^ (r & 15)) << 4);
-                    const char* p2 = ab + (((2 * s + 2 + hi) ^ (r & 15)) << 4);
                     const h16x8 wh = *reinterpret_cast<const h16x8*>(p), wl = *reinterpret_cast<const h16x8*>(p + F * 64);
-                    const h16x8 vh = *reinterpret_cast<const h16x8*>(p2), vl = *reinterpret_cast<const h16x8*>(p2 + F * 64);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, dh[s], acc, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, dh[s + 1], acc2, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, dl[s], acc, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, dl[s + 1], acc2, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, dh[s], acc, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, dh[s + 1], acc2, 0, 0, 0);
                 }
                 MB_T(p3);
+                if (!zlanes) {
+                    rows_to_lanes(zc);
+                    zlanes = true;
+                }
                 f32x4 s[4];
                 const int b0 = __builtin_amdgcn_readfirstlane(OFF[wv * K + k]);
                 gather(hb, b0, __builtin_amdgcn_readfirstlane(OFF[wv * K + k + 1]) - b0, s);
@@ -805,7 +852,7 @@ __global__ void __launch_bounds__(512) att_message_bwd_tile_kernel(
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float xg = __builtin_amdgcn_exp2f(fmaf(zc[q][j], MW_LOG2E, qv[j] - m)) * iv * s[q][j];   // X * un-scale
-                        const float u = xg * (acc[4 * q + j] + acc2[4 * q + j]);
+                        const float u = xg * acc[4 * q + j];
                         dsum += u;
                         P[q][j] += u;
                     }
@@ -821,14 +868,21 @@ __global__ void __launch_bounds__(512) att_message_bwd_tile_kernel(
                 MB_ADD(14, 1);
             }
             MB_T(p6);
-            if (k == K - 1) {                              // the chunk is done: first term of its dz columns
-                if (live) {
-                    float* o = dz + arow + 32 * kc + 4 * hi;
+            if (k == K - 1) {                              // the chunk is done: first term of its dz columns, whole lines per store
+                f32x4 pr[4];
+                if (amask != 0) {
+                    lanes_to_rows(P, pr);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(o + 8 * q) = P[q];
+                    for (int q = 0; q < 4; ++q) P[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pr[j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) P[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 4; ++j) {
+                    const int ra = AT[32 * wv + 8 * j + cr];
+                    if (ra >= 0) *reinterpret_cast<f32x4*>(dz + (int64_t)ra * F + 32 * kc + 4 * cp) = pr[j];
+                }
             }
             MB_T(p7);
             if (i_copy) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -836,55 +890,67 @@ __global__ void __launch_bounds__(512) att_message_bwd_tile_kernel(
             MB_ADD(6, p7 - p6);
             MB_ADD(7, p8 - p7);
         }
-        // ---- second term: dz -= sum_k g_k D_k, dq_k -= sum_atoms g_k D_k
+        // ---- second term: dz -= sum_k g_k D_k and dq_k -= sum_atoms g_k D_k, in a whole-row layout: a wave instruction
+        // covers two atoms' rows (lane: atom 2 it + half, columns 4 r ..), so every access is whole lines and the sum over
+        // atoms runs down a lane's registers.  Per-atom scalars (max, D / sum) travel through LDS.
         MB_T(f0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my first-term stores are done: other lanes of the wave read them back
+        MB_T(f0a);
         mw_barrier();                                      // every wave is done with the last chunk's h image (buffer 1): its
-                                                           // first 32 KB are the waves' transposition areas until the next tile
-        load_dout(at_next);                                // (no next tile: row 0, never used)
+                                                           // first 32 KB are free until the next tile's first phase
+        MB_T(f0b);
+        MB_T(f0c);
+        MB_ADD(9, f0a - f0);
+        MB_ADD(10, f0b - f0a);
+        MB_ADD(11, f0c - f0b);
         if (amask != 0) {
-            char* const SC = HB + MW_HB + wv * 4096;       // 32 atoms x 32 columns
+            float* const SC = reinterpret_cast<float*>(HB + MW_HB + wv * 4096);    // [32 atoms][max x 4 | D / sum x 4]
             D0 += __shfl_xor(D0, 32);
             D1 += __shfl_xor(D1, 32);
             D2 += __shfl_xor(D2, 32);
             D3 += __shfl_xor(D3, 32);
-            if (!live) D0 = D1 = D2 = D3 = 0.f;
-            for (int kc = 0; kc < NKC; ++kc) {
-                float* o = dz + arow + 32 * kc + 4 * hi;
-                f32x4 zz[4], pp[4];
-                MB_ZLOAD(zz, kc);
+            if (hi == 0) {
+                *reinterpret_cast<f32x4*>(SC + 8 * r) = f32x4{st0.x, st1.x, st2.x, st3.x};
+                *reinterpret_cast<f32x4*>(SC + 8 * r + 4) =
+                    live ? f32x4{st0.y * D0, st1.y * D1, st2.y * D2, st3.y * D3} : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            wave_sync();
+            f32x4 ql[4], dqa[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) pp[q] = *reinterpret_cast<const f32x4*>(o + 8 * q);
+            for (int k = 0; k < 4; ++k) {
+                ql[k] = *reinterpret_cast<const f32x4*>(qs_s + k * F + 4 * r);
+                dqa[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int a = 2 * it + hi;                 // the block's atom of this lane's row
+                const int atom = AT[32 * wv + a];
+                const int64_t off = (int64_t)(atom < 0 ? 0 : atom) * F + 4 * r;
+                const f32x4 zz = *reinterpret_cast<const f32x4*>(gt.z_atom + off);
+                f32x4 pp = *reinterpret_cast<const f32x4*>(dz + off);
+                const f32x4 mm = *reinterpret_cast<const f32x4*>(SC + 8 * a), gd = *reinterpret_cast<const f32x4*>(SC + 8 * a + 4);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (!((amask >> k) & 1)) continue;
-                    const float m = k == 0 ? st0.x : k == 1 ? st1.x : k == 2 ? st2.x : st3.x;
-                    const float gd = (k == 0 ? st0.y : k == 1 ? st1.y : k == 2 ? st2.y : st3.y) *
-                                     (k == 0 ? D0 : k == 1 ? D1 : k == 2 ? D2 : D3);
-                    const float* qp = qs_s + k * F + 32 * kc + 4 * hi;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 qv = *reinterpret_cast<const f32x4*>(qp + 8 * q);
-                        f32x4 v;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            v[j] = __builtin_amdgcn_exp2f(fmaf(zz[q][j], MW_LOG2E, qv[j] - m)) * gd;
-                            pp[q][j] -= v[j];
-                        }
-                        *reinterpret_cast<f32x4*>(SC + r * 128 + (((2 * q + hi) ^ (r & 7)) << 4)) = v;
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = __builtin_amdgcn_exp2f(fmaf(zz[j], MW_LOG2E, ql[k][j] - mm[k])) * gd[k];
+                        pp[j] -= v;
+                        dqa[k][j] += v;
                     }
-                    // sum over the block's atoms: lane (column c, half) adds 16 atoms of its column, the halves meet by a swap
-                    float sum = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const int a = 16 * hi + j;
-                        sum += *reinterpret_cast<const float*>(SC + a * 128 + (((r >> 2) ^ (a & 7)) << 4) + 4 * (r & 3));
-                    }
-                    sum += __shfl_xor(sum, 32);
-                    if (hi == 0) DQ[(wv * 4 + k) * F + 32 * kc + r] += sum;
                 }
-                if (live) {
+                if (atom >= 0) *reinterpret_cast<f32x4*>(dz + off) = pp;
+            }
+            MB_T(f0d);
+            MB_ADD(12, f0d - f0c);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(o + 8 * q) = pp[q];
+            for (int k = 0; k < 4; ++k) {
+                if (!((amask >> k) & 1)) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dqa[k][j] += __shfl_xor(dqa[k][j], 32);
+                if (hi == 0) {
+                    f32x4* d = reinterpret_cast<f32x4*>(DQ + (wv * 4 + k) * F + 4 * r);
+                    *d = *d + dqa[k];
                 }
             }
         }
@@ -898,7 +964,6 @@ __global__ void __launch_bounds__(512) att_message_bwd_tile_kernel(
     for (int i = lane; i < 4 * F; i += 64)
         if (i < K * F) dq_part[((int64_t)blockIdx.x * MW_NB + wv) * K * F + i] = DQ[wv * 4 * F + i];
 }
-#undef MB_ZLOAD
 
 // ------------------------------------------------------------------------------------------ width 64: resident matrices
 // At nf = mf = 64 the K <= 4 matrices fit in LDS as fp16 piece pairs (16 KB per type) next to a whole 256-atom tile of h

@@ -46,5 +46,7 @@ if hasattr(lib, "mpnn_debug_mb_stamps"):
     print("per phase: barrier %.0f | copy issue %.0f | chunk-end store %.0f | copy wait %.0f" %
           (buf[1] / ph, buf[2] / ph, buf[6] / ph, buf[7] / ph))
     print("per phase with work: 24 MFMAs issued %.0f | gather %.0f | gate, u, sums %.0f" % (buf[3] / work, buf[4] / work, buf[5] / work))
+    print("finishing: store wait %.0f | barrier %.0f | dout requests %.0f | publish + row loop %.0f" %
+          tuple(buf[i] / tiles for i in (9, 10, 11, 12)))
     tot = sum(buf[i] for i in range(9))
     print("sum per tile %.0f cycles" % (tot / tiles))
