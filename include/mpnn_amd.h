@@ -106,18 +106,6 @@ int mpnn_edge_message_agg_bwd_da_f32(const float* dagg, const float* h, const in
                                      float* dA, int64_t V, int64_t E, int K, int nf, int mf, void* stream);
 
 /*
- * The same weight gradient contracted over ATOMS: dA[k] += sum_i dagg[i] (x) X_ik with X_ik = the sum of h[src e] over atom
- * i's type-k edges (times the AttEdgeNetwork gate of (i, k) when z_atom is given: statistics as below).  Reads the CSR
- * itself (row_ptr [V+1], col_idx [E], edge_type [E] with values < K); no plan, no per-edge row is formed.
- * replaces: the same autograd as mpnn_edge_message_agg_bwd_da_f32 (unit adjacency weights).  nf = mf in {64, 128}
- * (gated: 128), K <= 4; dA is accumulated into (zero it first).
- */
-int mpnn_message_agg_bwd_da_rows_f32(const float* dagg, const float* h, const int32_t* row_ptr, const int32_t* col_idx,
-                                     const int32_t* edge_type, const float* z_atom /* may be NULL */,
-                                     const float* q /* may be NULL */, const float* stats_by_atom /* may be NULL */,
-                                     float* dA, int64_t V, int64_t E, int K, int nf, int mf, void* stream);
-
-/*
  * The same with AttEdgeNetwork's gate evaluated in flight, no (E, nf) gate tensor:
  *   gate[e, c] = exp2(log2(e) * (z_atom[dst e, c] + q[type e, c]) - stats[dst e, type e].x) * stats[dst e, type e].y,
  * stats_by_atom [V, K, 2] = (log2(e) * max_c(z + q), 1 / sum_c exp(z + q - max)) as mpnn_message_aggregate_wide_gated_bwd_f32

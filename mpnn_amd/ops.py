@@ -224,9 +224,8 @@ def message_aggregate_wide_gated_raw(h, A, z_atom, q, graph, keep_workspace=Fals
 def message_aggregate_wide_gated_bwd_raw(h, A, z_atom, q, dout, fwd_ws, graph):
     """Backward of the gated message + sum per (atom, type) on the forward's plan -> (dA, dz_atom, dq); no (E, nf) tensor.
     Two kernels: the logits' gradient on the plan (mpnn_message_aggregate_wide_gated_bwd_f32, which also hands the softmax
-    statistics over in atom order), then the matrices' gradient contracted over atoms with the gate evaluated in flight
-    (mpnn_message_agg_bwd_da_rows_f32; DA_PER_EDGE: mpnn_edge_message_agg_bwd_da_att_f32, over edges); dq's first term is read
-    off A * dA (include/mpnn_amd.h has the algebra)."""
+    statistics over in atom order), then the matrices' gradient with the gate evaluated in flight
+    (mpnn_edge_message_agg_bwd_da_att_f32); dq's first term is read off A * dA (include/mpnn_amd.h has the algebra)."""
     lib = _lib.load()
     K, mf, nf = (int(s) for s in A.shape)
     V, E = graph.num_nodes, graph.num_edges
@@ -243,16 +242,10 @@ def message_aggregate_wide_gated_bwd_raw(h, A, z_atom, q, dout, fwd_ws, graph):
         _lib.fptr(dz), _lib.fptr(dq_part), _lib.fptr(stats_atom), _lib.ptr(ws), ws_bytes, V, plan.num_tiles, K, nf, mf,
         _lib.stream())), "mpnn_message_aggregate_wide_gated_bwd_f32")
     dA = torch.zeros_like(A)
-    if DA_PER_EDGE:
-        _lib.check(_timed("message_aggregate_bwd", lambda: lib.mpnn_edge_message_agg_bwd_da_att_f32(
-            _lib.fptr(dout), _lib.fptr(h), _lib.iptr(graph.col_idx), _lib.iptr(graph.edge_dst), _lib.iptr(graph.order),
-            _lib.iptr(graph.type_ptr), _lib.fptr(z_atom), _lib.fptr(q), _lib.fptr(stats_atom), _lib.fptr(dA), V, E, K, nf, mf,
-            _lib.stream())), "mpnn_edge_message_agg_bwd_da_att_f32")
-    else:
-        _lib.check(_timed("message_aggregate_bwd", lambda: lib.mpnn_message_agg_bwd_da_rows_f32(
-            _lib.fptr(dout), _lib.fptr(h), _lib.iptr(graph.row_ptr), _lib.iptr(graph.col_idx), _lib.iptr(graph.edge_type),
-            _lib.fptr(z_atom), _lib.fptr(q), _lib.fptr(stats_atom), _lib.fptr(dA), V, E, K, nf, mf, _lib.stream())),
-            "mpnn_message_agg_bwd_da_rows_f32")
+    _lib.check(_timed("message_aggregate_bwd", lambda: lib.mpnn_edge_message_agg_bwd_da_att_f32(
+        _lib.fptr(dout), _lib.fptr(h), _lib.iptr(graph.col_idx), _lib.iptr(graph.edge_dst), _lib.iptr(graph.order),
+        _lib.iptr(graph.type_ptr), _lib.fptr(z_atom), _lib.fptr(q), _lib.fptr(stats_atom), _lib.fptr(dA), V, E, K, nf, mf,
+        _lib.stream())), "mpnn_edge_message_agg_bwd_da_att_f32")
     dq = (A * dA).sum(1) - dq_part.sum(0)
     return dA, dz, dq
 
@@ -409,13 +402,7 @@ class MessageAggregate(torch.autograd.Function):
                 return None, None, None, None, None
             lib = _lib.load()
             dA = torch.zeros_like(A)
-            if g.num_edges and da_rows_applies(A, gate, w, g):
-                # contracted over atoms: the neighbours of a type are summed before the outer product (csrc/edge_da_rows.hip)
-                _lib.check(_timed("message_aggregate_bwd", lambda: lib.mpnn_message_agg_bwd_da_rows_f32(
-                    _lib.fptr(dout), _lib.fptr(h), _lib.iptr(g.row_ptr), _lib.iptr(g.col_idx), _lib.iptr(g.edge_type), None,
-                    None, None, _lib.fptr(dA), g.num_nodes, g.num_edges, K, nf, mf, _lib.stream())),
-                    "mpnn_message_agg_bwd_da_rows_f32")
-            elif g.num_edges:
+            if g.num_edges:
                 _lib.check(_timed("message_aggregate_bwd", lambda: lib.mpnn_edge_message_agg_bwd_da_f32(
                     _lib.fptr(dout), _lib.fptr(h), _lib.iptr(g.col_idx), _lib.iptr(g.edge_dst), _lib.fptr(w),
                     _lib.iptr(g.order), _lib.iptr(g.type_ptr), _lib.fptr(gate), _lib.fptr(dA), g.num_nodes,
@@ -452,19 +439,6 @@ class MessageAggregate(torch.autograd.Function):
                 dx = dx * gate
         dh = segsum_gather_raw(dx, t_row_ptr, t_eid, None, g.num_nodes) if ctx.needs_input_grad[0] else None
         return dh, dA, dgate, None, None
-
-
-# True: the weight gradient of message + sum contracted over EDGES (mpnn_edge_message_agg_bwd_da_f32) also where the
-# per-atom kernel applies -- what the tests compare the per-atom kernel with
-DA_PER_EDGE = False
-
-
-def da_rows_applies(A, gate, w, graph):
-    """The weight gradient contracted over atoms (mpnn_message_agg_bwd_da_rows_f32): widths 64 / 128, at most four bond
-    types, unit adjacency weights, no per-edge gate tensor, split-precision math."""
-    K, mf, nf = (int(s) for s in A.shape)
-    return (not DA_PER_EDGE and gate is None and w is None and mf == nf and nf in (64, 128) and 1 <= K <= 4 and A.is_cuda
-            and graph.edge_type.dtype == torch.int32 and os.environ.get("MPNN_GRU_MATH") != "fp32")
 
 
 def message_aggregate(h, A, graph, w=None, gate=None):
