@@ -944,6 +944,31 @@ def expand_rows(x, graph):
     return _ExpandRows.apply(x, graph)
 
 
+# Column sums a backward kernel already has for a gradient tensor it hands to autograd: keyed by the tensor's address, valid
+# only while that very tensor is alive and unmodified (a weak reference and its version counter say so).  The gated message
+# backward knows sum_i dz_atom[i] = sum_k dq[k] for free; the Linear that made z_atom needs exactly that sum for its bias
+# gradient -- a (V, F) reduction of 0.5 ms at c3's size, five times per step.
+_KNOWN_COLSUMS = {}
+
+
+def _offer_colsum(t, colsum):
+    import weakref
+    if len(_KNOWN_COLSUMS) > 64:
+        _KNOWN_COLSUMS.clear()
+    _KNOWN_COLSUMS[t.data_ptr()] = (weakref.ref(t), t._version, colsum)
+
+
+def _take_colsum(t):
+    hit = _KNOWN_COLSUMS.pop(t.data_ptr(), None)
+    if hit is None:
+        return None
+    ref, version, colsum = hit
+    live = ref()
+    if live is None or live.data_ptr() != t.data_ptr() or live.shape != t.shape or t._version != version:
+        return None
+    return colsum
+
+
 class _TallLinear(torch.autograd.Function):
     """x (V,F) @ W^T + b for V in the millions.  Forward is the library GEMM; the weight gradient dy^T x is a GEMM with
     a contraction of V rows and a tiny output, which the library runs on a handful of CUs (3.8 ms at V = 3 M,
@@ -969,7 +994,11 @@ class _TallLinear(torch.autograd.Function):
                                x[:nfull * chunk].view(nfull, chunk, -1)).sum(0)
             if V > nfull * chunk:
                 dW = dW + dy[nfull * chunk:].t() @ x[nfull * chunk:]
-        db = dy.sum(0) if ctx.needs_input_grad[2] else None
+        db = None
+        if ctx.needs_input_grad[2]:
+            db = _take_colsum(dy)
+            if db is None:
+                db = dy.sum(0)
         return dx, dW, db
 
 
@@ -1068,6 +1097,8 @@ class GatedMessageAggregate(torch.autograd.Function):
         if (not ATT_BWD_PER_EDGE and ctx.fwd_ws is not None and os.environ.get("MPNN_GRU_MATH") != "fp32"
                 and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])):
             dA, dz_atom, dq = message_aggregate_wide_gated_bwd_raw(h, A, z_atom, q, dout, ctx.fwd_ws, g)
+            if ctx.needs_input_grad[2]:
+                _offer_colsum(dz_atom, dq.sum(0))              # sum_i dz_atom[i] = sum_k dq[k]
             return (None, dA if ctx.needs_input_grad[1] else None, dz_atom if ctx.needs_input_grad[2] else None,
                     dq if ctx.needs_input_grad[3] else None, None)
         gate = _empty((E, nf), h)

@@ -185,3 +185,36 @@ def test_attention_model_without_bonds_and_on_a_dense_batch(dev):
     out = model(dense["afm"], dense["bfm"], dense["adj"], dense["mask"])
     out.sum().backward()
     assert torch.isfinite(out).all()
+
+
+def test_bias_gradient_of_the_logits_linear_takes_the_known_column_sums(dev):
+    """sum_i dz_atom[i] = sum_k dq[k]: the Linear behind z_atom gets its bias gradient from the gated backward's dq instead
+    of reducing (V, F) again (ops._offer_colsum / _take_colsum) -- same values as the reduction, and the offer is refused
+    for any other tensor."""
+    from mpnn_amd import ops
+    mb, g = _batch(dev, 300)
+    V, K, F = g.num_nodes, g.num_types, 128
+    gen = torch.Generator(device=dev).manual_seed(9)
+    h = torch.randn(V, F, device=dev, generator=gen)
+    A = (torch.randn(K, F, F, device=dev, generator=gen) / F ** 0.5).requires_grad_(True)
+    W = (torch.randn(F, F, device=dev, generator=gen) / F ** 0.5).requires_grad_(True)
+    q = torch.randn(K, F, device=dev, generator=gen).requires_grad_(True)
+    cot = torch.randn(V, F, device=dev, generator=gen)
+    taken, real = [], ops._take_colsum
+    res = []
+    for use in (True, False):
+        b = torch.zeros(F, device=dev, requires_grad=True)
+        ops._take_colsum = (lambda t: (taken.append(real(t)), taken[-1])[1]) if use else (lambda t: None)
+        try:
+            z = ops.tall_linear(h, W, b)
+            out = ops.gated_message_aggregate(h, A, ops.LazyAttGate(z, q, g), g)
+            (out * cot).sum().backward()
+        finally:
+            ops._take_colsum = real
+        res.append(b.grad.clone())
+    assert len(taken) == 1 and taken[0] is not None            # the offer was found and accepted
+    assert float((res[0] - res[1]).abs().max() / res[1].abs().max()) < 2e-5
+    other = torch.zeros(V, F, device=dev)
+    ops._offer_colsum(other, torch.ones(F, device=dev))
+    other.add_(1.0)                                             # modified since the offer: refused
+    assert ops._take_colsum(other) is None
