@@ -285,7 +285,8 @@ def make_model(workload, hidden, T, dev):
                       message_steps=T).to(dev)
 
 
-SIDE_KERNELS = ["message_aggregate", "segsum", "edge_message", "gru_update", "gru_update_bwd", "message_aggregate_bwd"]
+SIDE_KERNELS = ["message_aggregate", "segsum", "edge_message", "gru_update", "gru_update_bwd", "message_aggregate_bwd",
+                "att_message_bwd"]
 
 
 def side_workload(name, dev, steps=3, warmup=1, scale=1.0):

@@ -78,10 +78,21 @@ __device__ __forceinline__ void guard_scale(float maxabs, float& s, float& inv) 
     inv = __int_as_float((e - 14) << 23);
 }
 
+// maximum over the 16 lanes of a DPP row (every lane gets it): two quad permutes, then rotations by 4 and 8 within the row --
+// no trip through the LDS crossbar (a __shfl_xor is a ds_bpermute), which the dx waves keep busy
+__device__ __forceinline__ float row16_max(float v) {
+    int x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]
+    v = fmaxf(v, __int_as_float(x));
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true);          // quad_perm [2,3,0,1]
+    v = fmaxf(v, __int_as_float(x));
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, true);         // row_ror:4
+    v = fmaxf(v, __int_as_float(x));
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, true);         // row_ror:8
+    return fmaxf(v, __int_as_float(x));
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    v = row16_max(v);
+    return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
 }
 
 // three partial products of one K=16 step for two row blocks that share the B pieces, small terms first
@@ -158,8 +169,7 @@ __global__ void __launch_bounds__(512) gru_bwd_f16_kernel(
                     cs[4 * s + j] = fmaf(G.s[s][j], count, cs[4 * s + j]);
                     rmx = fmaxf(rmx, fabsf(G.s[s][j]));
                 }
-#pragma unroll
-            for (int o = 8; o >= 1; o >>= 1) rmx = fmaxf(rmx, __shfl_xor(rmx, o));
+            rmx = row16_max(rmx);                          // the row's 16 staging lanes are one DPP row
             gmx = fmaxf(gmx, rmx);
 #pragma unroll
             for (int j = 0; j < 4; ++j) xmx = fmaxf(xmx, fmaxf(fabsf(G.s[4][j]), fabsf(G.s[5][j])));
@@ -284,6 +294,9 @@ __global__ void __launch_bounds__(512) gru_bwd_f16_kernel(
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            // the vector work of the next tile runs beside the SIMD partner's (a dx wave's) 36 MFMAs: at equal priority
+            // the partner wins the issue port and this stream crawls (measured on the wide kernels, gru_bwd_rc.hip)
+            asm volatile("s_setprio 2" ::: "memory");
             {
                 float gmx = 0.f, xmx = 0.f, r0, r1;
                 const float count = more ? 1.0f : 0.0f;   // the clamped re-stage counts nothing
@@ -301,6 +314,7 @@ __global__ void __launch_bounds__(512) gru_bwd_f16_kernel(
                 if ((tid & 15) == 0) scl[(cur ^ 1) * 32 + srow + 16] = inv_sg;
                 C_cur = C_run;
             }
+            asm volatile("s_setprio 0" ::: "memory");
             cur ^= 1;
         }
         const float inv_C = 1.0f / C_acc;
