@@ -38,10 +38,21 @@ __device__ __forceinline__ void g_guard_scale(float maxabs, float& s, float& inv
     inv = __int_as_float((e - 14) << 23);
 }
 
+// maxima by DPP (row of 16 lanes: two quad permutes, rotations by 4 and 8) and readlane: a __shfl_xor is a ds_bpermute, a
+// trip through the LDS crossbar that the MFMA operand reads keep busy
+__device__ __forceinline__ float g_row16_max(float v) {
+    int x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true);
+    v = fmaxf(v, __int_as_float(x));
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true);
+    v = fmaxf(v, __int_as_float(x));
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, true);
+    v = fmaxf(v, __int_as_float(x));
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, true);
+    return fmaxf(v, __int_as_float(x));
+}
 __device__ __forceinline__ float g_wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    v = g_row16_max(v);
+    return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
 }
 
 __device__ __forceinline__ void g_split8(const f32x4& x0, const f32x4& x1, float sc, h16x8& ph, h16x8& pl) {
@@ -169,8 +180,7 @@ __global__ void __launch_bounds__(512) gru_gate_f16_kernel(const float* __restri
         // factors out of dm | dh, whose rows are atoms, and the dW kernel folds it into that atom's m | h row -- so an atom
         // keeps its 22 bits whatever its tile-mates' magnitudes are (one scale per tile left an atom 1e6 below its
         // neighbours with ~15 bits), and the tile needs no block-wide maximum
-#pragma unroll
-        for (int o = 8; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        mx = g_row16_max(mx);
         float sg, inv_sg;
         g_guard_scale<90>(mx, sg, inv_sg);
         if (c16 == 0) inv_scale[t * 32 + srow] = inv_sg;
