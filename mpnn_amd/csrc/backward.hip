@@ -685,9 +685,18 @@ static inline int launch_gru_bwd_wide(const float* dout, const float* m, const f
 
 // the generic-width backward after the gate-gradient pass (ws = (V, 6H) pre-activation gradients, dh holds g * z):
 // dm, dh as row GEMMs, dW / db as accumulating contractions over the atoms
+namespace mpnn {
+bool gru_small_covers(int H, int64_t V);
+int launch_gru_bwd_small_tail(const float* m, const float* h, const float* W_ih, const float* W_hh, const float* ws, float* dm,
+                              float* dh, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, int64_t V, int H,
+                              hipStream_t s);
+}
+
 static int gru_bwd_generic_tail(const float* m, const float* h, const float* W_ih, const float* W_hh, float* ws, float* dm,
                                 float* dh, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, int64_t V, int H,
                                 hipStream_t s) {
+    if (gru_small_covers(H, V))                              // one vector-pipe kernel for the four contractions (gru_small.hip)
+        return launch_gru_bwd_small_tail(m, h, W_ih, W_hh, ws, dm, dh, dW_ih, dW_hh, db_ih, db_hh, V, H, s);
     int rc;
     // dm = dgi . W_ih^T : B given as [n = input feature][k = gate column], ld 3H
     rc = launch_rows_gemm<true, false>(ws, 6 * H, nullptr, nullptr, 0, W_ih, 0, 3 * H, nullptr, dm, H, V, 3 * H, H, s,

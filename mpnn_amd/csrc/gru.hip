@@ -356,6 +356,12 @@ int launch_gru_split_norm(const float* m, const float* h, const float* mask, con
                           const float* b_ih, const float* b_hh, const float* hs, const float* ht, float* out,
                           float* saved, float* hnorm, double* stats, int64_t V, int H, void* workspace, hipStream_t s);
 
+// widths up to 40 on the vector pipe (gru_small.hip)
+bool gru_small_covers(int H, int64_t V);
+int launch_gru_small(const float* m, const float* h, const float* mask, const float* W_ih, const float* W_hh,
+                     const float* b_ih, const float* b_hh, float* out, float* saved, int64_t V, int H, const float* hs,
+                     const float* ht, float* hnorm, double* stats, hipStream_t s);
+
 }  // namespace mpnn
 
 using namespace mpnn;
@@ -392,6 +398,8 @@ extern "C" int mpnn_gru_update_f32(const float* m, const float* h, const float* 
     if (H == 64) return launch_gru_resident<64, 2, 8>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, st);
     if (H == 128) return launch_gru_resident<128, 1, 4>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, st);
     if (H == 32) return launch_gru_resident<32, 1, 8>(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, st);
+    if (gru_small_covers(H, V))
+        return launch_gru_small(m, h, mask, W_ih, W_hh, b_ih, b_hh, out, saved, V, H, nullptr, nullptr, nullptr, nullptr, st);
     const int64_t row_tiles = ceil_div(V, kRows);
     MPNN_REQUIRE(row_tiles < (1 << 24), "mpnn_gru_update_f32: V too large for one launch");
     const int col_slices = (H + 31) / 32;
@@ -422,6 +430,9 @@ extern "C" int mpnn_gru_update_norm_f32(const float* m, const float* h_raw, cons
     MPNN_REQUIRE(m && h_raw && W_ih && W_hh_folded && b_ih && b_hh_folded && h_scale && h_shift && out && out_moments,
                  "mpnn_gru_update_norm_f32: NULL buffer");
     MPNN_REQUIRE(!saved || h_norm, "mpnn_gru_update_norm_f32: a training pass (saved != NULL) also needs h_norm");
+    if (kind == 1 && gru_small_covers(H, V))                  // the Lipophilicity model's widths: vector-pipe kernel, no workspace
+        return launch_gru_small(m, h_raw, mask, W_ih, W_hh_folded, b_ih, b_hh_folded, out, saved, V, H, h_scale, h_shift,
+                                h_norm, out_moments, (hipStream_t)stream);
     if (kind == 1) {                                       // generic fp32 kernel: no workspace
         const int64_t row_tiles = ceil_div(V, kRows);
         MPNN_REQUIRE(row_tiles < (1 << 24), "mpnn_gru_update_norm_f32: V too large for one launch");
