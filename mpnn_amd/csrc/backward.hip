@@ -686,17 +686,16 @@ static inline int launch_gru_bwd_wide(const float* dout, const float* m, const f
 // the generic-width backward after the gate-gradient pass (ws = (V, 6H) pre-activation gradients, dh holds g * z):
 // dm, dh as row GEMMs, dW / db as accumulating contractions over the atoms
 namespace mpnn {
+// widths up to 40, batches up to 8 k atoms: the whole backward as one vector-pipe kernel (gru_small.hip)
 bool gru_small_covers(int H, int64_t V);
-int launch_gru_bwd_small_tail(const float* m, const float* h, const float* W_ih, const float* W_hh, const float* ws, float* dm,
-                              float* dh, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, int64_t V, int H,
-                              hipStream_t s);
+int launch_gru_bwd_small(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
+                         const float* W_hh, const float* saved, const float* out_norm_k, float* dm, float* dh, float* dW_ih,
+                         float* dW_hh, float* db_ih, float* db_hh, int64_t V, int H, hipStream_t s);
 }
 
 static int gru_bwd_generic_tail(const float* m, const float* h, const float* W_ih, const float* W_hh, float* ws, float* dm,
                                 float* dh, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, int64_t V, int H,
                                 hipStream_t s) {
-    if (gru_small_covers(H, V))                              // one vector-pipe kernel for the four contractions (gru_small.hip)
-        return launch_gru_bwd_small_tail(m, h, W_ih, W_hh, ws, dm, dh, dW_ih, dW_hh, db_ih, db_hh, V, H, s);
     int rc;
     // dm = dgi . W_ih^T : B given as [n = input feature][k = gate column], ld 3H
     rc = launch_rows_gemm<true, false>(ws, 6 * H, nullptr, nullptr, 0, W_ih, 0, 3 * H, nullptr, dm, H, V, 3 * H, H, s,
@@ -765,6 +764,8 @@ extern "C" int mpnn_gru_update_bwd_f32(const float* dout, const float* m, const 
     if ((H == 128 || H == 256) && !fp32_only)
         return launch_gru_bwd_wide(dout, m, h, mask, W_ih, W_hh, saved, dm, dh, dW_ih, dW_hh, db_ih, db_hh, workspace, V, H,
                                    nullptr, nullptr, nullptr, s);
+    if (gru_small_covers(H, V))
+        return launch_gru_bwd_small(dout, m, h, mask, W_ih, W_hh, saved, nullptr, dm, dh, dW_ih, dW_hh, db_ih, db_hh, V, H, s);
     hipLaunchKernelGGL(gru_gate_grad_kernel<false>, dim3((unsigned)g), dim3(256), 0, s, dout, h, mask, saved, ws, dh, V,
                        H);
     rc = launch_status("mpnn_gru_update_bwd_f32(gates)");
@@ -868,6 +869,13 @@ extern "C" int mpnn_gru_update_norm_bwd_f32(const float* dout, const float* m, c
         // generic widths: the plain backward with the gate-gradient pass in its NORM form, then the two column sums of
         // dh_norm in a pass of their own (the generic dm / dh are library-style GEMM launches without an epilogue hook)
         hipStream_t s = (hipStream_t)stream;
+        if (gru_small_covers(H, V)) {
+            const int rc = launch_gru_bwd_small(dout, m, h_norm, mask, W_ih, W_hh, saved, out_norm_k, dm, dh_norm, dW_ih,
+                                                dW_hh, db_ih, db_hh, V, H, s);
+            if (rc) return rc;
+            if (in_norm_sums) return mpnn_norm_bwd_sums_f32(dh_norm, h_raw, nullptr, in_norm_sums, V, H, stream);
+            return MPNN_OK;
+        }
         float* ws = (float*)workspace;
         int64_t g = ceil_div(V * H, 256);
         if (g > 256 * 16) g = 256 * 16;

@@ -10,8 +10,8 @@
 // problem is a few hundred thousand multiply-adds: both weight matrices (2 x H x 3H floats, 12-38 KB) sit in LDS, a thread
 // owns one (atom, feature) and runs its 6 H multiply-adds from LDS operands.
 //   forward   gru_update_small_kernel<NORM>      same contract as gru_update_kernel<NORM> (gru.hip), incl. the fused norm
-//   backward  gru_bwd_small_tail_kernel          dm, dh (+= the direct term), dW_ih, dW_hh, db_ih, db_hh from the (V, 6H)
-//                                                pre-activation gradients of gru_gate_grad_kernel -- one launch for four
+//   backward  gru_bwd_small_kernel<NQ, NORM>     gate gradients, dm, dh, dW_ih, dW_hh, db_ih, db_hh -- one launch for five, no
+//                                                (V, 6H) workspace
 // fp32 throughout (fused multiply-adds in a fixed order): no operand splitting, nothing to range-guard.
 #include "common.h"
 
@@ -150,15 +150,20 @@ int launch_gru_small(const float* m, const float* h, const float* mask, const fl
 }
 
 // ---------------------------------------------------------------------------------------------------------- backward
-// ws = (V, 6H) rows [dgi_r dgi_z dgi_n | dgh_r dgh_z dgh_n] (gru_gate_grad_kernel), dh holds the direct term g * z.
-//   phase A, thread (atom, feature j):   dm[j] = sum_g dgi[g] W_ih[j][g],   dh[j] += sum_g dgh[g] W_hh[j][g]
+// The whole backward of one update in one launch (the generic path: a gate-gradient pass into a (V, 6H) workspace, two row
+// GEMMs, two accumulating contractions).  Per pass of RB atoms:
+//   staging, thread (atom, feature j): the gate gradients of (atom, j) from dout, h and the saved gates (gru_update.py:29-34
+//            differentiated; NORM: dout is the gradient of norm(out), see gru_gate_grad_kernel) -> G [RB][6H] in LDS as
+//            [dgi_r dgi_z dgi_n | dgh_r dgh_z dgh_n]; the direct term g * z of dh stays in a register
+//   phase A, thread (atom, feature j):   dm[j] = sum_g dgi[g] W_ih[j][g],   dh[j] = g z + sum_g dgh[g] W_hh[j][g]
 //   phase B, thread (matrix, gate column g): dW[j][g] += x[j] * d[g] for every feature j (H register accumulators),
 //                                            db[g] += d[g]; the block's sums leave by atomicAdd at its end
 // LDS: Wi [H][3H + 1] | Wh [H][3H + 1] (odd row stride: a lane per row reads conflict-free) | G [RB][6H] | Xm [RB][H] | Xh [RB][H]
-template <int NQ>   // H <= NQ: accumulators of phase B (a multiple of 8: the loop over features carries no branch)
-__global__ void __launch_bounds__(256) gru_bwd_small_tail_kernel(
-    const float* __restrict__ m, const float* __restrict__ h, const float* __restrict__ W_ih, const float* __restrict__ W_hh,
-    const float* __restrict__ ws, float* __restrict__ dm, float* __restrict__ dh, float* dW_ih, float* dW_hh, float* db_ih,
+template <int NQ, bool NORM>   // H <= NQ: accumulators of phase B (a multiple of 8: the loop over features carries no branch)
+__global__ void __launch_bounds__(256) gru_bwd_small_kernel(
+    const float* __restrict__ dout, const float* __restrict__ m, const float* __restrict__ h, const float* __restrict__ mask,
+    const float* __restrict__ W_ih, const float* __restrict__ W_hh, const float* __restrict__ saved,
+    const float* __restrict__ kn, float* __restrict__ dm, float* __restrict__ dh, float* dW_ih, float* dW_hh, float* db_ih,
     float* db_hh, int64_t V, int H, int64_t rows_per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int HP = H <= 32 ? 32 : 64, RB = 256 / HP, LDW = 3 * H + 1;
@@ -175,6 +180,8 @@ __global__ void __launch_bounds__(256) gru_bwd_small_tail_kernel(
         Wh[jj * LDW + g] = W_hh[i];
     }
     const bool col = j < H;
+    float k1 = 0.f, k2 = 0.f, k4 = 0.f;
+    if (NORM && col) { k1 = kn[j]; k2 = kn[H + j]; k4 = kn[2 * H + j]; }
     // phase B role: tid -> (matrix, gate column)
     const bool bwork = tid < 6 * H;
     const int bmat = tid >= 3 * H ? 1 : 0;
@@ -189,12 +196,32 @@ __global__ void __launch_bounds__(256) gru_bwd_small_tail_kernel(
     for (int64_t r0 = r_begin; r0 < r_end; r0 += RB) {
         __syncthreads();                                    // the previous pass is done with G / Xm / Xh (first pass: W is in)
         const int nrows = (int)(r_end - r0 < RB ? r_end - r0 : RB);
-        for (int i = tid; i < nrows * 6 * H; i += 256) G[i] = ws[r0 * 6 * H + i];
         const int64_t row = r0 + rl;
         const bool live = col && rl < nrows;
+        float direct = 0.f;
         if (live) {
+            const float mk = mask ? mask[row] : 1.0f;
+            const float* sv = saved + row * 4 * H + j;
+            const float r = sv[0], z = sv[H], n = sv[2 * H], nh = sv[3 * H];
+            const float hv = h[row * H + j], d = dout[row * H + j];
+            float g = d * mk;                               // through the final "* mask"
+            if (NORM) {
+                const float y = ((1.0f - z) * n + z * hv) * mk;
+                g = (d * k1 + y * k2 + k4) * mk;
+            }
+            const float dan = g * (1.0f - z) * mk * (1.0f - n * n);     // n = tanh(.) * mask
+            const float dar = dan * nh * mk * r * (1.0f - r);
+            const float daz = g * (hv - n) * mk * z * (1.0f - z);
+            float* gr = G + rl * 6 * H + j;
+            gr[0] = dar;
+            gr[H] = daz;
+            gr[2 * H] = dan;
+            gr[3 * H] = dar;
+            gr[4 * H] = daz;
+            gr[5 * H] = dan * r;
+            direct = g * z;
             Xm[rl * H + j] = m[row * H + j];
-            Xh[rl * H + j] = h[row * H + j];
+            Xh[rl * H + j] = hv;
         }
         __syncthreads();
         if (live) {
@@ -202,14 +229,14 @@ __global__ void __launch_bounds__(256) gru_bwd_small_tail_kernel(
             const float* gh = gi + 3 * H;
             const float* wi = Wi + j * LDW;
             const float* wh = Wh + j * LDW;
-            float am = 0.f, ah = 0.f;
+            float am = 0.f, ah = direct;
 #pragma unroll 6
             for (int g = 0; g < 3 * H; ++g) {
                 am = fmaf(gi[g], wi[g], am);
                 ah = fmaf(gh[g], wh[g], ah);
             }
             dm[row * H + j] = am;
-            dh[row * H + j] += ah;
+            dh[row * H + j] = ah;
         }
         if (bwork) {
             const float* X = bmat ? Xh : Xm;
@@ -235,22 +262,28 @@ __global__ void __launch_bounds__(256) gru_bwd_small_tail_kernel(
     }
 }
 
-int launch_gru_bwd_small_tail(const float* m, const float* h, const float* W_ih, const float* W_hh, const float* ws, float* dm,
-                              float* dh, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, int64_t V, int H,
-                              hipStream_t s) {
+int launch_gru_bwd_small(const float* dout, const float* m, const float* h, const float* mask, const float* W_ih,
+                         const float* W_hh, const float* saved, const float* out_norm_k, float* dm, float* dh, float* dW_ih,
+                         float* dW_hh, float* db_ih, float* db_hh, int64_t V, int H, hipStream_t s) {
     const int RB = H <= 32 ? 8 : 4;
     int64_t rows_per_block = RB;                            // one pass per block (a pass is a chain of memory round trips);
     if ((V + rows_per_block - 1) / rows_per_block > 256)    // at most 256 blocks: every block ends in 6 H^2 atomics
         rows_per_block = ((V + 255) / 256 + RB - 1) / RB * RB;
     const int64_t blocks = (V + rows_per_block - 1) / rows_per_block;
     const size_t lds = (size_t)(2 * H * (3 * H + 1) + RB * 6 * H + 2 * RB * H + kSmallMaxH) * sizeof(float);   // + padding read by phase B
-#define MPNN_SMALL_TAIL(NQ)                                                                                                  \
-    hipLaunchKernelGGL(gru_bwd_small_tail_kernel<NQ>, dim3((unsigned)blocks), dim3(256), lds, s, m, h, W_ih, W_hh, ws, dm, dh, \
-                       dW_ih, dW_hh, db_ih, db_hh, V, H, rows_per_block)
-    if (H <= 24) MPNN_SMALL_TAIL(24);
-    else if (H <= 32) MPNN_SMALL_TAIL(32);
-    else MPNN_SMALL_TAIL(40);
-#undef MPNN_SMALL_TAIL
+#define MPNN_SMALL_BWD(NQ)                                                                                                    \
+    do {                                                                                                                      \
+        if (out_norm_k)                                                                                                       \
+            hipLaunchKernelGGL((gru_bwd_small_kernel<NQ, true>), dim3((unsigned)blocks), dim3(256), lds, s, dout, m, h, mask,  \
+                               W_ih, W_hh, saved, out_norm_k, dm, dh, dW_ih, dW_hh, db_ih, db_hh, V, H, rows_per_block);      \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((gru_bwd_small_kernel<NQ, false>), dim3((unsigned)blocks), dim3(256), lds, s, dout, m, h, mask, \
+                               W_ih, W_hh, saved, out_norm_k, dm, dh, dW_ih, dW_hh, db_ih, db_hh, V, H, rows_per_block);      \
+    } while (0)
+    if (H <= 24) MPNN_SMALL_BWD(24);
+    else if (H <= 32) MPNN_SMALL_BWD(32);
+    else MPNN_SMALL_BWD(40);
+#undef MPNN_SMALL_BWD
     return launch_status("mpnn_gru_update_bwd_f32(small width)");
 }
 

@@ -13,8 +13,11 @@ the ORIGINAL atom features; `hoist_message=True` computes message+aggregate once
 import torch
 from torch import nn
 
+from mpnn_amd import ops
 from mpnn_amd.graph import MolGraph
+from mpnn_amd.messages import EdgeMessages
 from mpnn_amd.mpnn_functions import AdjMsgAgg, EdgeNetwork, GraphLevelOutput, GRUUpdate
+from mpnn_amd.mpnn_functions.message_aggregators._common import adjacency_multiplier
 from ._batch import graph_of
 
 
@@ -34,6 +37,7 @@ class BasicModel(nn.Module):
         self.out_dim = output_dim
         self.iters = message_steps
         self.hoist_message = False
+        self.chain_updates = True          # False: T separate update nodes (what the tests compare the chain with)
         self.mf = message_func(**message_opts)
         self.ma = message_agg_func(**agg_opts)
         self.uf = update_func(**update_opts)
@@ -48,11 +52,35 @@ class BasicModel(nn.Module):
             self.mf.bind_graph(graph)
         node_state = afm
         agg = None
+        if self.chain_updates and self.iters > 0 and type(self.uf) is GRUUpdate and self.uf.mf == self.uf.nf:
+            # the messages first (they depend on the atom features only: every step computes its own, as the loop below), then
+            # the T updates as one autograd node (ops.GRUChain): the same kernels, one buffer of weight gradients for the T steps
+            aggs = self._messages_of_all_steps(afm, bfm, adj)
+            cell = self.uf.gru_cell
+            out = ops.gru_chain(afm.reshape(-1, self.uf.nf), aggs, mask.reshape(-1), cell.weight_ih, cell.weight_hh,
+                                cell.bias_ih, cell.bias_hh)
+            return out.view(afm.shape), graph
         for i in range(self.iters):
             if agg is None or not self.hoist_message:
                 agg = self.ma(self.mf(afm, bfm, reuse_graph_tensors=(i > 0)), adj)
             node_state = self.uf(agg, node_state, mask)
         return node_state, graph
+
+    def _messages_of_all_steps(self, afm, bfm, adj):
+        """[aggregated message of step 0, ..., step T-1], each (V, mf).  Every step launches its own message + sum (unless
+        `hoist_message`).  With the default operators (EdgeNetwork + AdjMsgAgg on lazy messages, constant atom features) the
+        T evaluations are one autograd node (ops.MessageAggregateSteps): their weight gradients share one buffer."""
+        T = 1 if self.hoist_message else self.iters
+        first = self.mf(afm, bfm, reuse_graph_tensors=False)
+        if (type(self.ma) is AdjMsgAgg and isinstance(first, EdgeMessages) and first._values is None
+                and first.recipe[1] is None and not first.h.requires_grad):
+            w = adjacency_multiplier(first, adj)
+            aggs = ops.message_aggregate_steps(first.h, first.recipe[0], first.graph, w, T)
+            aggs = [first.graph.node_unview(a) for a in aggs]
+        else:
+            aggs = [self.ma(first, adj)] + [self.ma(self.mf(afm, bfm, reuse_graph_tensors=True), adj) for _ in range(1, T)]
+        aggs = [a.reshape(-1, self.uf.mf) for a in aggs]
+        return aggs * self.iters if self.hoist_message else aggs
 
     def forward(self, afm, bfm, adj, mask):
         node_state, graph = self.message_passing(afm, bfm, adj, mask)

@@ -250,12 +250,13 @@ def message_aggregate_wide_gated_bwd_raw(h, A, z_atom, q, dout, fwd_ws, graph):
     return dA, dz, dq
 
 
-def edge_message_bwd_raw(h, A, graph, gate, dmsg, need_dx=True, need_dA=True):
+def edge_message_bwd_raw(h, A, graph, gate, dmsg, need_dx=True, need_dA=True, dA_accum=None):
+    """`dA_accum`: a (K, mf, nf) buffer the weight gradient is ADDED to (the kernels accumulate) instead of a fresh zero one."""
     lib = _lib.load()
     K, mf, nf = (int(s) for s in A.shape)
     E = graph.num_edges
     dx = _empty((E, nf), h) if need_dx else None
-    dA = torch.zeros_like(A) if need_dA else None
+    dA = (dA_accum if dA_accum is not None else torch.zeros_like(A)) if need_dA else None
     if E == 0 or not (need_dx or need_dA):
         return dx, dA
     _lib.check(lib.mpnn_edge_message_bwd_f32(_lib.fptr(h), _lib.fptr(A), _lib.iptr(graph.col_idx),
@@ -280,16 +281,22 @@ def gru_update_raw(m, h, mask, W_ih, W_hh, b_ih, b_hh, save):
     return out, saved
 
 
-def gru_update_bwd_raw(dout, m, h, mask, W_ih, W_hh, saved):
+def gru_weight_grad_buffers(H, like):
+    """(dW_ih, dW_hh, db_ih, db_hh) as views of ONE zero-filled buffer (one fill launch instead of four: the reference driver's
+    batches of 16 molecules are bound by the count of such launches); the backward kernels ACCUMULATE into them."""
+    nW, nb = (3 * H * H + 3) // 4 * 4, (3 * H + 3) // 4 * 4          # (every view starts on a 16-byte boundary)
+    zeros = torch.zeros(2 * nW + 2 * nb, dtype=torch.float32, device=like.device)
+    return (zeros[:3 * H * H].view(H, 3 * H), zeros[nW:nW + 3 * H * H].view(H, 3 * H),
+            zeros[2 * nW:2 * nW + 3 * H], zeros[2 * nW + nb:2 * nW + nb + 3 * H])
+
+
+def gru_update_bwd_raw(dout, m, h, mask, W_ih, W_hh, saved, accum=None):
+    """`accum`: gru_weight_grad_buffers of an earlier call -- this call's weight gradients are added to them (the T updates of
+    a model share their weights: one buffer instead of T buffers and T - 1 additions per parameter)."""
     lib = _lib.load()
     V, H = int(h.shape[0]), int(h.shape[1])
     dm, dh = _empty((V, H), h), _empty((V, H), h)
-    # the four accumulated outputs are views of ONE zero-filled buffer (one fill launch instead of four: the reference driver's
-    # batches of 16 molecules are bound by the count of such launches)
-    nW, nb = (3 * H * H + 3) // 4 * 4, (3 * H + 3) // 4 * 4          # (every view starts on a 16-byte boundary)
-    zeros = torch.zeros(2 * nW + 2 * nb, dtype=torch.float32, device=h.device)
-    dW_ih, dW_hh = zeros[:3 * H * H].view(H, 3 * H), zeros[nW:nW + 3 * H * H].view(H, 3 * H)
-    db_ih, db_hh = zeros[2 * nW:2 * nW + 3 * H], zeros[2 * nW + nb:2 * nW + nb + 3 * H]
+    dW_ih, dW_hh, db_ih, db_hh = accum if accum is not None else gru_weight_grad_buffers(H, h)
     ws_bytes = lib.mpnn_gru_bwd_workspace_bytes(V, H)
     ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=h.device)
     _lib.check(_timed("gru_update_bwd", lambda: lib.mpnn_gru_update_bwd_f32(
@@ -369,6 +376,57 @@ class EdgeMessage(torch.autograd.Function):
         return dh, (dA if ctx.needs_input_grad[1] else None), dgate, None
 
 
+def _message_aggregate_backward(h, A, gate, w, g, dout, needs, dA_accum=None):
+    """(dh, dA, dgate) of MessageAggregate for one incoming gradient; `needs` = needs_input_grad of (h, A, gate); `dA_accum`: a
+    zero-initialised (or partly summed) buffer the weight gradient is added to."""
+    dout = dout.contiguous()
+    need_dx = needs[0] or (gate is not None and needs[2])
+    K, mf, nf = (int(s) for s in A.shape)
+    fused_widths = (64, 128) if os.environ.get("MPNN_GRU_MATH") == "fp32" else (64, 128, 256)   # no fp32 twin at 256
+    if not need_dx and mf == nf and mf in fused_widths and K <= 64:
+        if not needs[1]:
+            return None, None, None
+        lib = _lib.load()
+        dA = dA_accum if dA_accum is not None else torch.zeros_like(A)
+        if g.num_edges:
+            _lib.check(_timed("message_aggregate_bwd", lambda: lib.mpnn_edge_message_agg_bwd_da_f32(
+                _lib.fptr(dout), _lib.fptr(h), _lib.iptr(g.col_idx), _lib.iptr(g.edge_dst), _lib.fptr(w),
+                _lib.iptr(g.order), _lib.iptr(g.type_ptr), _lib.fptr(gate), _lib.fptr(dA), g.num_nodes,
+                g.num_edges, K, nf, mf, _lib.stream())), "mpnn_edge_message_agg_bwd_da_f32")
+        return None, dA, None
+    if (gate is not None and needs[2] and not needs[0] and mf == nf
+            and mf in (64, 128) and K <= 64 and os.environ.get("MPNN_GRU_MATH") != "fp32"):
+        # attention models: the node features feeding the message are constants, only the gate (and A) want
+        # gradients -- both come straight from dout[dst(e)]; d(msg) and dx are never written
+        lib = _lib.load()
+        dA = (dA_accum if dA_accum is not None else torch.zeros_like(A)) if needs[1] else None
+        dgate = _empty((g.num_edges, nf), h)
+        if g.num_edges:
+            if dA is not None:
+                _lib.check(lib.mpnn_edge_message_agg_bwd_da_f32(
+                    _lib.fptr(dout), _lib.fptr(h), _lib.iptr(g.col_idx), _lib.iptr(g.edge_dst), _lib.fptr(w),
+                    _lib.iptr(g.order), _lib.iptr(g.type_ptr), _lib.fptr(gate), _lib.fptr(dA), g.num_nodes,
+                    g.num_edges, K, nf, mf, _lib.stream()), "mpnn_edge_message_agg_bwd_da_f32")
+            _lib.check(lib.mpnn_edge_message_agg_bwd_dgate_f32(
+                _lib.fptr(dout), _lib.fptr(A), _lib.fptr(h), _lib.iptr(g.col_idx), _lib.iptr(g.edge_dst), _lib.fptr(w),
+                _lib.iptr(g.order), _lib.iptr(g.type_ptr), _lib.fptr(dgate), g.num_nodes, g.num_edges, K, nf, mf,
+                _lib.stream()), "mpnn_edge_message_agg_bwd_dgate_f32")
+        return None, dA, dgate
+    dmsg = segsum_bwd_raw(dout, g.row_ptr, w, g.num_edges)
+    dx, dA = edge_message_bwd_raw(h, A, g, gate, dmsg, need_dx=need_dx, need_dA=needs[1], dA_accum=dA_accum)
+    if not need_dx:
+        return None, dA, None
+    t_row_ptr, t_eid = g.transpose
+    dgate = None
+    if gate is not None:
+        if needs[2]:
+            dgate = dx * h[g.col_idx.to(torch.int64)]
+        if needs[0]:
+            dx = dx * gate
+    dh = segsum_gather_raw(dx, t_row_ptr, t_eid, None, g.num_nodes) if needs[0] else None
+    return dh, dA, dgate
+
+
 class MessageAggregate(torch.autograd.Function):
     """out[i] = sum_{e in row i} w[e] * (A[type e] . (gate[e] * h[src e])) -- the edge message followed by
     the adjacency-weighted sum as ONE autograd node.  Forward launches the same two kernels as the
@@ -392,57 +450,49 @@ class MessageAggregate(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         h, A, gate, w = ctx.saved_tensors
-        g = ctx.graph
-        dout = dout.contiguous()
-        need_dx = ctx.needs_input_grad[0] or (gate is not None and ctx.needs_input_grad[2])
-        K, mf, nf = (int(s) for s in A.shape)
-        fused_widths = (64, 128) if os.environ.get("MPNN_GRU_MATH") == "fp32" else (64, 128, 256)   # no fp32 twin at 256
-        if not need_dx and mf == nf and mf in fused_widths and K <= 64:
-            if not ctx.needs_input_grad[1]:
-                return None, None, None, None, None
-            lib = _lib.load()
-            dA = torch.zeros_like(A)
-            if g.num_edges:
-                _lib.check(_timed("message_aggregate_bwd", lambda: lib.mpnn_edge_message_agg_bwd_da_f32(
-                    _lib.fptr(dout), _lib.fptr(h), _lib.iptr(g.col_idx), _lib.iptr(g.edge_dst), _lib.fptr(w),
-                    _lib.iptr(g.order), _lib.iptr(g.type_ptr), _lib.fptr(gate), _lib.fptr(dA), g.num_nodes,
-                    g.num_edges, K, nf, mf, _lib.stream())), "mpnn_edge_message_agg_bwd_da_f32")
-            return None, dA, None, None, None
-        if (gate is not None and ctx.needs_input_grad[2] and not ctx.needs_input_grad[0] and mf == nf
-                and mf in (64, 128) and K <= 64 and os.environ.get("MPNN_GRU_MATH") != "fp32"):
-            # attention models: the node features feeding the message are constants, only the gate (and A) want
-            # gradients -- both come straight from dout[dst(e)]; d(msg) and dx are never written
-            lib = _lib.load()
-            dA = torch.zeros_like(A) if ctx.needs_input_grad[1] else None
-            dgate = _empty((g.num_edges, nf), h)
-            if g.num_edges:
-                if dA is not None:
-                    _lib.check(lib.mpnn_edge_message_agg_bwd_da_f32(
-                        _lib.fptr(dout), _lib.fptr(h), _lib.iptr(g.col_idx), _lib.iptr(g.edge_dst), _lib.fptr(w),
-                        _lib.iptr(g.order), _lib.iptr(g.type_ptr), _lib.fptr(gate), _lib.fptr(dA), g.num_nodes,
-                        g.num_edges, K, nf, mf, _lib.stream()), "mpnn_edge_message_agg_bwd_da_f32")
-                _lib.check(lib.mpnn_edge_message_agg_bwd_dgate_f32(
-                    _lib.fptr(dout), _lib.fptr(A), _lib.fptr(h), _lib.iptr(g.col_idx), _lib.iptr(g.edge_dst), _lib.fptr(w),
-                    _lib.iptr(g.order), _lib.iptr(g.type_ptr), _lib.fptr(dgate), g.num_nodes, g.num_edges, K, nf, mf,
-                    _lib.stream()), "mpnn_edge_message_agg_bwd_dgate_f32")
-            return None, dA, dgate, None, None
-        dmsg = segsum_bwd_raw(dout, g.row_ptr, w, g.num_edges)
-        dx, dA = edge_message_bwd_raw(h, A, g, gate, dmsg, need_dx=need_dx, need_dA=ctx.needs_input_grad[1])
-        if not need_dx:
-            return None, dA, None, None, None
-        t_row_ptr, t_eid = g.transpose
-        dgate = None
-        if gate is not None:
-            if ctx.needs_input_grad[2]:
-                dgate = dx * h[g.col_idx.to(torch.int64)]
-            if ctx.needs_input_grad[0]:
-                dx = dx * gate
-        dh = segsum_gather_raw(dx, t_row_ptr, t_eid, None, g.num_nodes) if ctx.needs_input_grad[0] else None
-        return dh, dA, dgate, None, None
+        return _message_aggregate_backward(h, A, gate, w, ctx.graph, dout, ctx.needs_input_grad) + (None, None)
 
 
 def message_aggregate(h, A, graph, w=None, gate=None):
     return MessageAggregate.apply(h, A, gate, w, graph)
+
+
+class MessageAggregateSteps(torch.autograd.Function):
+    """T evaluations of MessageAggregate on the SAME (h, A) -- BasicModel computes its message from the constant atom features
+    at every step (basic_model.py:57) -- as one node: T forward launches, T weight-gradient launches, but the T gradients
+    are added inside the kernels into ONE zero-filled buffer instead of T buffers that autograd sums.  h carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, h, A, w, graph, steps):
+        h, A = h.contiguous(), A.contiguous()
+        ctx.graph, ctx.steps = graph, steps
+        ctx.save_for_backward(h, A, w)
+        outs = []
+        for _ in range(steps):
+            if tile_kernel_applies(A, None, w, graph):
+                outs.append(message_aggregate_tile_raw(h, A, graph))
+            elif wide_kernel_applies(A, None, w, graph):
+                outs.append(message_aggregate_wide_raw(h, A, graph))
+            else:
+                outs.append(segsum_raw(edge_message_raw(h, A, graph, None), graph.row_ptr, w, graph.num_nodes))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        h, A, w = ctx.saved_tensors
+        if not ctx.needs_input_grad[1]:
+            return None, None, None, None, None
+        dA = torch.zeros_like(A)
+        for dout in douts:
+            _message_aggregate_backward(h, A, None, w, ctx.graph, dout, (False, True, False), dA_accum=dA)
+        return None, dA, None, None, None
+
+
+def message_aggregate_steps(h, A, graph, w, steps):
+    """-> list of `steps` tensors, each out[i] = sum_{e in row i} w[e] * A[type e] . h[src e]; h must not require a gradient."""
+    if h.requires_grad:
+        return [message_aggregate(h, A, graph, w) for _ in range(steps)]
+    return list(MessageAggregateSteps.apply(h, A, w, graph, steps))
 
 
 BN_MASKED_MEAN, BN_EPS_INSIDE, BN_USE_STATS = 1, 2, 4
@@ -1181,3 +1231,43 @@ def edge_message(h, A, graph, gate=None):
 
 def gru_update(m, h, mask, W_ih, W_hh, b_ih, b_hh):
     return GRUUpdateFn.apply(m, h, mask, W_ih, W_hh, b_ih, b_hh, torch.is_grad_enabled())
+
+
+class GRUChain(torch.autograd.Function):
+    """h_T of h_{t+1} = update(msgs[t], h_t), t = 0 .. T-1, with ONE set of weights (basic_model.py:57-59: the T steps of a model
+    call the same GRUUpdate).  The same kernels as T separate updates; as one node the backward adds the T weight gradients
+    into one zero-filled buffer inside the kernels instead of handing autograd T tensors per parameter to sum."""
+
+    @staticmethod
+    def forward(ctx, h0, mask, W_ih, W_hh, b_ih, b_hh, grad_mode, *msgs):
+        mask = mask.contiguous() if mask is not None else None
+        Wc = [t.contiguous() for t in (W_ih, W_hh, b_ih, b_hh)]
+        need = grad_mode and any(ctx.needs_input_grad)
+        h = h0.contiguous()
+        keep = []
+        for m in msgs:
+            m = m.contiguous()
+            out, saved = gru_update_raw(m, h, mask, *Wc, need)
+            keep += [m, h, saved]
+            h = out
+        if need:
+            ctx.save_for_backward(mask, Wc[0], Wc[1], *keep)
+        ctx.steps = len(msgs)
+        return h
+
+    @staticmethod
+    def backward(ctx, dout):
+        mask, W_ih, W_hh = ctx.saved_tensors[:3]
+        keep = ctx.saved_tensors[3:]
+        T = ctx.steps
+        acc = gru_weight_grad_buffers(int(W_hh.shape[0]), dout)
+        dh = dout.contiguous()
+        dms = [None] * T
+        for t in reversed(range(T)):
+            m, h, saved = keep[3 * t:3 * t + 3]
+            dms[t], dh, *_ = gru_update_bwd_raw(dh, m, h, mask, W_ih, W_hh, saved, accum=acc)
+        return (dh, None, acc[0], acc[1], acc[2], acc[3], None, *dms)
+
+
+def gru_chain(h0, msgs, mask, W_ih, W_hh, b_ih, b_hh):
+    return GRUChain.apply(h0, mask, W_ih, W_hh, b_ih, b_hh, torch.is_grad_enabled(), *msgs)
