@@ -36,6 +36,10 @@ def main():
     for w in workloads:
         pre = os.path.join(G, "w_%s" % w)
         commit = open(pre + "_commit.txt").read().strip() if os.path.exists(pre + "_commit.txt") else None
+        if not commit:
+            # the GPU box gets a snapshot of the working tree without .git: the commit is the local HEAD the snapshot was
+            # taken from (run this script before committing anything else)
+            commit = subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip() or None
         bench = None
         if os.path.exists(pre + "_bench.log"):
             lines = [x for x in open(pre + "_bench.log") if x.startswith("{")]
