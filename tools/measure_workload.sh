@@ -2,8 +2,8 @@
 # One workload's full measurement set on the GPU box (run through gpurun): the bench line, rocprofv3 kernel statistics of
 # the same command, the HBM-traffic PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs) and one SQ counter pass.
 # Everything lands in gpurun_out/w_<workload>_*; afterwards, on the build machine,
-#     python tools/write_profiles.py r03 <workloads...>
-# copies the summaries into profiles/r03_*.  (measure_all.sh / refresh_profiles.py are round 2's writers.)
+#     python tools/write_profiles.py r04 <workloads...>
+# copies the summaries into profiles/r04_*.
 #   usage: bash tools/measure_workload.sh <workload> [bench|stats|pmc|sq ...]   (default: all four)
 set -e
 cd "${GRAFT_REPO_ROOT:-.}"

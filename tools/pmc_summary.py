@@ -5,7 +5,7 @@ MI355X_MICROARCH.md "HBM": counters are in KiB; FETCH_SIZE reports exactly half 
 (16 B/lane) coalesced read stream, WRITE_SIZE is exact for 16-B-per-lane stores.
 
     python tools/pmc_summary.py gpurun_out/m_fetch gpurun_out/m_write profiles/r02_pmc_c2.json [commit]
-(called by tools/refresh_profiles.py, the only writer of profiles/r02_pmc_*.json)
+(used by tools/write_profiles.py)
 """
 import csv
 import glob
