@@ -536,8 +536,6 @@ __device__ __attribute__((noinline)) void gru_rc_dx_consumer(const RcDxCtx& c) {
         if (st + 1 == NSTEP) {
             // ---- epilogue: this lane's atom, 16 x 4 consecutive features of dm and of dh
             const int64_t t = tile_of(rd);
-            const int64_t row = row_of(t);
-            const bool on = t * 32 + a < V;
             const float un = r_pow2(e_note - 11) * inv_sw;                     // 1 / (sg * sw)
             {
                 // A lane holds 4 x 4 consecutive features of ITS atom per block: stored from here an instruction would touch 32
@@ -554,39 +552,53 @@ __device__ __attribute__((noinline)) void gru_rc_dx_consumer(const RcDxCtx& c) {
 #pragma unroll
                     for (int nb = 0; nb < 4; ++nb) {
                         const f32x16& d = mat ? d_h[nb] : d_m[nb];
+                        // NORM_IN: the column sums over the tile's atoms of dh and dh * y_in ride on the row layout the block
+                        // leaves in: a lane adds its four rows in registers, the eight lanes of a column group meet in three
+                        // steps (as a butterfly over the 32 lanes of every accumulator entry this was 640 ds_bpermute per
+                        // tile and +1.7 ms per launch at c3's size); y_in is requested here, whole lines, ahead of the round trip
+                        f32x4 yv[4];
+                        if (NORM_IN && mat == 1) {
+                            const float* py = y_in + 128 * slice + 32 * nb + 4 * ch;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const int64_t gr = t * 32 + rr + 8 * k;    // (a block's last round can hold tiles past V: clamped,
+                                yv[k] = *reinterpret_cast<const f32x4*>(py + (gr < V ? gr : V - 1) * H);   // and not summed below)
+                            }
+                        }
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const f32x4 v = {d[4 * q] * un, d[4 * q + 1] * un, d[4 * q + 2] * un, d[4 * q + 3] * un};
                             *reinterpret_cast<f32x4*>(epi + a * 144 + (8 * q + 4 * hi) * 4) = v;
                         }
                         float* po = (mat ? dh : dm) + (t * 32) * H + 128 * slice + 32 * nb + 4 * ch;
+                        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const int r = rr + 8 * k;
                             const f32x4 v = *reinterpret_cast<const f32x4*>(epi + r * 144 + ch * 16);
-                            if (t * 32 + r < V) *reinterpret_cast<f32x4*>(po + (int64_t)r * H) = v;
+                            if (t * 32 + r < V) {
+                                *reinterpret_cast<f32x4*>(po + (int64_t)r * H) = v;
+                                if (NORM_IN && mat == 1) {
+                                    s1 += v;
+                                    s2 += v * yv[k];
+                                }
+                            }
                         }
-                    }
-            }
-            if (NORM_IN) {
-                // column sums over the tile's atoms of dh and dh * y_in: per accumulator entry a butterfly over the 32 lanes
-                // of the half, then one LDS add per feature
-                const float uz = on ? un : 0.0f;
-                const float* py = y_in + row * H + 128 * slice + 4 * hi;
+                        if (NORM_IN && mat == 1) {
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 yv = *reinterpret_cast<const f32x4*>(py + 32 * nb + 8 * q);
-#pragma unroll
-                        for (int t4 = 0; t4 < 4; ++t4) {
-                            float s1 = d_h[nb][4 * q + t4] * uz, s2 = s1 * yv[t4];
-#pragma unroll
-                            for (int o = 16; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-                            if (a == 0) {
-                                const int f = 32 * nb + 8 * q + 4 * hi + t4;
-                                atomicAdd(&stat_s[f], (double)s1);
-                                atomicAdd(&stat_s[128 + f], (double)s2);
+                            for (int j = 0; j < 4; ++j) {
+                                float x1 = s1[j], x2 = s2[j];
+                                x1 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x1), 0x128, 0xf, 0xf, true));   // row_ror:8 = lane ^ 8
+                                x2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x2), 0x128, 0xf, 0xf, true));
+                                x1 += __shfl_xor(x1, 16);
+                                x2 += __shfl_xor(x2, 16);
+                                x1 += __shfl_xor(x1, 32);
+                                x2 += __shfl_xor(x2, 32);
+                                if (rr == 0) {
+                                    const int f = 32 * nb + 4 * ch + j;
+                                    atomicAdd(&stat_s[f], (double)x1);
+                                    atomicAdd(&stat_s[128 + f], (double)x2);
+                                }
                             }
                         }
                     }
