@@ -37,9 +37,10 @@ def main():
         pre = os.path.join(G, "w_%s" % w)
         commit = open(pre + "_commit.txt").read().strip() if os.path.exists(pre + "_commit.txt") else None
         if not commit:
-            # the GPU box gets a snapshot of the working tree without .git: the commit is the local HEAD the snapshot was
-            # taken from (run this script before committing anything else)
-            commit = subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip() or None
+            # the GPU box gets a snapshot of the working tree without .git: the commit is the last local one that touches the
+            # code the snapshot ran (run this script before committing further code changes)
+            commit = subprocess.run(["git", "log", "-1", "--format=%H", "--", "mpnn_amd", "bench.py", "include"], cwd=ROOT,
+                                    capture_output=True, text=True).stdout.strip() or None      # the last commit that touches code
         bench = None
         if os.path.exists(pre + "_bench.log"):
             lines = [x for x in open(pre + "_bench.log") if x.startswith("{")]
